@@ -1,0 +1,61 @@
+"""ctypes binding of libpesr_hip.so (C ABI declared in include/pesr_hip.h).
+
+The product path has no fallback: if the shared object is missing or a symbol is absent this
+module raises at import time of the first op, loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpesr_hip.so")
+
+_P = c_void_p  # every device pointer / stream crosses the ABI as void*
+
+# name -> (restype, argtypes); must mirror include/pesr_hip.h (tests/test_abi.py checks the symbol list)
+SIGNATURES = {
+    "pesr_abi_version": (c_int, []),
+    "pesr_pack_conv3x3": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pesr_pack_bias_ps": (c_int, [_P, _P, c_int, _P]),
+    "pesr_conv3x3_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                 c_float, c_int, _P]),
+    "pesr_conv3x3_dgrad": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "pesr_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pesr_conv3x3_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P,
+                                   c_size_t, _P]),
+}
+
+_lib = None
+
+
+class PesrHipError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PesrHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m pesr_amd.build` "
+                "(or __graft_entry__.build()). pesr_amd has no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError as e:  # pragma: no cover
+                raise PesrHipError(f"libpesr_hip.so lacks symbol {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = {-1: "PESR_EINVAL (unsupported shape/argument)", -2: "PESR_EWORKSPACE (workspace too small)"}.get(
+            rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")
+        raise PesrHipError(f"{what} failed: {kind}")

@@ -1,0 +1,352 @@
+// 3x3 convolution as implicit GEMM on the fp32-input MFMA (v_mfma_f32_16x16x4_f32), gfx950.
+//
+// Replaces the reference's nn.Conv2d(k=3, padding=1, stride in {1,2}) forward
+// (reference model/basic.py:4-7) and, with tap-flipped / transposed packed weights, its
+// input-gradient (dgrad).  Layout: activations NHWC fp32, weights pre-packed by pack.hip into
+// [tap][Cin/16][Cout][16] so that one (tap, 16-channel chunk) "slab" is one contiguous block.
+//
+// Work decomposition (one workgroup = one tile of MT output pixels x BN output channels):
+//   * the (TH x TW) pixel tile's input halo for one 16-channel chunk sits in LDS ([pixel][16ch],
+//     64 B per pixel) and is reused by all taps; it is double buffered across chunks;
+//   * one weight slab [BN][16] per (chunk, tap) sits in LDS, double buffered across slabs;
+//   * every lane feeds 4 consecutive k-steps of the MFMA from ONE ds_read_b128 per operand:
+//     lane l holds A[pixel = l&15][k = l>>4]; we let MFMA k-slot g of step kk stand for channel
+//     4*g + kk of the chunk, so the lane's four A values (and four B values) are contiguous.
+//   * global -> LDS staging goes through registers, issued one slab ahead (loads before the MFMA
+//     block, ds_write after it), one barrier per slab.
+// fp32 MFMA is an exact k-ordered fmaf chain, so results differ from a CPU conv only by
+// summation order.
+#include "common.h"
+#include "launchers.h"
+
+struct ConvArgs {
+    const float* x;     // [N][H][W][Cin]
+    const float* wp;    // packed weights [9][Cin/16][Cout][16]
+    const float* bias;  // [Cout] or null
+    const float* skip;  // [N][OH][OW][Cout] or null : added after scaling
+    const float* mask;  // [N][OH][OW][Cout] or null : result zeroed where mask <= 0
+    float* y;           // [N][OH][OW][Cout]
+    int N, H, W, Cin, Cout, OH, OW;
+    int GH, GW;                 // iteration domain per image (== OH, OW for a plain conv)
+    int TH, TW, tiles_x, tiles_y, n_tiles;
+    int in_oy, in_ox;           // halo origin in the input = g0*S + in_o
+    int HT, WT;                 // halo tile extent (rows, cols)
+    int out_my, out_ay, out_mx, out_ax;  // output coordinate = g*out_m + out_a
+    int ntaps;
+    int tap_dy[9], tap_dx[9];   // position of the tap inside the halo tile
+    int tap_w[9];               // tap index into the packed weights
+    float alpha, slope;
+    int act;
+    int ps;                     // 1: output channels are stored pixel-shuffled (r=2), Cout = 4*C
+    int ps_in;                  // 1: x is a pixel-shuffled tensor [N][2H][2W][Cin/4] read as its
+                                //    un-shuffled, sub-pixel-major [N][H][W][Cin] view (dgrad of a PS conv)
+};
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(const ConvArgs a) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int BN = WAVES_N * WN * 16;
+    constexpr int WL = (BN * 4 + NT - 1) / NT;  // float4 units per thread per weight slab
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int halo_pix = a.HT * a.WT;
+    const int halo_bytes = ((halo_pix * 64 + 255) / 256) * 256;
+    char* const halo0 = smem;
+    char* const halo1 = smem + halo_bytes;
+    char* const wb0 = smem + 2 * halo_bytes;
+    char* const wb1 = wb0 + BN * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int r = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int nt = bid % a.n_tiles;  bid /= a.n_tiles;
+    const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int gy0 = ty * a.TH, gx0 = tx * a.TW;
+    const int n0 = nt * BN;
+    const int C16 = a.Cin >> 4;
+
+    // per-lane LDS offsets of the A (pixel) and B (channel) fragments
+    int a_off[WM], b_off[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int m = (wave_m * WM + i) * 16 + r;
+        const int py = m / a.TW, px = m - py * a.TW;
+        a_off[i] = ((py * S) * a.WT + px * S) * 64 + g * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b_off[j] = ((wave_n * WN + j) * 16 + r) * 64 + g * 16;
+
+    // halo staging bookkeeping: element offset of this thread's float4 units inside the image
+    const float* const xi = a.x + (size_t)img * a.H * a.W * a.Cin;
+    int h_src[HL];
+#pragma unroll
+    for (int k = 0; k < HL; ++k) {
+        const int e = tid + k * NT;
+        const int hp = e >> 2, q = e & 3;
+        int off = -2;
+        if (hp < halo_pix) {
+            const int hy = hp / a.WT, hx = hp - hy * a.WT;
+            const int iy = gy0 * S + a.in_oy + hy, ix = gx0 * S + a.in_ox + hx;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                off = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * (a.Cin >> 2) + q * 4 : (iy * a.W + ix) * a.Cin + q * 4;
+            else
+                off = -1;
+        }
+        h_src[k] = off;
+    }
+    const float* const wn = a.wp + (size_t)n0 * 16;
+    const size_t slab_stride = (size_t)a.Cout * 16;  // floats between consecutive (tap, chunk) slabs
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 hreg[HL], wreg[WL];
+
+    auto load_halo = [&](int c) {
+        int coff = c * 16;
+        if (a.ps_in) {  // chunk c covers packed channels (2*si+sj)*C + cc0 .. +15
+            const int C = a.Cin >> 2;
+            const int sub = coff / C, cc0 = coff - sub * C;
+            coff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * C + cc0;
+        }
+#pragma unroll
+        for (int k = 0; k < HL; ++k) {
+            const int o = h_src[k] < 0 ? 0 : h_src[k];
+            f32x4 v = *(const f32x4*)(xi + o + coff);
+            hreg[k] = h_src[k] >= 0 ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_halo = [&](char* hb) {
+#pragma unroll
+        for (int k = 0; k < HL; ++k)
+            if (h_src[k] != -2) *(f32x4*)(hb + (tid + k * NT) * 16) = hreg[k];
+    };
+    auto load_w = [&](int c, int tw) {
+        const float* src = wn + ((size_t)tw * C16 + c) * slab_stride;
+#pragma unroll
+        for (int k = 0; k < WL; ++k) {
+            const int e = tid + k * NT;
+            if (BN * 4 % NT == 0 || e < BN * 4) wreg[k] = *(const f32x4*)(src + e * 4);
+        }
+    };
+    auto store_w = [&](char* wb) {
+#pragma unroll
+        for (int k = 0; k < WL; ++k) {
+            const int e = tid + k * NT;
+            if (BN * 4 % NT == 0 || e < BN * 4) *(f32x4*)(wb + e * 16) = wreg[k];
+        }
+    };
+
+    // prologue: chunk 0 halo + slab (chunk 0, tap 0)
+    load_halo(0);
+    load_w(0, a.tap_w[0]);
+    store_halo(halo0);
+    store_w(wb0);
+    __syncthreads();
+
+    int s = 0;
+#pragma unroll 1
+    for (int c = 0; c < C16; ++c) {
+        const char* const hb = (c & 1) ? halo1 : halo0;
+        char* const hb_next = (c & 1) ? halo0 : halo1;
+        const bool halo_next = (c + 1 < C16);
+#pragma unroll 1
+        for (int t = 0; t < a.ntaps; ++t, ++s) {
+            const char* const wb = (s & 1) ? wb1 : wb0;
+            char* const wb_next = (s & 1) ? wb0 : wb1;
+            // prefetch the next slab (wraps to a harmless re-read at the very end)
+            int tn = t + 1, cn = c;
+            if (tn == a.ntaps) { tn = 0; cn = c + 1; }
+            if (cn == C16) { cn = 0; }
+            load_w(cn, a.tap_w[tn]);
+            if (t == 0 && halo_next) load_halo(c + 1);
+
+            const int toff = (a.tap_dy[t] * a.WT + a.tap_dx[t]) * 64;
+            f32x4 av[WM], bv[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[i] = *(const f32x4*)(hb + a_off[i] + toff);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[j] = *(const f32x4*)(wb + b_off[j]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
+
+            store_w(wb_next);
+            if (t == 0 && halo_next) store_halo(hb_next);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D layout of the 16x16 tile: col = lane&15 (channel), row = (lane>>4)*4 + reg (pixel)
+    const size_t img_out = (size_t)img * a.OH * a.OW;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = (wave_m * WM + i) * 16 + g * 4 + jj;
+            const int py = m / a.TW, px = m - py * a.TW;
+            const int gy = gy0 + py, gx = gx0 + px;
+            if (gy >= a.GH || gx >= a.GW) continue;
+            const int oy = gy * a.out_my + a.out_ay, ox = gx * a.out_mx + a.out_ax;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int co = n0 + (wave_n * WN + j) * 16 + r;
+                float v = acc[i][j][jj];
+                if (a.bias) v += a.bias[co];
+                v *= a.alpha;
+                size_t idx;
+                if (a.ps) {
+                    // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
+                    const int C = a.Cout >> 2;
+                    const int sub = co / C, cc = co - sub * C;
+                    idx = (((size_t)img * (2 * a.OH) + 2 * oy + (sub >> 1)) * (2 * a.OW) + 2 * ox + (sub & 1)) * C + cc;
+                } else {
+                    idx = (img_out + (size_t)oy * a.OW + ox) * a.Cout + co;
+                }
+                if (a.mask) v = a.mask[idx] > 0.f ? v : 0.f;
+                if (a.skip) v += a.skip[idx];
+                if (a.act == PESR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                else if (a.act == PESR_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+                a.y[idx] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct TileChoice { int TH, TW; };
+
+// pick (TH, TW) with TH*TW == MT minimising wasted (out-of-image) tile area, subject to the halo
+// fitting the per-thread staging registers (HL float4 per thread) and the LDS budget.
+static bool choose_tile(int MT, int S, int hext, int wext, int GH, int GW, int max_halo_pix, TileChoice* out) {
+    long best = -1;
+    for (int TW = 1; TW <= MT; ++TW) {
+        if (MT % TW) continue;
+        const int TH = MT / TW;
+        const int HTl = (TH - 1) * S + hext, WTl = (TW - 1) * S + wext;
+        if ((long)HTl * WTl > max_halo_pix) continue;
+        const long cover = (long)pesr_cdiv(GH, TH) * TH * pesr_cdiv(GW, TW) * TW;
+        // prefer less waste, then the smaller halo
+        const long score = cover * 4096 + (long)HTl * WTl;
+        if (best < 0 || score < best) { best = score; out->TH = TH; out->TW = TW; }
+    }
+    return best >= 0;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL>
+static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int MT = WAVES_M * WM * 16;
+    constexpr int BN = WAVES_N * WN * 16;
+    if (a.Cout % BN) return PESR_EINVAL;
+    TileChoice tc;
+    const int max_halo = (HL * NT) / 4;
+    if (!choose_tile(MT, S, hext, wext, a.GH, a.GW, max_halo, &tc)) return PESR_EINVAL;
+    a.TH = tc.TH; a.TW = tc.TW;
+    a.HT = (a.TH - 1) * S + hext; a.WT = (a.TW - 1) * S + wext;
+    a.tiles_y = pesr_cdiv(a.GH, a.TH); a.tiles_x = pesr_cdiv(a.GW, a.TW);
+    a.n_tiles = a.Cout / BN;
+    const int halo_bytes = ((a.HT * a.WT * 64 + 255) / 256) * 256;
+    const size_t lds = 2 * (size_t)halo_bytes + 2 * (size_t)BN * 64;
+    if (lds > 160 * 1024) return PESR_EINVAL;
+    auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL>;
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long grid = (long)a.N * a.tiles_y * a.tiles_x * a.n_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    return pesr_launch_status();
+}
+
+// choose the tile configuration from the channel count and the amount of parallel work
+template <int S>
+static int dispatch(ConvArgs& a, int hext, int wext, hipStream_t stream) {
+    const long M = (long)a.N * a.GH * a.GW;
+    if (a.Cout % 256 == 0) {
+        // enough tiles to fill 256 CUs with the big tile?
+        const long tiles_big = (M / 144) * (a.Cout / 256);
+        if (tiles_big >= 192) return launch_cfg<1, 8, 9, 2, S, (S == 1 ? 2 : 6)>(a, hext, wext, stream);
+    }
+    if (a.Cout % 128 == 0) {
+        const long tiles = (M / 144) * (a.Cout / 128);
+        if (tiles >= 192) return launch_cfg<1, 8, 9, 1, S, (S == 1 ? 2 : 6)>(a, hext, wext, stream);
+    }
+    if (a.Cout % 64 == 0) return launch_cfg<1, 4, 9, 1, S, (S == 1 ? 4 : 11)>(a, hext, wext, stream);
+    return PESR_EINVAL;
+}
+
+}  // namespace
+
+// Plain conv (forward).  Also serves the stride-1 dgrad when given dgrad-packed weights
+// (pack.hip mode 1: Cin/Cout swapped) and flip=1 (tap t reads weight tap 8-t).
+int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask,
+                        float* y, int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act,
+                        float slope, int ps, int ps_in, int flip, hipStream_t stream) {
+    if (ps_in && (Cin % 64 || stride != 1)) return PESR_EINVAL;
+    if (ps && Cout % 4) return PESR_EINVAL;
+    if (Cin % 16 || (stride != 1 && stride != 2) || N <= 0 || H <= 0 || W <= 0) return PESR_EINVAL;
+    ConvArgs a{};
+    a.x = x; a.wp = wp; a.bias = bias; a.skip = skip; a.mask = mask; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
+    a.GH = a.OH; a.GW = a.OW;
+    a.in_oy = -1; a.in_ox = -1;
+    a.out_my = 1; a.out_ay = 0; a.out_mx = 1; a.out_ax = 0;
+    a.ntaps = 9;
+    for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3; a.tap_dx[t] = t % 3; a.tap_w[t] = flip ? 8 - t : t; }
+    a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
+    return stride == 1 ? dispatch<1>(a, 3, 3, stream) : dispatch<2>(a, 3, 3, stream);
+}
+
+// Input gradient of a stride-2 3x3 conv (pad 1): dx[y][x] = sum over taps with (y+1-ky), (x+1-kx)
+// even of dy[(y+1-ky)/2][(x+1-kx)/2] * W[ky][kx].  The four output parity classes (y&1, x&1) are
+// four small stride-1 problems over dy with 1, 2, 2 and 4 taps - no multiply-by-zero work.
+// wp is the dgrad packing (pack.hip mode 1; tap index = ky*3+kx of the forward weights).
+int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* mask, float* dx, int N, int H, int W,
+                                 int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream) {
+    // H, W: spatial size of dx (the forward input); dy is [N][OH][OW][Cout_fwd]
+    if (Cout_fwd % 16) return PESR_EINVAL;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            ConvArgs a{};
+            a.x = dy; a.wp = wp; a.bias = nullptr; a.skip = nullptr; a.mask = mask; a.y = dx;
+            a.N = N; a.H = OH; a.W = OW; a.Cin = Cout_fwd; a.Cout = Cin_fwd;
+            a.OH = H; a.OW = W;
+            a.GH = (H - py + 1) / 2; a.GW = (W - px + 1) / 2;  // number of u with 2u+py < H
+            if (a.GH <= 0 || a.GW <= 0) continue;
+            a.in_oy = 0; a.in_ox = 0;
+            a.out_my = 2; a.out_ay = py; a.out_mx = 2; a.out_ax = px;
+            // rows: py==0 -> ky=1 reads dy row u ; py==1 -> ky=0 reads u+1, ky=2 reads u
+            int kys[2], dys[2], nky, kxs[2], dxs[2], nkx;
+            if (py == 0) { nky = 1; kys[0] = 1; dys[0] = 0; } else { nky = 2; kys[0] = 0; dys[0] = 1; kys[1] = 2; dys[1] = 0; }
+            if (px == 0) { nkx = 1; kxs[0] = 1; dxs[0] = 0; } else { nkx = 2; kxs[0] = 0; dxs[0] = 1; kxs[1] = 2; dxs[1] = 0; }
+            a.ntaps = 0;
+            for (int i = 0; i < nky; ++i)
+                for (int j = 0; j < nkx; ++j) {
+                    a.tap_dy[a.ntaps] = dys[i]; a.tap_dx[a.ntaps] = dxs[j]; a.tap_w[a.ntaps] = kys[i] * 3 + kxs[j];
+                    ++a.ntaps;
+                }
+            a.alpha = alpha; a.slope = 0.f; a.act = PESR_ACT_NONE; a.ps = 0;
+            const int rc = dispatch<1>(a, py + 1, px + 1, stream);
+            if (rc) return rc;
+        }
+    return PESR_OK;
+}

@@ -1,0 +1,342 @@
+// Weight gradient of the 3x3 conv (pad 1, stride 1|2) on the fp32-input MFMA, gfx950.
+//
+// Stands in for ATen convolution_backward's grad_weight for the reference `Conv`
+// (reference model/basic.py:4-7), reached from loss.backward() in reference train.py:172,228,258.
+//   dw[co][ci][ky][kx] = alpha * sum_{n,oy,ox} dy[n][oy][ox][co] * x[n][oy*S+ky-1][ox*S+kx-1][ci]
+// GEMM view: M = Cout, N = 9*Cin, K = pixels.  The reduction runs over pixels, the slow dimension of
+// both NHWC operands, so fragments are read with ds_read_b32 (16 consecutive channels per MFMA row
+// group, 4 consecutive pixels as the 4 k-slots).
+//
+// One workgroup owns a (CO_T = 32*COW) x (CI_T = 64) x 9-tap block of dw in registers (8 waves x 36 or
+// 18 accumulator tiles) and sweeps a contiguous range of output-row segments (TWO pixels each); per
+// segment the 3-row input halo and the dy row segment are staged through registers into LDS (double
+// buffered, one barrier per segment).  Split-K partial blocks go to a workspace slab and a second
+// kernel reduces them in a fixed order (bitwise reproducible, no atomics) into the OIHW parameter
+// layout, applying alpha and the pixel-shuffle channel un-permutation.
+#include "common.h"
+#include "launchers.h"
+
+struct WgradArgs {
+    const float* x;    // [N][H][W][Cin]
+    const float* dy;   // [N][OH][OW][Cout]   (or shuffled [N][2OH][2OW][Cout/4] when ps_in)
+    float* slab;       // [split][9][Cout][Cin]
+    int N, H, W, Cin, Cout, OH, OW;
+    int segs_x;        // segments per output row
+    int total_segs;    // N*OH*segs_x
+    int segs_per_split;
+    int co_tiles, ci_tiles;
+    int ps_in;
+};
+
+template <int COW, int S, int TWO>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
+    constexpr int NT = 512;
+    constexpr int CO_T = 32 * COW;
+    constexpr int CI_T = 64;
+    constexpr int TWX = (TWO - 1) * S + 3;          // halo columns
+    constexpr int XPAD = (S == 1) ? 16 : 8;         // keeps the two pixel rows of a b32 read on different bank halves
+    constexpr int XS = CI_T + XPAD;                 // floats per halo pixel in LDS
+    constexpr int DS = CO_T + 16;                   // floats per dy pixel in LDS
+    constexpr int X_F4 = 3 * TWX * (CI_T / 4);      // float4 units of one halo segment
+    constexpr int D_F4 = TWO * (CO_T / 4);
+    constexpr int XL = (X_F4 + NT - 1) / NT;
+    constexpr int DL = (D_F4 + NT - 1) / NT;
+    constexpr int X_FLOATS = 3 * TWX * XS;
+    constexpr int BUF_FLOATS = X_FLOATS + TWO * DS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int ci_tile = wave & 3, co_half = wave >> 2;
+
+    int bid = blockIdx.x;
+    const int cit = bid % a.ci_tiles;  bid /= a.ci_tiles;
+    const int cot = bid % a.co_tiles;
+    const int sp = bid / a.co_tiles;
+    const int ci0 = cit * CI_T, co0 = cot * CO_T;
+
+    const int seg_begin = sp * a.segs_per_split;
+    int seg_end = seg_begin + a.segs_per_split;
+    if (seg_end > a.total_segs) seg_end = a.total_segs;
+
+    f32x4 acc[9][COW];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < COW; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xreg[XL], dreg[DL];
+
+    // dy channel base for this workgroup's co tile (ps_in: packed channel p = sub*C + cc)
+    int d_sub = 0, d_cc0 = co0, d_C = a.Cout;
+    if (a.ps_in) { d_C = a.Cout >> 2; d_sub = co0 / d_C; d_cc0 = co0 - d_sub * d_C; }
+
+    auto load_seg = [&](int seg) {
+        const int xs = seg % a.segs_x;
+        const int rowid = seg / a.segs_x;
+        const int oy = rowid % a.OH, img = rowid / a.OH;
+        const int ox0 = xs * TWO;
+        const float* xi = a.x + (size_t)img * a.H * a.W * a.Cin;
+#pragma unroll
+        for (int k = 0; k < XL; ++k) {
+            const int e = tid + k * NT;
+            const int q = e % (CI_T / 4);
+            const int pix = e / (CI_T / 4);
+            const int hx = pix % TWX, hy = pix / TWX;
+            const int iy = oy * S - 1 + hy, ix = ox0 * S - 1 + hx;
+            const bool ok = (e < X_F4) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const size_t off = ok ? ((size_t)iy * a.W + ix) * a.Cin + ci0 + q * 4 : 0;
+            f32x4 v = *(const f32x4*)(xi + off);
+            xreg[k] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < DL; ++k) {
+            const int e = tid + k * NT;
+            const int q = e % (CO_T / 4);
+            const int px = e / (CO_T / 4);
+            const int ox = ox0 + px;
+            const bool ok = (e < D_F4) && ox < a.OW;
+            size_t off = 0;
+            if (ok) {
+                if (a.ps_in)
+                    off = (((size_t)img * (2 * a.OH) + 2 * oy + (d_sub >> 1)) * (2 * a.OW) + 2 * ox + (d_sub & 1)) * d_C + d_cc0 + q * 4;
+                else
+                    off = (((size_t)img * a.OH + oy) * a.OW + ox) * a.Cout + co0 + q * 4;
+            }
+            f32x4 v = *(const f32x4*)(a.dy + off);
+            dreg[k] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_seg = [&](float* buf) {
+#pragma unroll
+        for (int k = 0; k < XL; ++k) {
+            const int e = tid + k * NT;
+            if (X_F4 % NT == 0 || e < X_F4) {
+                const int q = e % (CI_T / 4), pix = e / (CI_T / 4);
+                *(f32x4*)(buf + pix * XS + q * 4) = xreg[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DL; ++k) {
+            const int e = tid + k * NT;
+            if (D_F4 % NT == 0 || e < D_F4) {
+                const int q = e % (CO_T / 4), px = e / (CO_T / 4);
+                *(f32x4*)(buf + X_FLOATS + px * DS + q * 4) = dreg[k];
+            }
+        }
+    };
+
+    if (seg_begin < seg_end) {
+        load_seg(seg_begin);
+        store_seg(lds);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int seg = seg_begin; seg < seg_end; ++seg) {
+        const int par = (seg - seg_begin) & 1;
+        const float* buf = lds + par * BUF_FLOATS;
+        float* nbuf = lds + (par ^ 1) * BUF_FLOATS;
+        const bool more = seg + 1 < seg_end;
+        if (more) load_seg(seg + 1);
+
+        const float* xb = buf + ci_tile * 16 + r;
+        const float* db = buf + X_FLOATS + (co_half * COW) * 16 + r;
+#pragma unroll 2
+        for (int k4 = 0; k4 < TWO / 4; ++k4) {
+            const int px = k4 * 4 + g;
+            float av[COW], bv[9];
+#pragma unroll
+            for (int i = 0; i < COW; ++i) av[i] = db[px * DS + i * 16];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bv[t] = xb[((t / 3) * TWX + px * S + (t % 3)) * XS];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < COW; ++i)
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[t][i], 0, 0, 0);
+        }
+        if (more) store_seg(nbuf);
+        __syncthreads();
+    }
+
+    // slab[sp][t][co][ci]: D tile row = co (= (lane>>4)*4 + reg), col = ci (= lane&15)
+    float* out = a.slab + (size_t)sp * 9 * a.Cout * a.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < COW; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int co = co0 + (co_half * COW + i) * 16 + g * 4 + jj;
+                const int ci = ci0 + ci_tile * 16 + r;
+                out[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[t][i][jj];
+            }
+}
+
+// dw[o][i][t] = alpha * sum_s slab[s][t][p][i]   (p = packed channel of o when ps)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int split, int Cout, int Cin,
+                                    float alpha, int ps) {
+    const long total = 9L * Cout * Cin;
+    const int C = Cout >> 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < split; ++k) s += slab[(size_t)k * total + e];
+        const int ci = (int)(e % Cin);
+        long rest = e / Cin;
+        const int p = (int)(rest % Cout);
+        const int t = (int)(rest / Cout);
+        int o = p;
+        if (ps) { const int sub = p / C, cc = p - sub * C; o = 4 * cc + sub; }
+        dw[((size_t)o * Cin + ci) * 9 + t] = alpha * s;
+    }
+}
+
+// Bias gradient db[o] = alpha * sum over pixels of dy[.., o]  (ATen convolution_backward grad_bias).
+// dy is viewed as a 2-D array [M][C] (C % 4 == 0).  Rows carry a class bit (row / class_div) & 1 and
+// each class is summed separately: for a plain tensor class_div is huge (one class); for the gradient
+// of a pixel-shuffled output the view is [N*2OH*OW][2*Cq] (two horizontally adjacent sub-pixels per
+// row) with class = parity of the shuffled row, which yields the four sub-pixel sums per channel.
+// Stage 1 writes per-block partials, stage 2 sums them in a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, long M,
+                                                             int C, long rows_per_block, long class_div) {
+    const int C4 = C >> 2;
+    const int cw = C4 < 256 ? C4 : 256;  // float4 columns handled per pass
+    const int rl = 256 / cw;             // row lanes
+    const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    __shared__ f32x4 red[2][256];
+    for (int c0 = 0; c0 < C4; c0 += cw) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        if (tr < rl && c0 + tc < C4) {
+            const f32x4* base = (const f32x4*)dy + c0 + tc;
+            for (long rr = r0 + tr; rr < r1; rr += 4L * rl) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long q = rr + (long)u * rl;
+                    v[u] = q < r1 ? base[q * C4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long q = rr + (long)u * rl;
+                    if ((q / class_div) & 1) s1 += v[u]; else s0 += v[u];
+                }
+            }
+        }
+        red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+        __syncthreads();
+        if (tr == 0 && c0 + tc < C4) {
+            for (int k = 1; k < rl; ++k) { s0 += red[0][k * cw + tc]; s1 += red[1][k * cw + tc]; }
+            f32x4* p = (f32x4*)part + (size_t)blockIdx.x * 2 * C4;
+            p[c0 + tc] = s0; p[C4 + c0 + tc] = s1;
+        }
+        __syncthreads();
+    }
+}
+// ps == 0: db[c] = alpha * sum_b part[b][0][c].   ps == 1 (C = 2*Cq): db[4*cc + 2*si + sj] = alpha * sum_b part[b][si][sj*Cq + cc]
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nblocks, int C, float alpha, int ps) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = ps ? 2 * C : C;
+    if (e >= total) return;
+    const int si = e / C, col = e - si * C;
+    double s = 0.0;
+    for (int k = 0; k < nblocks; ++k) s += (double)part[((size_t)k * 2 + si) * C + col];
+    int o = col;
+    if (ps) { const int Cq = C >> 1; const int sj = col / Cq, cc = col - sj * Cq; o = 4 * cc + 2 * si + sj; }
+    db[o] = alpha * (float)s;
+}
+
+int pesr_bias_grad_launch(const float* dy, float* db, long pixels, int Cout, int OW, float alpha, int ps_in, float* part,
+                          size_t part_bytes, hipStream_t stream) {
+    // pixels = N*OH*OW of the (un-shuffled) conv output; Cout its channel count
+    long M; int C; long class_div;
+    if (!ps_in) { M = pixels; C = Cout; class_div = (1L << 62); }
+    else { M = pixels * 2; C = Cout / 2; class_div = OW; }  // [N*2OH*OW][2*Cq]
+    if (C % 4) return PESR_EINVAL;
+    long nb = (M + 63) / 64; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
+    long rpb = (M + nb - 1) / nb;
+    nb = (M + rpb - 1) / rpb;
+    if (part_bytes < (size_t)nb * 2 * C * sizeof(float)) return PESR_EWORKSPACE;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, dy, part, M, C, rpb, class_div);
+    const int total = ps_in ? 2 * C : C;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const float*)part, db, (int)nb, C, alpha, ps_in);
+    return pesr_launch_status();
+}
+
+namespace {
+struct WgradPlan { int cow, two, co_tiles, ci_tiles, segs_x, total_segs, split, segs_per_split; size_t slab_bytes, total_bytes; int colsum_blocks; };
+
+static bool wgrad_plan(int N, int H, int W, int Cin, int Cout, int stride, WgradPlan* p) {
+    if (Cin % 64 || Cout % 64 || (stride != 1 && stride != 2)) return false;
+    const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+    p->cow = (Cout % 128 == 0) ? 4 : 2;
+    p->two = stride == 1 ? 48 : 24;
+    p->co_tiles = Cout / (32 * p->cow);
+    p->ci_tiles = Cin / 64;
+    p->segs_x = (OW + p->two - 1) / p->two;
+    p->total_segs = N * OH * p->segs_x;
+    const int out_tiles = p->co_tiles * p->ci_tiles;
+    int split = (256 + out_tiles - 1) / out_tiles;     // aim at >= 256 workgroups
+    if (split > p->total_segs) split = p->total_segs;
+    if (split < 1) split = 1;
+    p->segs_per_split = (p->total_segs + split - 1) / split;
+    p->split = (p->total_segs + p->segs_per_split - 1) / p->segs_per_split;
+    p->slab_bytes = (size_t)p->split * 9 * Cout * Cin * sizeof(float);
+    (void)OH;
+    p->colsum_blocks = 2048;
+    const size_t part_bytes = (size_t)p->colsum_blocks * 2 * Cout * sizeof(float);
+    p->total_bytes = p->slab_bytes + part_bytes;
+    return true;
+}
+
+template <int COW, int S, int TWO>
+static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
+    constexpr int TWX = (TWO - 1) * S + 3;
+    constexpr int XS = 64 + (S == 1 ? 16 : 8);
+    constexpr int DS = 32 * COW + 16;
+    constexpr size_t lds = 2 * (size_t)(3 * TWX * XS + TWO * DS) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "wgrad LDS budget");
+    auto kern = conv3x3_wgrad_kernel<COW, S, TWO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int grid = split * a.co_tiles * a.ci_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+    return pesr_launch_status();
+}
+}  // namespace
+
+size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int stride) {
+    WgradPlan p;
+    if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return 0;
+    return p.total_bytes;
+}
+
+int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                              int stride, float alpha, int ps_in, void* ws, size_t ws_bytes, hipStream_t stream) {
+    WgradPlan p;
+    if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return PESR_EINVAL;
+    if (ws_bytes < p.total_bytes || !ws) return PESR_EWORKSPACE;
+    if (ps_in && (stride != 1 || (Cout / 4) % (32 * p.cow))) return PESR_EINVAL;
+    WgradArgs a{};
+    a.x = x; a.dy = dy; a.slab = (float*)ws;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
+    a.segs_x = p.segs_x; a.total_segs = p.total_segs; a.segs_per_split = p.segs_per_split;
+    a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.ps_in = ps_in;
+    int rc;
+    if (stride == 1) rc = p.cow == 4 ? launch_wgrad<4, 1, 48>(a, p.split, stream) : launch_wgrad<2, 1, 48>(a, p.split, stream);
+    else rc = p.cow == 4 ? launch_wgrad<4, 2, 24>(a, p.split, stream) : launch_wgrad<2, 2, 24>(a, p.split, stream);
+    if (rc) return rc;
+    const long total = 9L * Cout * Cin;
+    const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in);
+    rc = pesr_launch_status();
+    if (rc || !db) return rc;
+    float* part = (float*)((char*)ws + p.slab_bytes);
+    return pesr_bias_grad_launch(dy, db, (long)N * a.OH * a.OW, Cout, a.OW, alpha, ps_in, part, ws_bytes - p.slab_bytes, stream);
+}

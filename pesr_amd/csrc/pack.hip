@@ -1,0 +1,55 @@
+// Weight packing for the MFMA conv kernels (gfx950).
+//
+// The nn.Module boundary keeps the reference's OIHW fp32 parameters (state_dict schema of
+// reference model/pesr.py, model/basic.py).  The kernels want one contiguous [N][16] block per
+// (tap, 16-channel chunk of the reduction dimension):
+//   mode 0 (forward):  out[t][c][n][k] = w[o = unperm(n)][i = 16c+k][ky][kx],           t = 3ky+kx
+//   mode 1 (dgrad):    out[t][c][n][k] = w[o = unperm(16c+k)][i = n][ky][kx]            (reduce over o)
+// `ps` = 1 orders the output channels of a conv that feeds nn.PixelShuffle(2) sub-pixel-major:
+// packed channel p = (2*si+sj)*C + cc  <->  original channel o = 4*cc + 2*si + sj, so the conv
+// epilogue can write the shuffled tensor with contiguous channel runs (reference model/basic.py:56-59).
+#include "common.h"
+#include "launchers.h"
+
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode, int ps) {
+    const int R = mode == 0 ? I : O;   // reduction channels
+    const int Nn = mode == 0 ? O : I;  // "n" channels
+    const long total = 9L * R * Nn;
+    const int C = O >> 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(e & 15);
+        long rest = e >> 4;
+        const int n = (int)(rest % Nn); rest /= Nn;
+        const int c = (int)(rest % (R >> 4));
+        const int t = (int)(rest / (R >> 4));
+        const int red = c * 16 + k;
+        int o = mode == 0 ? n : red;
+        const int i = mode == 0 ? red : n;
+        if (ps) { const int sub = o / C, cc = o - sub * C; o = 4 * cc + sub; }
+        out[e] = w[((long)o * I + i) * 9 + t];
+    }
+}
+
+// permute a bias vector into the packed (pixel-shuffle) channel order
+__global__ void pack_bias_ps_kernel(const float* __restrict__ b, float* __restrict__ out, int O) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= O) return;
+    const int C = O >> 2;
+    const int sub = p / C, cc = p - sub * C;
+    out[p] = b[4 * cc + sub];
+}
+
+int pesr_pack_conv3x3_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream) {
+    const int R = mode == 0 ? I : O;
+    if (R % 16 || (ps && O % 4)) return PESR_EINVAL;
+    const long total = 9L * O * I;
+    const int block = 256;
+    const int grid = (int)((total + block - 1) / block < 4096 ? (total + block - 1) / block : 4096);
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid), dim3(block), 0, stream, w, out, O, I, mode, ps);
+    return pesr_launch_status();
+}
+
+int pesr_pack_bias_ps_launch(const float* b, float* out, int O, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_bias_ps_kernel, dim3((O + 255) / 256), dim3(256), 0, stream, b, out, O);
+    return pesr_launch_status();
+}
