@@ -1,0 +1,128 @@
+"""CPU restatement of the reference's losses and train steps - TEST INFRASTRUCTURE.
+
+Follows reference train.py:123-140 (optimizers, loss closures), :164-173 (pretrain step) and :194-259
+(GAN step) and model/focal_loss.py:9-13, on the functional networks of oracle/model.py.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import model as M
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+def focal_loss(x, t, gamma):
+    """model/focal_loss.py:9-13.  The reference passes a grad-requiring `w` as the BCE `weight`; under its
+    pinned torch 0.4 BCE-with-logits was a Python composite and gradient flowed through BOTH w and the BCE
+    term.  This composite restates exactly that; the forward value equals the reference's."""
+    p = torch.sigmoid(x)
+    pt = p * t + (1 - p) * (1 - t)
+    w = (1 - pt).pow(gamma)
+    return (w * F.binary_cross_entropy_with_logits(x, t, reduction="none")).mean()
+
+
+def focal_loss_grad_closed_form(x, t, gamma):
+    """dL/dx of focal_loss: [dw/dx * bce + w * (p - t)] / N with dw/dx = -gamma (1-pt)^(gamma-1) (2t-1) p (1-p)."""
+    p = torch.sigmoid(x)
+    pt = p * t + (1 - p) * (1 - t)
+    bce = F.binary_cross_entropy_with_logits(x, t, reduction="none")
+    w = (1 - pt).pow(gamma)
+    if gamma == 0:
+        dw = torch.zeros_like(x)
+    else:
+        dw = -gamma * (1 - pt).pow(gamma - 1) * (2 * t - 1) * p * (1 - p)
+    return (dw * bce + w * (p - t)) / x.numel()
+
+
+def tv_loss(y):
+    """train.py:137-140: SUM (not mean) of absolute horizontal and vertical differences."""
+    return torch.sum(torch.abs(y[:, :, :, :-1] - y[:, :, :, 1:])) + torch.sum(torch.abs(y[:, :, :-1, :] - y[:, :, 1:, :]))
+
+
+# ------------------------------------------------------------------------------------------------
+# train state
+# ------------------------------------------------------------------------------------------------
+class TrainState:
+    """Parameters as leaf tensors + torch.optim.Adam exactly as train.py:123-128 builds them."""
+
+    def __init__(self, g_sd, d_sd, vgg_sd, cfg):
+        self.cfg = dict(cfg)
+        self.g = {k: v.clone().requires_grad_(True) for k, v in g_sd.items()}            # all of G trains (Q1)
+        self.d = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+                  for k, v in (d_sd or {}).items()}
+        self.vgg = {k: v.clone() for k, v in (vgg_sd or {}).items()}
+        lr = cfg.get("learning_rate", 5e-5)
+        self.optim_g = torch.optim.Adam(list(self.g.values()), betas=(0.9, 0.999), lr=lr)
+        d_params = [v for v in self.d.values() if v.requires_grad]
+        self.optim_d = torch.optim.Adam(d_params, betas=(0.9, 0.999), lr=lr) if d_params else None
+
+    def G(self, x):
+        return M.generator_forward(self.g, x, self.cfg["depth"], self.cfg["res_scale"])
+
+    def D(self, x):
+        return M.discriminator_forward(self.d, x, update_running_stats=True)
+
+
+def pretrain_step(st: TrainState, lr, hr):
+    """train.py:164-173."""
+    sr = st.G(lr)
+    st.optim_g.zero_grad()
+    loss = F.l1_loss(sr, hr)
+    loss.backward()
+    st.optim_g.step()
+    return {"l1": loss.item()}
+
+
+def gan_step(st: TrainState, lr, hr):
+    """train.py:194-259 with the defaults' branches kept selectable (gan_type, focal_loss); GP is off."""
+    c = st.cfg
+    B = lr.size(0)
+    target_real = torch.ones(B, 1)
+    target_fake = torch.zeros(B, 1)
+    d_leaves = [v for k, v in st.d.items() if v.is_floating_point() and "running" not in k]
+
+    # ---- discriminator phase (:202-229)
+    for p in d_leaves:
+        p.requires_grad_(True)
+    st.optim_d.zero_grad()
+    pred_real = st.D(hr)
+    sr = st.G(lr)
+    pred_fake = st.D(sr.detach())
+    if c.get("gan_type", "RSGAN") == "SGAN":
+        d_loss = F.binary_cross_entropy_with_logits(pred_real, target_real) + \
+            F.binary_cross_entropy_with_logits(pred_fake, target_fake)
+    else:
+        d_loss = F.binary_cross_entropy_with_logits(pred_real - pred_fake, target_real)
+    d_loss.backward()
+    st.optim_d.step()
+
+    # ---- generator phase (:234-259)
+    for p in d_leaves:
+        p.requires_grad_(False)
+    st.optim_g.zero_grad()
+    pred_fake = st.D(sr)
+    pred_real = st.D(hr)
+    l1 = F.l1_loss(sr, hr) * c.get("alpha_l1", 0.0)
+    f_sr, f_hr = M.vgg_forward(st.vgg, sr, hr)
+    vgg = F.mse_loss(f_sr, f_hr) * c.get("alpha_vgg", 50.0)
+    tv = tv_loss(sr) * c.get("alpha_tv", 1e-6)
+    gamma = c.get("fl_gamma", 1.0)
+    use_focal = c.get("focal_loss", True)
+    if c.get("gan_type", "RSGAN") == "SGAN":
+        z = pred_fake
+    else:
+        z = pred_fake - pred_real
+    g_loss = focal_loss(z, target_real, gamma) if use_focal else F.binary_cross_entropy_with_logits(z, target_real)
+    g_loss = g_loss * c.get("alpha_gan", 1.0)
+    total = l1 + vgg + g_loss + tv
+    total.backward()
+    st.optim_g.step()
+    return {"l1": l1.item(), "vgg": vgg.item(), "g": g_loss.item(), "tv": tv.item(), "d": d_loss.item()}
+
+
+def step_lr(base_lr, epoch, lr_step, gamma=0.5):
+    """StepLR stepped at EPOCH START (train.py:156,185-186): epoch e (1-based) trains at base*gamma^floor(e/lr_step)."""
+    return base_lr * math.pow(gamma, epoch // lr_step)

@@ -1,0 +1,159 @@
+"""CPU: the oracle (oracle/) against golden vectors made by importing the reference (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detrand
+from oracle import model as OM
+from oracle import step as OS
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def gen_sd(C, depth, seed=0):
+    shapes = {k: v for k, v in OM.generator_shapes(C, depth).items() if not k.startswith(("sub_mean", "add_mean"))}
+    sd = detrand.fill_state_dict(shapes, seed)
+    OM.set_meanshift(sd, "G")
+    return {k: sd[k] for k in OM.generator_shapes(C, depth)}
+
+
+def dis_sd(ps, seed=1):
+    return detrand.fill_state_dict(OM.discriminator_shapes(ps), seed)
+
+
+def vgg_sd(seed=2):
+    shapes = {k: v for k, v in OM.vgg_shapes().items() if not k.startswith("sub_mean")}
+    sd = detrand.fill_state_dict(shapes, seed, "vgg")
+    return OM.set_meanshift(sd, "V")
+
+
+def close(a, b, rtol=1e-6, atol=0.0):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.abs(b).max() + 1e-30
+    assert a.shape == b.shape
+    assert np.abs(a - b).max() <= rtol * scale + atol, (np.abs(a - b).max(), scale)
+
+
+def test_gv1_generator_small():
+    g = load("gv1_generator_small")
+    sd = gen_sd(16, 2)
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]          # state_dict key order = reference's
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lr = detrand.image_batch((2, 3, 12, 12), 1234)
+    hr = detrand.image_batch((2, 3, 48, 48), 1235)
+    sr = OM.generator_forward(leaves, lr, 2, 0.1)
+    close(sr.detach(), g["sr"], 1e-6)
+    loss = F.l1_loss(sr, hr)
+    close(loss.item(), g["loss"], 1e-6)
+    loss.backward()
+    for k, v in leaves.items():
+        close(v.grad, g["grad." + k], 2e-5)
+
+
+def test_gv3_pixel_shuffle_bit_exact():
+    g = load("gv3_pixel_shuffle")
+    x = torch.arange(2 * 16 * 3 * 5, dtype=torch.float32).reshape(2, 16, 3, 5)
+    y = F.pixel_shuffle(x, 2)
+    assert np.array_equal(y.numpy(), g["y"])
+    # explicit index formula (reference semantics: out[n,c,2h+i,2w+j] = in[n,4c+2i+j,h,w])
+    n, c, h, w = 1, 3, 2, 4
+    for i in range(2):
+        for j in range(2):
+            assert y[n, c, 2 * h + i, 2 * w + j] == x[n, 4 * c + 2 * i + j, h, w]
+    gy = torch.arange(y.numel(), dtype=torch.float32).reshape(y.shape) * 0.5
+    assert np.array_equal(F.pixel_unshuffle(gy, 2).numpy(), g["gx"])
+
+
+def test_gv4_discriminator_small():
+    g = load("gv4_discriminator_small")
+    sd = dis_sd(8)
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    a = detrand.image_batch((4, 3, 32, 32), 21)
+    b = detrand.image_batch((4, 3, 32, 32), 22).requires_grad_(True)
+    o1 = OM.discriminator_forward(leaves, a)
+    o2 = OM.discriminator_forward(leaves, b)
+    close(o1.detach(), g["o1"], 1e-5)
+    close(o2.detach(), g["o2"], 1e-5)
+    l = F.binary_cross_entropy_with_logits(o1 - o2, torch.ones(4, 1))
+    l.backward()
+    close(b.grad, g["gin"], 1e-4)
+    for k, v in leaves.items():
+        if v.requires_grad:
+            close(v.grad.reshape(-1)[g["gidx." + k]], g["gval." + k], 1e-4, atol=1e-4 * float(g["gmax." + k]))
+        elif "running" in k:
+            close(v, g["buf." + k], 1e-5)
+        else:
+            assert int(v) == int(g["buf." + k]) == 2
+
+
+def test_gv5_focal_forward_and_grad():
+    g = load("gv5_focal")
+    x = torch.from_numpy(g["x"])
+    for gamma in (0, 1, 2):
+        for t in (0, 1):
+            tt = torch.full_like(x, float(t))
+            per = torch.stack([OS.focal_loss(x[i:i + 1], tt[i:i + 1], gamma) for i in range(x.size(0))])
+            close(per, g[f"f_g{gamma}_t{t}"], 1e-6, atol=1e-9)
+            close(OS.focal_loss(x, tt, gamma).item(), g[f"mean_g{gamma}_t{t}"], 1e-6)
+            # backward: autograd of the composite == closed form
+            xr = x.clone().requires_grad_(True)
+            OS.focal_loss(xr, tt, gamma).backward()
+            close(xr.grad, OS.focal_loss_grad_closed_form(x, tt, gamma), 1e-5, atol=1e-9)
+
+
+def test_gv6_losses():
+    g = load("gv6_losses")
+    s = (detrand.image_batch((2, 3, 10, 12), 51) + detrand.uniform((2, 3, 10, 12), 52, -0.5, 0.5)).requires_grad_(True)
+    h = detrand.image_batch((2, 3, 10, 12), 53)
+    l1 = F.l1_loss(s, h)
+    tv = OS.tv_loss(s)
+    (l1 + tv).backward()
+    close(l1.item(), g["l1"]); close(tv.item(), g["tv"]); close(s.grad, g["g_l1_tv"])
+    z = detrand.uniform((6, 1), 54, -3, 3).requires_grad_(True)
+    bce = F.binary_cross_entropy_with_logits(z, torch.ones(6, 1))
+    bce.backward()
+    close(bce.item(), g["bce"]); close(z.grad, g["g_bce"])
+
+
+def test_gv7_vgg_small():
+    g = load("gv7_vgg_small")
+    sd = vgg_sd()
+    assert sorted(sd.keys()) == sorted(str(k) for k in g["keys"])
+    close(sd["sub_mean.weight"], g["sub_w"], 0); close(sd["sub_mean.bias"], g["sub_b"], 0)
+    a = detrand.image_batch((2, 3, 32, 32), 31).requires_grad_(True)
+    b = detrand.image_batch((2, 3, 32, 32), 32)
+    fa, fb = OM.vgg_forward(sd, a, b)
+    close(fa.detach(), g["f_sr"], 1e-5); close(fb, g["f_hr"], 1e-5)
+    m = F.mse_loss(fa, fb)
+    close(m.item(), g["mse"], 1e-5)
+    m.backward()
+    close(a.grad, g["gin"], 1e-4)
+
+
+def test_gv8_two_gan_steps():
+    g = load("gv8_gan_steps_small")
+    cfg = {"depth": 2, "res_scale": 0.1, "learning_rate": 5e-5}
+    st = OS.TrainState(gen_sd(16, 2), dis_sd(8), vgg_sd(), cfg)
+    for it in range(2):
+        lr = detrand.image_batch((4, 3, 8, 8), 100 + it)
+        hr = detrand.image_batch((4, 3, 32, 32), 200 + it)
+        log = OS.gan_step(st, lr, hr)
+        close([log["l1"], log["vgg"], log["g"], log["tv"], log["d"]], g["losses"][it], 2e-5)
+    for k, v in st.g.items():
+        close(v.detach().reshape(-1)[g["G.idx." + k]], g["G.val." + k], 1e-5)
+    for k, v in st.d.items():
+        close(v.detach().reshape(-1).float()[g["D.idx." + k]], g["D.val." + k], 1e-5)
+
+
+@pytest.mark.parametrize("epoch,expect", [(1, 5e-5), (119, 5e-5), (120, 2.5e-5), (239, 2.5e-5), (240, 1.25e-5)])
+def test_step_lr_schedule(epoch, expect):
+    assert OS.step_lr(5e-5, epoch, 120) == pytest.approx(expect)
