@@ -63,6 +63,69 @@ size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout
 int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                        int stride, float alpha, int ps_in, void* workspace, size_t ws_bytes, void* stream);
 
+/* Weight gradient of the RGB-boundary convs (one operand has 3 channels): reference `embed`
+ * (model/pesr.py:23), Discriminator features.0 (model/pesr.py:53), Upsampler's last conv (model/basic.py:60).
+ * a: the C-channel tensor [N][H][W][C], b3: the 3-channel tensor [N][H][W][3].
+ * mode 0 (3 -> C): a = dy, b3 = x, dw [C][3][3][3], db [C].  mode 1 (C -> 3): a = x, b3 = dy, dw [3][C][3][3], db [3]. */
+size_t pesr_conv3x3_wgrad_rgb_workspace_bytes(int N, int H, int W, int C);
+int pesr_conv3x3_wgrad_rgb(const float* a, const float* b3, float* dw, float* db, int N, int H, int W, int C, int mode,
+                           float alpha, void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- MeanShift: trainable 1x1 conv 3->3 (reference model/basic.py:9-17) ----------- */
+/* x_nchw / y_nchw: the 3-channel tensor is stored NCHW-contiguous instead of NHWC (folds the layout
+ * change of the network's RGB input/output into this kernel). */
+int pesr_meanshift_fwd(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int x_nchw, int y_nchw,
+                       void* stream);
+/* dy, dx NHWC; dx may be NULL.  dw [3][3], db [3].  workspace >= 1024*12*4 bytes. */
+int pesr_meanshift_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int N, int H, int W,
+                       int x_nchw, void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- nn.PixelShuffle(2) standalone (reference model/basic.py:57,59), bit-exact indexing ------- */
+/* x [N][H][W][4C] -> y [N][2H][2W][C]:  y[n][2h+i][2w+j][c] = x[n][h][w][4c+2i+j];  bwd is the inverse. */
+int pesr_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int pesr_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
+/* out = (ref > 0 ? alpha*g : 0) + add : ReLU threshold_backward (+ residual fan-in); ref/add may be NULL */
+int pesr_relu_mask(const float* g, const float* ref, const float* add, float* out, long n, float alpha, void* stream);
+
+/* ---- 2x2/2 max-pool (torchvision vgg19 features, reference model/vgg.py:8-10) ------------------ */
+int pesr_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* relu_in=1 also applies the mask of the ReLU that produced x (gradient only where x > 0) */
+int pesr_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int relu_in, void* stream);
+
+/* ---- BatchNorm2d(train) + LeakyReLU (reference model/basic.py:29-30, model/pesr.py:47) --------- */
+size_t pesr_bn_workspace_bytes(long M, int C);
+/* mean_invstd [2][C] is saved for backward; running stats / num_batches (int64) updated as nn.BatchNorm2d
+ * does, may be NULL.  y_nchw=1 writes y NCHW-contiguous (the flatten of reference model/pesr.py:79). */
+int pesr_bn_lrelu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_invstd,
+                      float* running_mean, float* running_var, long long* num_batches, int N, int H, int W, int C, float eps,
+                      float momentum, float slope, int y_nchw, void* workspace, size_t ws_bytes, void* stream);
+int pesr_bn_lrelu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
+                      float* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw,
+                      void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- skinny-batch Linear (reference model/pesr.py:69-74; ATen addmm/mm), M <= 32 ---------------- */
+size_t pesr_linear_workspace_bytes(int M, int N, long K);
+int pesr_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, long K, int act, float slope,
+                    void* workspace, size_t ws_bytes, void* stream);
+int pesr_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, long K, void* workspace, size_t ws_bytes,
+                      void* stream);
+int pesr_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, long K, void* stream);
+
+/* ---- losses, fused forward + gradient (reference train.py:131-140) --------------------------------- */
+/* sr, hr, grad: [N][H][W][3].  out2[0] = mean|sr-hr|, out2[1] = TV sum.  grad = g_l1*sign(sr-hr) + g_tv*dTV/dsr
+ * (caller folds alpha_l1/numel and alpha_tv into g_l1, g_tv); grad may be NULL.  workspace >= 8 KiB. */
+int pesr_loss_l1_tv_fwd_bwd(const float* sr, const float* hr, float* grad, float* out2, int N, int H, int W, float g_l1,
+                            float g_tv, void* workspace, size_t ws_bytes, void* stream);
+/* out1[0] = mean (a-b)^2 ; grad = gscale*(a-b) (caller passes 2*alpha/numel); grad may be NULL */
+int pesr_mse_fwd_bwd(const float* a, const float* b, float* grad, float* out1, long n, float gscale, void* workspace,
+                     size_t ws_bytes, void* stream);
+
+/* ---- fused Adam on one flat buffer (reference train.py:124-125; torch.optim.Adam) ---------------- */
+/* g is multiplied by grad_scale first (1/world_size after a sum all-reduce). step is 1-based. */
+int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,30 @@ SIGNATURES = {
                                    c_size_t, _P]),
 }
 
+SIGNATURES.update({
+    "pesr_conv3x3_wgrad_rgb_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "pesr_conv3x3_wgrad_rgb": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    "pesr_meanshift_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pesr_meanshift_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "pesr_pixel_shuffle_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pesr_pixel_shuffle_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pesr_relu_mask": (c_int, [_P, _P, _P, _P, c_long, c_float, _P]),
+    "pesr_maxpool2x2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pesr_maxpool2x2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pesr_bn_workspace_bytes": (c_size_t, [c_long, c_int]),
+    "pesr_bn_lrelu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
+                                  c_int, _P, c_size_t, _P]),
+    "pesr_bn_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_size_t,
+                                  _P]),
+    "pesr_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_long]),
+    "pesr_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_long, c_int, c_float, _P, c_size_t, _P]),
+    "pesr_linear_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_long, _P, c_size_t, _P]),
+    "pesr_linear_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_long, _P]),
+    "pesr_loss_l1_tv_fwd_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
+    "pesr_mse_fwd_bwd": (c_int, [_P, _P, _P, _P, c_long, c_float, _P, c_size_t, _P]),
+    "pesr_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
+})
+
 _lib = None
 
 

@@ -4,6 +4,9 @@
 #include "launchers.h"
 #include "../../include/pesr_hip.h"
 
+static inline int pad16(int c) { return (c + 15) / 16 * 16; }
+static inline int pad64(int c) { return (c + 63) / 64 * 64; }
+
 PESR_API int pesr_abi_version(void) { return 1; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
@@ -16,15 +19,15 @@ PESR_API int pesr_pack_bias_ps(const float* b, float* out, int O, void* stream) 
 PESR_API int pesr_conv3x3_fwd(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask,
                               float* y, int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act,
                               float slope, int ps_out, void* stream) {
-    return pesr_conv3x3_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, stride, alpha, act, slope, ps_out, 0, 0,
-                               (hipStream_t)stream);
+    return pesr_conv3x3_launch(x, w_packed, bias, skip, mask, y, N, H, W, pad16(Cin), pad64(Cout), stride, alpha, act, slope,
+                               ps_out, 0, 0, Cin, Cout, (hipStream_t)stream);
 }
 
 PESR_API int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float* mask, const float* skip, float* dx,
                                 int N, int H, int W, int Cin, int Cout, int stride, float alpha, int ps_in, void* stream) {
     if (stride == 1)  // a stride-1 conv over dy with Cin/Cout swapped and the taps flipped
-        return pesr_conv3x3_launch(dy, w_packed_dgrad, nullptr, skip, mask, dx, N, H, W, Cout, Cin, 1, alpha, PESR_ACT_NONE,
-                                   0.f, 0, ps_in, 1, (hipStream_t)stream);
+        return pesr_conv3x3_launch(dy, w_packed_dgrad, nullptr, skip, mask, dx, N, H, W, pad16(Cout), pad64(Cin), 1, alpha,
+                                   PESR_ACT_NONE, 0.f, 0, ps_in, 1, Cout, Cin, (hipStream_t)stream);
     if (stride == 2 && !ps_in && !skip)
         return pesr_conv3x3_s2_dgrad_launch(dy, w_packed_dgrad, mask, dx, N, H, W, Cout, Cin, alpha, (hipStream_t)stream);
     return PESR_EINVAL;
@@ -37,4 +40,82 @@ PESR_API int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, floa
                                 int stride, float alpha, int ps_in, void* workspace, size_t ws_bytes, void* stream) {
     return pesr_conv3x3_wgrad_launch(x, dy, dw, db, N, H, W, Cin, Cout, stride, alpha, ps_in, workspace, ws_bytes,
                                      (hipStream_t)stream);
+}
+
+PESR_API size_t pesr_conv3x3_wgrad_rgb_workspace_bytes(int N, int H, int W, int C) {
+    return pesr_conv3x3_wgrad_rgb_ws_bytes(N, H, W, C);
+}
+PESR_API int pesr_conv3x3_wgrad_rgb(const float* a, const float* b3, float* dw, float* db, int N, int H, int W, int C, int mode,
+                                    float alpha, void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_conv3x3_wgrad_rgb_launch(a, b3, dw, db, N, H, W, C, mode, alpha, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+PESR_API int pesr_meanshift_fwd(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int x_nchw,
+                                int y_nchw, void* stream) {
+    const long HW = (long)H * W;
+    const long xsn = 3 * HW, xsc = x_nchw ? HW : 1, xsp = x_nchw ? 1 : 3;
+    const long ysn = 3 * HW, ysc = y_nchw ? HW : 1, ysp = y_nchw ? 1 : 3;
+    return pesr_meanshift_fwd_launch(x, w, b, y, N, H, W, xsn, xsc, xsp, ysn, ysc, ysp, (hipStream_t)stream);
+}
+PESR_API int pesr_meanshift_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int N, int H,
+                                int W, int x_nchw, void* workspace, size_t ws_bytes, void* stream) {
+    const long HW = (long)H * W;
+    const long xsn = 3 * HW, xsc = x_nchw ? HW : 1, xsp = x_nchw ? 1 : 3;
+    return pesr_meanshift_bwd_launch(dy, x, w, dx, dw, db, N, H, W, xsn, xsc, xsp, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+PESR_API int pesr_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    return pesr_pixel_shuffle_launch(x, y, N, H, W, C, 0, (hipStream_t)stream);
+}
+PESR_API int pesr_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    return pesr_pixel_shuffle_launch(dy, dx, N, H, W, C, 1, (hipStream_t)stream);
+}
+PESR_API int pesr_relu_mask(const float* g, const float* ref, const float* add, float* out, long n, float alpha, void* stream) {
+    return pesr_relu_mask_launch(g, ref, add, out, n, alpha, (hipStream_t)stream);
+}
+PESR_API int pesr_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    return pesr_maxpool2x2_fwd_launch(x, y, N, H, W, C, (hipStream_t)stream);
+}
+PESR_API int pesr_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int relu_in, void* stream) {
+    return pesr_maxpool2x2_bwd_launch(x, dy, dx, N, H, W, C, relu_in, (hipStream_t)stream);
+}
+
+PESR_API size_t pesr_bn_workspace_bytes(long M, int C) { return pesr_bn_ws_bytes(M, C); }
+PESR_API int pesr_bn_lrelu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_invstd,
+                               float* running_mean, float* running_var, long long* num_batches, int N, int H, int W, int C,
+                               float eps, float momentum, float slope, int y_nchw, void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_bn_lrelu_fwd_launch(x, gamma, beta, y, mean_invstd, running_mean, running_var, num_batches, (long)N * H * W, C,
+                                    (long)H * W, eps, momentum, slope, y_nchw, workspace, ws_bytes, (hipStream_t)stream);
+}
+PESR_API int pesr_bn_lrelu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
+                               float* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw,
+                               void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_bn_lrelu_bwd_launch(x, dy, gamma, beta, mean_invstd, dx, dgamma, dbeta, (long)N * H * W, C, (long)H * W, slope,
+                                    dy_nchw, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+PESR_API size_t pesr_linear_workspace_bytes(int M, int N, long K) { return pesr_linear_ws_bytes(M, N, K); }
+PESR_API int pesr_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, long K, int act, float slope,
+                             void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_linear_fwd_launch(x, w, b, y, M, N, K, act, slope, workspace, ws_bytes, (hipStream_t)stream);
+}
+PESR_API int pesr_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, long K, void* workspace, size_t ws_bytes,
+                               void* stream) {
+    return pesr_linear_dgrad_launch(dy, w, dx, M, N, K, workspace, ws_bytes, (hipStream_t)stream);
+}
+PESR_API int pesr_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, long K, void* stream) {
+    return pesr_linear_wgrad_launch(dy, x, dw, db, M, N, K, (hipStream_t)stream);
+}
+
+PESR_API int pesr_loss_l1_tv_fwd_bwd(const float* sr, const float* hr, float* grad, float* out2, int N, int H, int W, float g_l1,
+                                     float g_tv, void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_loss_l1_tv_launch(sr, hr, grad, out2, N, H, W, g_l1, g_tv, workspace, ws_bytes, (hipStream_t)stream);
+}
+PESR_API int pesr_mse_fwd_bwd(const float* a, const float* b, float* grad, float* out1, long n, float gscale, void* workspace,
+                              size_t ws_bytes, void* stream) {
+    return pesr_loss_mse_launch(a, b, grad, out1, n, gscale, workspace, ws_bytes, (hipStream_t)stream);
+}
+PESR_API int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                            int step, float grad_scale, void* stream) {
+    return pesr_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
 }

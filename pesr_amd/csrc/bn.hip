@@ -1,0 +1,206 @@
+// BatchNorm2d (training mode, batch statistics) + LeakyReLU for the Discriminator's BasicBlock
+// (reference model/basic.py:29-30, model/pesr.py:47: eps 1e-5, momentum 0.1, slope 0.2), NHWC fp32.
+//   stats   : per-channel sum and sum of squares  -> per-block partials (no atomics)
+//   finalize: mean, biased var, invstd in double over the partials (fixed order); running stats
+//             (unbiased var, momentum) and num_batches_tracked updated as nn.BatchNorm2d does
+//   apply   : y = lrelu(gamma * (x - mean) * invstd + beta)         (optionally written NCHW for the
+//             flatten in reference model/pesr.py:79)
+//   backward: pass 1 reduces sum(dz) and sum(dz * xhat) with dz = dy * lrelu'(z); pass 2 writes
+//             dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))
+#include "common.h"
+#include "launchers.h"
+
+// partial sums over rows [r0, r1) of a [M][C] array of f(x): which = 0: {x, x^2}; which = 1: {dz, dz*xhat}
+template <int WHICH>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ part, long M, int C,
+                                                        long rows_per_block, float slope, long dy_sn, long dy_sc, long dy_sp, long HW) {
+    const int C4 = C >> 2;
+    const int cw = C4 < 256 ? C4 : 256;
+    const int rl = 256 / cw;
+    const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    __shared__ f32x4 red[2][256];
+    for (int c0 = 0; c0 < C4; c0 += cw) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        const int c4 = c0 + tc;
+        if (tr < rl && c4 < C4) {
+            f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu, be = mu;
+            if (WHICH == 1) {
+                mu = ((const f32x4*)mean_invstd)[c4]; is = ((const f32x4*)(mean_invstd + C))[c4];
+                ga = ((const f32x4*)gamma)[c4]; be = ((const f32x4*)beta)[c4];
+            }
+            for (long rr = r0 + tr; rr < r1; rr += rl) {
+                const f32x4 v = ((const f32x4*)x)[rr * C4 + c4];
+                if (WHICH == 0) {
+                    s0 += v; s1 += v * v;
+                } else {
+                    f32x4 g;
+                    if (dy_sc == 1) g = ((const f32x4*)dy)[rr * C4 + c4];
+                    else {  // dy stored NCHW (flattened classifier input): gather 4 channels
+                        const long n = rr / HW, p = rr - n * HW;
+                        const float* q = dy + n * dy_sn + p * dy_sp + (long)(c4 * 4) * dy_sc;
+                        g = (f32x4){q[0], q[dy_sc], q[2 * dy_sc], q[3 * dy_sc]};
+                    }
+                    const f32x4 xh = (v - mu) * is;
+                    const f32x4 z = ga * xh + be;
+                    f32x4 dz;
+                    dz.x = z.x > 0.f ? g.x : g.x * slope; dz.y = z.y > 0.f ? g.y : g.y * slope;
+                    dz.z = z.z > 0.f ? g.z : g.z * slope; dz.w = z.w > 0.f ? g.w : g.w * slope;
+                    s0 += dz; s1 += dz * xh;
+                }
+            }
+        }
+        red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+        __syncthreads();
+        if (tr == 0 && c4 < C4) {
+            for (int k = 1; k < rl; ++k) { s0 += red[0][k * cw + tc]; s1 += red[1][k * cw + tc]; }
+            f32x4* p = (f32x4*)part + (size_t)blockIdx.x * 2 * C4;
+            p[c4] = s0; p[C4 + c4] = s1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, int C, long M, float eps, float momentum,
+                                   float* __restrict__ mean_invstd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, long long* __restrict__ num_batches) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches) *num_batches += 1;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nb; ++k) { s += (double)part[((size_t)k * 2) * C + c]; ss += (double)part[((size_t)k * 2 + 1) * C + c]; }
+    const double mean = s / (double)M;
+    double var = ss / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_invstd[c] = (float)mean;
+    mean_invstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+}
+
+// second-stage reduce for backward: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat
+__global__ void bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * C) return;
+    const int which = e / C, c = e - which * C;
+    double s = 0.0;
+    for (int k = 0; k < nb; ++k) s += (double)part[((size_t)k * 2 + which) * C + c];
+    sums[e] = (float)s;
+}
+
+__global__ void bn_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ y, long M, int C, float slope, long HW,
+                                long ysn, long ysc, long ysp) {
+    const int C4 = C >> 2;
+    const long total = M * C4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        const long rr = e / C4;
+        const f32x4 mu = ((const f32x4*)mean_invstd)[c4], is = ((const f32x4*)(mean_invstd + C))[c4];
+        const f32x4 ga = ((const f32x4*)gamma)[c4], be = ((const f32x4*)beta)[c4];
+        f32x4 z = ga * ((x[e] - mu) * is) + be;
+        z.x = z.x > 0.f ? z.x : z.x * slope; z.y = z.y > 0.f ? z.y : z.y * slope;
+        z.z = z.z > 0.f ? z.z : z.z * slope; z.w = z.w > 0.f ? z.w : z.w * slope;
+        if (ysc == 1) ((f32x4*)y)[e] = z;
+        else {
+            const long n = rr / HW, p = rr - n * HW;
+            float* q = y + n * ysn + p * ysp + (long)(c4 * 4) * ysc;
+            q[0] = z.x; q[ysc] = z.y; q[2 * ysc] = z.z; q[3 * ysc] = z.w;
+        }
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean_invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums,
+                                    f32x4* __restrict__ dx, long M, int C, float slope, long HW, long dy_sn, long dy_sc, long dy_sp) {
+    const int C4 = C >> 2;
+    const long total = M * C4;
+    const float invM = 1.0f / (float)M;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        const long rr = e / C4;
+        const f32x4 mu = ((const f32x4*)mean_invstd)[c4], is = ((const f32x4*)(mean_invstd + C))[c4];
+        const f32x4 ga = ((const f32x4*)gamma)[c4], be = ((const f32x4*)beta)[c4];
+        const f32x4 sdz = ((const f32x4*)sums)[c4] * invM, sdzx = ((const f32x4*)(sums + C))[c4] * invM;
+        f32x4 g;
+        if (dy_sc == 1) g = ((const f32x4*)dy)[e];
+        else {
+            const long n = rr / HW, p = rr - n * HW;
+            const float* q = dy + n * dy_sn + p * dy_sp + (long)(c4 * 4) * dy_sc;
+            g = (f32x4){q[0], q[dy_sc], q[2 * dy_sc], q[3 * dy_sc]};
+        }
+        const f32x4 xh = (x[e] - mu) * is;
+        const f32x4 z = ga * xh + be;
+        f32x4 dz;
+        dz.x = z.x > 0.f ? g.x : g.x * slope; dz.y = z.y > 0.f ? g.y : g.y * slope;
+        dz.z = z.z > 0.f ? g.z : g.z * slope; dz.w = z.w > 0.f ? g.w : g.w * slope;
+        dx[e] = ga * is * (dz - sdz - xh * sdzx);
+    }
+}
+
+namespace {
+static void bn_grid(long M, long* nb, long* rpb) {
+    long b = (M + 63) / 64; if (b > 1024) b = 1024; if (b < 1) b = 1;
+    *rpb = (M + b - 1) / b;
+    *nb = (M + *rpb - 1) / *rpb;
+}
+}  // namespace
+
+size_t pesr_bn_ws_bytes(long M, int C) {
+    long nb, rpb; bn_grid(M, &nb, &rpb);
+    return (size_t)nb * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(float);
+}
+
+// forward: x [M][C] (M = N*H*W) -> y; saves mean_invstd [2][C]
+int pesr_bn_lrelu_fwd_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean_invstd,
+                             float* running_mean, float* running_var, long long* num_batches, long M, int C, long HW, float eps,
+                             float momentum, float slope, int y_nchw, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (C % 4) return PESR_EINVAL;
+    long nb, rpb; bn_grid(M, &nb, &rpb);
+    if (!ws || ws_bytes < (size_t)nb * 2 * C * sizeof(float)) return PESR_EWORKSPACE;
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, part, M, C, rpb, slope, 0L, 1L, 0L, HW);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)part, (int)nb, C, M, eps, momentum,
+                       mean_invstd, running_mean, running_var, num_batches);
+    const long total = M * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    long ysn = HW * C, ysc = 1, ysp = C;
+    if (y_nchw) { ysn = HW * C; ysc = HW; ysp = 1; }
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, (const float*)mean_invstd, gamma, beta, y, M, C,
+                       slope, HW, ysn, ysc, ysp);
+    return pesr_launch_status();
+}
+
+// backward: dy is the gradient w.r.t. the LeakyReLU output (NHWC, or NCHW when dy_nchw); dgamma/dbeta may be NULL
+int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
+                             float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, void* ws,
+                             size_t ws_bytes, hipStream_t stream) {
+    if (C % 4) return PESR_EINVAL;
+    long nb, rpb; bn_grid(M, &nb, &rpb);
+    const size_t part_bytes = (size_t)nb * 2 * C * sizeof(float);
+    if (!ws || ws_bytes < part_bytes + 2 * (size_t)C * sizeof(float)) return PESR_EWORKSPACE;
+    float* part = (float*)ws;
+    float* sums = (float*)((char*)ws + part_bytes);
+    long sn = HW * C, sc = 1, sp = C;
+    if (dy_nchw) { sn = HW * C; sc = HW; sp = 1; }
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb, slope,
+                       sn, sc, sp, HW);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)part, (int)nb, C, sums);
+    const long total = M * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, dy, mean_invstd, gamma, beta, (const float*)sums,
+                       (f32x4*)dx, M, C, slope, HW, sn, sc, sp);
+    int rc = pesr_launch_status();
+    if (rc) return rc;
+    // dbeta = sum dz, dgamma = sum dz*xhat : copy out of `sums` (device-to-device, async)
+    if (dbeta) (void)hipMemcpyAsync(dbeta, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    if (dgamma) (void)hipMemcpyAsync(dgamma, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    return pesr_launch_status();
+}

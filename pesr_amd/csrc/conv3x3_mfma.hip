@@ -38,6 +38,8 @@ struct ConvArgs {
     float alpha, slope;
     int act;
     int ps;                     // 1: output channels are stored pixel-shuffled (r=2), Cout = 4*C
+    int cin_real;               // channels physically present in x (3 for the RGB layers; Cin is then 16, zero padded)
+    int cout_store;             // channels physically present in y (3 for the ->RGB layers; Cout is then 64, zero padded)
     int ps_in;                  // 1: x is a pixel-shuffled tensor [N][2H][2W][Cin/4] read as its
                                 //    un-shuffled, sub-pixel-major [N][H][W][Cin] view (dgrad of a PS conv)
 };
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     for (int j = 0; j < WN; ++j) b_off[j] = ((wave_n * WN + j) * 16 + r) * 64 + g * 16;
 
     // halo staging bookkeeping: element offset of this thread's float4 units inside the image
-    const float* const xi = a.x + (size_t)img * a.H * a.W * a.Cin;
+    const float* const xi = a.x + (size_t)img * a.H * a.W * a.cin_real;
     int h_src[HL];
 #pragma unroll
     for (int k = 0; k < HL; ++k) {
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
             const int hy = hp / a.WT, hx = hp - hy * a.WT;
             const int iy = gy0 * S + a.in_oy + hy, ix = gx0 * S + a.in_ox + hx;
             if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                off = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * (a.Cin >> 2) + q * 4 : (iy * a.W + ix) * a.Cin + q * 4;
+                off = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * (a.Cin >> 2) + q * 4 : (iy * a.W + ix) * a.cin_real + q * 4;
             else
                 off = -1;
         }
@@ -115,6 +117,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
             const int C = a.Cin >> 2;
             const int sub = coff / C, cc0 = coff - sub * C;
             coff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * C + cc0;
+        }
+        if (a.cin_real == 3) {  // RGB input: 3 floats per pixel, chunk 0 only, channels 3..15 are zero
+#pragma unroll
+            for (int k = 0; k < HL; ++k) {
+                const bool ok = h_src[k] >= 0 && ((tid + k * NT) & 3) == 0;
+                const int o = ok ? h_src[k] : 0;
+                const float v0 = xi[o], v1 = xi[o + 1], v2 = xi[o + 2];
+                hreg[k] = ok ? (f32x4){v0, v1, v2, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            return;
         }
 #pragma unroll
         for (int k = 0; k < HL; ++k) {
@@ -202,6 +214,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int co = n0 + (wave_n * WN + j) * 16 + r;
+                if (co >= a.cout_store) continue;
                 float v = acc[i][j][jj];
                 if (a.bias) v += a.bias[co];
                 v *= a.alpha;
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
                     const int sub = co / C, cc = co - sub * C;
                     idx = (((size_t)img * (2 * a.OH) + 2 * oy + (sub >> 1)) * (2 * a.OW) + 2 * ox + (sub & 1)) * C + cc;
                 } else {
-                    idx = (img_out + (size_t)oy * a.OW + ox) * a.Cout + co;
+                    idx = (img_out + (size_t)oy * a.OW + ox) * a.cout_store + co;
                 }
                 if (a.mask) v = a.mask[idx] > 0.f ? v : 0.f;
                 if (a.skip) v += a.skip[idx];
@@ -298,7 +311,12 @@ static int dispatch(ConvArgs& a, int hext, int wext, hipStream_t stream) {
 // (pack.hip mode 1: Cin/Cout swapped) and flip=1 (tap t reads weight tap 8-t).
 int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask,
                         float* y, int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act,
-                        float slope, int ps, int ps_in, int flip, hipStream_t stream) {
+                        float slope, int ps, int ps_in, int flip, int cin_real, int cout_store, hipStream_t stream) {
+    // cin_real / cout_store: physical channel counts of x / y (0 = same as Cin / Cout).  The RGB layers
+    // (3 -> N, N -> 3) run here zero-padded to Cin = 16 / Cout = 64 with 3-channel tensors in memory.
+    if (cin_real == 0) cin_real = Cin;
+    if (cout_store == 0) cout_store = Cout;
+    if ((cin_real != Cin && (cin_real != 3 || Cin != 16 || ps_in)) || (cout_store != Cout && ps)) return PESR_EINVAL;
     if (ps_in && (Cin % 64 || stride != 1)) return PESR_EINVAL;
     if (ps && Cout % 4) return PESR_EINVAL;
     if (Cin % 16 || (stride != 1 && stride != 2) || N <= 0 || H <= 0 || W <= 0) return PESR_EINVAL;
@@ -312,6 +330,7 @@ int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, cons
     a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3; a.tap_dx[t] = t % 3; a.tap_w[t] = flip ? 8 - t : t; }
     a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
+    a.cin_real = cin_real; a.cout_store = cout_store;
     return stride == 1 ? dispatch<1>(a, 3, 3, stream) : dispatch<2>(a, 3, 3, stream);
 }
 
@@ -344,7 +363,8 @@ int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* 
                     a.tap_dy[a.ntaps] = dys[i]; a.tap_dx[a.ntaps] = dxs[j]; a.tap_w[a.ntaps] = kys[i] * 3 + kxs[j];
                     ++a.ntaps;
                 }
-            a.alpha = alpha; a.slope = 0.f; a.act = PESR_ACT_NONE; a.ps = 0;
+            a.alpha = alpha; a.slope = 0.f; a.act = PESR_ACT_NONE; a.ps = 0; a.ps_in = 0;
+            a.cin_real = Cout_fwd; a.cout_store = Cin_fwd;
             const int rc = dispatch<1>(a, py + 1, px + 1, stream);
             if (rc) return rc;
         }

@@ -8,7 +8,7 @@ int pesr_pack_bias_ps_launch(const float* b, float* out, int O, hipStream_t stre
 
 int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
                         int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act, float slope, int ps,
-                        int ps_in, int flip, hipStream_t stream);
+                        int ps_in, int flip, int cin_real, int cout_store, hipStream_t stream);
 int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* mask, float* dx, int N, int H, int W,
                                  int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream);
 
@@ -17,3 +17,38 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
                               int stride, float alpha, int ps_in, void* ws, size_t ws_bytes, hipStream_t stream);
 int pesr_bias_grad_launch(const float* dy, float* db, long pixels, int Cout, int OW, float alpha, int ps_in, float* part,
                           size_t part_bytes, hipStream_t stream);
+
+size_t pesr_conv3x3_wgrad_rgb_ws_bytes(int N, int H, int W, int C);
+int pesr_conv3x3_wgrad_rgb_launch(const float* A, const float* b3, float* dw, float* db, int N, int H, int W, int C, int mode,
+                                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream);
+
+int pesr_meanshift_fwd_launch(const float* x, const float* w, const float* b, float* y, int N, int H, int W, long xsn, long xsc,
+                              long xsp, long ysn, long ysc, long ysp, hipStream_t stream);
+int pesr_meanshift_bwd_launch(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int N, int H,
+                              int W, long xsn, long xsc, long xsp, void* ws, size_t ws_bytes, hipStream_t stream);
+int pesr_pixel_shuffle_launch(const float* in, float* out, int N, int H, int W, int C, int inverse, hipStream_t stream);
+int pesr_relu_mask_launch(const float* g, const float* ref, const float* add, float* out, long n, float alpha, hipStream_t stream);
+int pesr_maxpool2x2_fwd_launch(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream);
+int pesr_maxpool2x2_bwd_launch(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int relu_in, hipStream_t stream);
+
+size_t pesr_bn_ws_bytes(long M, int C);
+int pesr_bn_lrelu_fwd_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean_invstd,
+                             float* running_mean, float* running_var, long long* num_batches, long M, int C, long HW, float eps,
+                             float momentum, float slope, int y_nchw, void* ws, size_t ws_bytes, hipStream_t stream);
+int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
+                             float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, void* ws,
+                             size_t ws_bytes, hipStream_t stream);
+
+size_t pesr_linear_ws_bytes(int M, int N, long K);
+int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float* y, int M, int N, long K, int act, float slope,
+                           void* ws, size_t ws_bytes, hipStream_t stream);
+int pesr_linear_dgrad_launch(const float* dy, const float* W, float* dx, int M, int N, long K, void* ws, size_t ws_bytes,
+                             hipStream_t stream);
+int pesr_linear_wgrad_launch(const float* dy, const float* x, float* dW, float* db, int M, int N, long K, hipStream_t stream);
+
+int pesr_loss_l1_tv_launch(const float* sr, const float* hr, float* grad, float* out2, int N, int H, int W, float g_l1, float g_tv,
+                           void* ws, size_t ws_bytes, hipStream_t stream);
+int pesr_loss_mse_launch(const float* a, const float* b, float* grad, float* out1, long n, float gscale, void* ws, size_t ws_bytes,
+                         hipStream_t stream);
+int pesr_adam_launch(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
+                     float gscale, hipStream_t stream);

@@ -1,0 +1,183 @@
+// Skinny-batch Linear for the Discriminator's classifier (reference model/pesr.py:69-74: Linear(73728, 1024)
+// -> LeakyReLU(0.2) -> Linear(1024, 1); ATen addmm / mm in forward and backward).  M (batch) <= 32.
+// All three passes are HBM-bound on the 302 MB weight matrix, which each streams exactly once:
+//   fwd  : y[m][n]  = act(sum_k x[m][k] W[n][k] + b[n])     split-K partials + fixed-order finalize
+//   dgrad: dx[m][k] = sum_n dy[m][n] W[n][k]                 split-N partials + fixed-order finalize
+//   wgrad: dW[n][k] = sum_m dy[m][n] x[m][k],  db[n] = sum_m dy[m][n]
+#include "common.h"
+#include "launchers.h"
+
+#define LIN_MAXM 32
+
+// ---- forward -----------------------------------------------------------------------------------
+// one wave: NR consecutive output features, one K slice; lanes stride over K with float4 loads.
+template <int MB, int NR>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         float* __restrict__ part, int M, int N, long K, int ksplit, long kchunk) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int ngroups = (N + NR - 1) / NR;
+    const int ng = wave % ngroups, ks = wave / ngroups;
+    if (ks >= ksplit) return;
+    const int n0 = ng * NR;
+    const long k0 = ks * kchunk;
+    long k1 = k0 + kchunk; if (k1 > K) k1 = K;
+    float acc[NR][MB];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+    for (long k = k0 + lane * 4; k < k1; k += 256) {
+        f32x4 w[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) w[r] = (n0 + r < N) ? *(const f32x4*)(W + (size_t)(n0 + r) * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m < M) {
+                const f32x4 xv = *(const f32x4*)(x + (size_t)m * K + k);
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    acc[r][m] = fmaf(w[r].w, xv.w, fmaf(w[r].z, xv.z, fmaf(w[r].y, xv.y, fmaf(w[r].x, xv.x, acc[r][m]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float s = wave_sum(acc[r][m]);
+            if (lane == 0 && m < M && n0 + r < N) part[((size_t)ks * M + m) * N + n0 + r] = s;
+        }
+}
+__global__ void linear_fwd_final_kernel(const float* __restrict__ part, const float* __restrict__ b, float* __restrict__ y, int M,
+                                        int N, int ksplit, int act, float slope) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * N) return;
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += part[(size_t)k * M * N + e];
+    if (b) s += b[e % N];
+    if (act == PESR_ACT_LRELU) s = s > 0.f ? s : s * slope;
+    else if (act == PESR_ACT_RELU) s = s > 0.f ? s : 0.f;
+    y[e] = s;
+}
+
+// ---- dgrad -------------------------------------------------------------------------------------
+// thread: 4 consecutive k, all M rows; loops over an N slice; dy values are wave-uniform (scalar loads).
+template <int MB>
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                           float* __restrict__ part, int M, int N, long K, int nchunk) {
+    const long k = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int ns = blockIdx.y;
+    const int n0 = ns * nchunk;
+    int n1 = n0 + nchunk; if (n1 > N) n1 = N;
+    if (k >= K) return;
+    f32x4 acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = n0; n < n1; ++n) {
+        const f32x4 w = *(const f32x4*)(W + (size_t)n * K + k);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m < M) acc[m] += w * dy[(size_t)m * N + n];
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+        if (m < M) *(f32x4*)(part + ((size_t)ns * M + m) * K + k) = acc[m];
+}
+// finalize: dx = sum over N-slices; the LeakyReLU derivative of the layer below is applied by its own backward
+__global__ void linear_dgrad_final_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dx, long MK4, int nsplit) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < MK4; e += (long)gridDim.x * blockDim.x) {
+        f32x4 s = part[e];
+        for (int k = 1; k < nsplit; ++k) s += part[(size_t)k * MK4 + e];
+        dx[e] = s;
+    }
+}
+
+// ---- wgrad -------------------------------------------------------------------------------------
+// thread: 4 consecutive k with x[0..M)[k4] held in registers; loops over an N slice writing dW rows.
+template <int MB>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dW, int M, int N, long K, int nchunk) {
+    const long k = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int n0 = blockIdx.y * nchunk;
+    int n1 = n0 + nchunk; if (n1 > N) n1 = N;
+    if (k >= K) return;
+    f32x4 xv[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) xv[m] = m < M ? *(const f32x4*)(x + (size_t)m * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = n0; n < n1; ++n) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m < M) s += xv[m] * dy[(size_t)m * N + n];
+        *(f32x4*)(dW + (size_t)n * K + k) = s;
+    }
+}
+__global__ void linear_bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
+    db[n] = s;
+}
+
+namespace {
+struct LinPlan { int ksplit; long kchunk; int nsplit, nchunk; };
+static void lin_plan(int M, int N, long K, LinPlan* p) {
+    // forward: waves = ceil(N/4) * ksplit ~ 4096
+    const int ngroups = (N + 3) / 4;
+    int ks = 4096 / ngroups; if (ks < 1) ks = 1;
+    long kc = ((K + ks - 1) / ks + 255) / 256 * 256;
+    if (kc < 256) kc = 256;
+    p->kchunk = kc; p->ksplit = (int)((K + kc - 1) / kc);
+    // dgrad: blocks = ceil(K/1024) * nsplit ~ 1024
+    const long kb = (K + 1023) / 1024;
+    int ns = (int)(1024 / kb); if (ns < 1) ns = 1; if (ns > N) ns = N; if (ns > 16) ns = 16;
+    p->nchunk = (N + ns - 1) / ns; p->nsplit = (N + p->nchunk - 1) / p->nchunk;
+    (void)M;
+}
+}  // namespace
+
+size_t pesr_linear_ws_bytes(int M, int N, long K) {
+    LinPlan p; lin_plan(M, N, K, &p);
+    const size_t a = (size_t)p.ksplit * M * N * sizeof(float);
+    const size_t b = (size_t)p.nsplit * M * K * sizeof(float);
+    return a > b ? a : b;
+}
+
+int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float* y, int M, int N, long K, int act, float slope,
+                           void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
+    LinPlan p; lin_plan(M, N, K, &p);
+    if (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float)) return PESR_EWORKSPACE;
+    const int ngroups = (N + 3) / 4;
+    const long waves = (long)ngroups * p.ksplit;
+    const int grid = (int)((waves + 3) / 4);
+    if (M <= 16) hipLaunchKernelGGL((linear_fwd_kernel<16, 4>), dim3(grid), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+    else hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), dim3((int)(((long)((N + 1) / 2) * p.ksplit + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+    hipLaunchKernelGGL(linear_fwd_final_kernel, dim3((M * N + 255) / 256), dim3(256), 0, stream, (const float*)ws, b, y, M, N, p.ksplit, act, slope);
+    return pesr_launch_status();
+}
+
+int pesr_linear_dgrad_launch(const float* dy, const float* W, float* dx, int M, int N, long K, void* ws, size_t ws_bytes,
+                             hipStream_t stream) {
+    if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
+    LinPlan p; lin_plan(M, N, K, &p);
+    if (!ws || ws_bytes < (size_t)p.nsplit * M * K * sizeof(float)) return PESR_EWORKSPACE;
+    const dim3 grid((unsigned)((K / 4 + 255) / 256), (unsigned)p.nsplit);
+    if (M <= 16) hipLaunchKernelGGL(linear_dgrad_kernel<16>, grid, dim3(256), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(256), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
+    const long MK4 = (long)M * K / 4;
+    hipLaunchKernelGGL(linear_dgrad_final_kernel, dim3((unsigned)((MK4 + 255) / 256 < 4096 ? (MK4 + 255) / 256 : 4096)), dim3(256), 0, stream,
+                       (const f32x4*)ws, (f32x4*)dx, MK4, p.nsplit);
+    return pesr_launch_status();
+}
+
+int pesr_linear_wgrad_launch(const float* dy, const float* x, float* dW, float* db, int M, int N, long K, hipStream_t stream) {
+    if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
+    int nchunk = 64; if (nchunk > N) nchunk = N;
+    const dim3 grid((unsigned)((K / 4 + 255) / 256), (unsigned)((N + nchunk - 1) / nchunk));
+    if (M <= 16) hipLaunchKernelGGL(linear_wgrad_kernel<16>, grid, dim3(256), 0, stream, dy, x, dW, M, N, K, nchunk);
+    else hipLaunchKernelGGL(linear_wgrad_kernel<32>, grid, dim3(256), 0, stream, dy, x, dW, M, N, K, nchunk);
+    if (db) hipLaunchKernelGGL(linear_bgrad_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dy, db, M, N);
+    return pesr_launch_status();
+}

@@ -11,9 +11,10 @@
 #include "common.h"
 #include "launchers.h"
 
-__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode, int ps) {
-    const int R = mode == 0 ? I : O;   // reduction channels
-    const int Nn = mode == 0 ? O : I;  // "n" channels
+// R (reduction channels) is zero-padded to a multiple of 16 and Nn ("n" channels) to a multiple of 64, so
+// the 3-channel RGB layers run on the same MFMA kernels.
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode, int ps,
+                                    int R, int Nn) {
     const long total = 9L * R * Nn;
     const int C = O >> 2;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -26,7 +27,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
         int o = mode == 0 ? n : red;
         const int i = mode == 0 ? red : n;
         if (ps) { const int sub = o / C, cc = o - sub * C; o = 4 * cc + sub; }
-        out[e] = w[((long)o * I + i) * 9 + t];
+        out[e] = (o < O && i < I) ? w[((long)o * I + i) * 9 + t] : 0.f;
     }
 }
 
@@ -40,12 +41,13 @@ __global__ void pack_bias_ps_kernel(const float* __restrict__ b, float* __restri
 }
 
 int pesr_pack_conv3x3_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream) {
-    const int R = mode == 0 ? I : O;
-    if (R % 16 || (ps && O % 4)) return PESR_EINVAL;
-    const long total = 9L * O * I;
+    const int R = (((mode == 0 ? I : O) + 15) / 16) * 16;
+    const int Nn = (((mode == 0 ? O : I) + 63) / 64) * 64;
+    if (ps && (O % 64 || I % 16)) return PESR_EINVAL;
+    const long total = 9L * R * Nn;
     const int block = 256;
     const int grid = (int)((total + block - 1) / block < 4096 ? (total + block - 1) / block : 4096);
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid), dim3(block), 0, stream, w, out, O, I, mode, ps);
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid), dim3(block), 0, stream, w, out, O, I, mode, ps, R, Nn);
     return pesr_launch_status();
 }
 

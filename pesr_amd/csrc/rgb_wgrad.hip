@@ -1,0 +1,144 @@
+// Weight gradients of the 3x3 convs that touch a 3-channel (RGB) tensor: 3 -> C (reference `embed`
+// model/pesr.py:23, Discriminator features.0 model/pesr.py:53) and C -> 3 (Upsampler's last conv,
+// model/basic.py:60).  Both are the same correlation of a C-channel tensor A with a 3-channel tensor B3:
+//   corr[c][oy][ox][k] = sum_p A[p][c] * B3[p + (oy-1, ox-1)][k]          (zero outside the image)
+//   mode 0 (3 -> C):  A = dy, B3 = x  : dw[c][k][ky][kx] = corr[c][ky][kx][k]
+//   mode 1 (C -> 3):  A = x,  B3 = dy : dw[k][c][ky][kx] = corr[c][2-ky][2-kx][k]
+// HBM-bound on reading A once (27 FMAs per loaded float).  One wave owns 64 channels and a range of
+// image rows; the 27 B3 values of a pixel are wave-uniform, so they come through scalar loads from a
+// zero-padded copy of B3 and feed v_fma as SGPR operands.  Per-wave partial sums are reduced by a
+// second kernel in a fixed order (deterministic).
+#include "common.h"
+#include "launchers.h"
+
+// B3 [N][H][W][3] -> zero-padded [N][H+2][W+2][3]
+__global__ void pad_rgb_kernel(const float* __restrict__ b3, float* __restrict__ out, int N, int H, int W) {
+    const long total = (long)N * (H + 2) * (W + 2) * 3;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(e % 3);
+        long rest = e / 3;
+        const int x = (int)(rest % (W + 2)) - 1; rest /= (W + 2);
+        const int y = (int)(rest % (H + 2)) - 1;
+        const int n = (int)(rest / (H + 2));
+        out[e] = (x >= 0 && x < W && y >= 0 && y < H) ? b3[(((long)n * H + y) * W + x) * 3 + k] : 0.f;
+    }
+}
+
+// grid.x = (C/64) * nsplit blocks of ONE wave (64 threads); lane = channel
+__global__ __launch_bounds__(64) void corr_rgb_kernel(const float* __restrict__ A, const float* __restrict__ b3p,
+                                                      float* __restrict__ part, int NH, int H, int W, int C,
+                                                      int rows_per_split) {
+    const int cg = blockIdx.x % (C >> 6);
+    const int sp = blockIdx.x / (C >> 6);
+    const int c = cg * 64 + threadIdx.x;
+    const int r0 = sp * rows_per_split;
+    int r1 = r0 + rows_per_split; if (r1 > NH) r1 = NH;
+    float acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.f;
+    const int WP = W + 2;
+    for (int row = r0; row < r1; ++row) {
+        const int n = row / H, y = row - n * H;
+        const float* arow = A + (size_t)row * W * C + c;
+        const float* brow = b3p + ((size_t)n * (H + 2) + y) * WP * 3;  // padded row y-1 of image n
+        for (int x0 = 0; x0 < W; x0 += 4) {
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = (x0 + u < W) ? arow[(size_t)(x0 + u) * C] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (x0 + u < W) {
+                    const float* b = brow + (x0 + u) * 3;  // top-left neighbour (y-1, x-1) in padded coords
+#pragma unroll
+                    for (int oy = 0; oy < 3; ++oy)
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) acc[oy * 9 + j] = fmaf(a[u], b[oy * WP * 3 + j], acc[oy * 9 + j]);
+                }
+            }
+        }
+    }
+    float* o = part + ((size_t)sp * C + c) * 27;
+#pragma unroll
+    for (int i = 0; i < 27; ++i) o[i] = acc[i];
+}
+
+__global__ void corr_rgb_final_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int C, int mode,
+                                      float alpha) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // e = c*27 + oy*9 + ox*3 + k
+    if (e >= C * 27) return;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += (double)part[(size_t)k * C * 27 + e];
+    const int c = e / 27, rem = e - c * 27;
+    const int oy = rem / 9, ox = (rem - oy * 9) / 3, k = rem % 3;
+    const float v = alpha * (float)s;
+    if (mode == 0) dw[((c * 3 + k) * 3 + oy) * 3 + ox] = v;                    // [C][3][3][3]
+    else dw[(((size_t)k * C + c) * 3 + (2 - oy)) * 3 + (2 - ox)] = v;          // [3][C][3][3]
+}
+
+// column sums of a 3-channel tensor [P][3] -> db[3]
+__global__ __launch_bounds__(256) void colsum3_kernel(const float* __restrict__ t, float* __restrict__ part, long P) {
+    float s[3] = {0.f, 0.f, 0.f};
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        s[0] += t[p * 3]; s[1] += t[p * 3 + 1]; s[2] += t[p * 3 + 2];
+    }
+    __shared__ float red[4][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float w = wave_sum(s[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) part[blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum3_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nb, float alpha) {
+    if (threadIdx.x < 3) {
+        double s = 0.0;
+        for (int k = 0; k < nb; ++k) s += (double)part[k * 3 + threadIdx.x];
+        db[threadIdx.x] = alpha * (float)s;
+    }
+}
+
+namespace {
+struct RgbPlan { int nsplit, rows_per_split; size_t pad_bytes, part_bytes, bias_bytes, total; };
+static bool rgb_plan(int N, int H, int W, int C, RgbPlan* p) {
+    if (C % 64) return false;
+    const int NH = N * H;
+    int want = 4096 / (C / 64);
+    if (want > NH) want = NH;
+    if (want < 1) want = 1;
+    p->rows_per_split = (NH + want - 1) / want;
+    p->nsplit = (NH + p->rows_per_split - 1) / p->rows_per_split;
+    p->pad_bytes = ((size_t)N * (H + 2) * (W + 2) * 3 * sizeof(float) + 255) / 256 * 256;
+    p->part_bytes = ((size_t)p->nsplit * C * 27 * sizeof(float) + 255) / 256 * 256;
+    p->bias_bytes = (size_t)2048 * 2 * (C > 4 ? C : 4) * sizeof(float);
+    p->total = p->pad_bytes + p->part_bytes + p->bias_bytes;
+    return true;
+}
+}  // namespace
+
+size_t pesr_conv3x3_wgrad_rgb_ws_bytes(int N, int H, int W, int C) {
+    RgbPlan p;
+    return rgb_plan(N, H, W, C, &p) ? p.total : 0;
+}
+
+int pesr_conv3x3_wgrad_rgb_launch(const float* A, const float* b3, float* dw, float* db, int N, int H, int W, int C, int mode,
+                                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream) {
+    RgbPlan p;
+    if (!rgb_plan(N, H, W, C, &p)) return PESR_EINVAL;
+    if (!ws || ws_bytes < p.total) return PESR_EWORKSPACE;
+    float* b3p = (float*)ws;
+    float* part = (float*)((char*)ws + p.pad_bytes);
+    float* bpart = (float*)((char*)ws + p.pad_bytes + p.part_bytes);
+    const long padn = (long)N * (H + 2) * (W + 2) * 3;
+    hipLaunchKernelGGL(pad_rgb_kernel, dim3((unsigned)((padn + 255) / 256 < 2048 ? (padn + 255) / 256 : 2048)), dim3(256), 0, stream, b3, b3p, N, H, W);
+    hipLaunchKernelGGL(corr_rgb_kernel, dim3((C / 64) * p.nsplit), dim3(64), 0, stream, A, (const float*)b3p, part, N * H, H, W, C, p.rows_per_split);
+    hipLaunchKernelGGL(corr_rgb_final_kernel, dim3((C * 27 + 255) / 256), dim3(256), 0, stream, (const float*)part, dw, p.nsplit, C, mode, alpha);
+    int rc = pesr_launch_status();
+    if (rc || !db) return rc;
+    const long P = (long)N * H * W;
+    if (mode == 0) return pesr_bias_grad_launch(A, db, P, C, W, alpha, 0, bpart, p.bias_bytes, stream);
+    const int nb = 512;
+    hipLaunchKernelGGL(colsum3_kernel, dim3(nb), dim3(256), 0, stream, b3, bpart, P);
+    hipLaunchKernelGGL(colsum3_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)bpart, db, nb, alpha);
+    return pesr_launch_status();
+}

@@ -54,7 +54,8 @@ def pack_conv3x3(w: torch.Tensor, mode: int, ps: bool = False) -> torch.Tensor:
     _chk(w, "pack_conv3x3.w")
     O, I = w.shape[0], w.shape[1]
     assert w.shape[2:] == (3, 3)
-    out = torch.empty(9 * O * I, dtype=torch.float32, device=w.device)
+    R, Nn = (I, O) if mode == 0 else (O, I)
+    out = torch.empty(9 * ((R + 15) // 16 * 16) * ((Nn + 63) // 64 * 64), dtype=torch.float32, device=w.device)
     _lib.check(_lib.lib().pesr_pack_conv3x3(_p(w), _p(out), O, I, mode, int(ps), _stream()), "pesr_pack_conv3x3")
     return out
 
@@ -125,3 +126,190 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
                               ws.numel(), _stream())
     _lib.check(rc, f"pesr_conv3x3_wgrad[{N}x{H}x{W}x{Cin}->{cout},s{stride}]")
     return dw, db
+
+
+def conv3x3_wgrad_rgb(a: torch.Tensor, b3: torch.Tensor, mode: int, alpha: float = 1.0, want_bias: bool = True):
+    """Weight grad of a conv with a 3-channel side. mode 0: a=dy [N,H,W,C], b3=x -> dw [C,3,3,3]; mode 1: a=x, b3=dy -> dw [3,C,3,3]."""
+    _chk(a, "conv3x3_wgrad_rgb.a")
+    _chk(b3, "conv3x3_wgrad_rgb.b3")
+    N, H, W, C = a.shape
+    assert b3.shape == (N, H, W, 3)
+    L = _lib.lib()
+    nbytes = L.pesr_conv3x3_wgrad_rgb_workspace_bytes(N, H, W, C)
+    if nbytes == 0:
+        raise _lib.PesrHipError(f"pesr_conv3x3_wgrad_rgb: unsupported channel count {C}")
+    ws = workspace(nbytes, a.device)
+    dw = torch.empty((C, 3, 3, 3) if mode == 0 else (3, C, 3, 3), dtype=torch.float32, device=a.device)
+    db = torch.empty((C if mode == 0 else 3,), dtype=torch.float32, device=a.device) if want_bias else None
+    rc = L.pesr_conv3x3_wgrad_rgb(_p(a), _p(b3), _p(dw), _p(db), N, H, W, C, mode, alpha, _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "pesr_conv3x3_wgrad_rgb")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------------------
+# MeanShift / PixelShuffle / masks / pooling
+# ------------------------------------------------------------------------------------------------
+def meanshift_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, x_nchw: bool = False, y_nchw: bool = False):
+    """x: [N,H,W,3] (or [N,3,H,W] contiguous when x_nchw) -> y in NHWC (or NCHW when y_nchw)."""
+    _chk(x, "meanshift_fwd.x")
+    if x_nchw:
+        N, _, H, W = x.shape
+    else:
+        N, H, W, _ = x.shape
+    y = torch.empty((N, 3, H, W) if y_nchw else (N, H, W, 3), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().pesr_meanshift_fwd(_p(x), _p(w), _p(b), _p(y), N, H, W, int(x_nchw), int(y_nchw), _stream())
+    _lib.check(rc, "pesr_meanshift_fwd")
+    return y
+
+
+def meanshift_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, x_nchw: bool = False, need_dx: bool = True):
+    _chk(dy, "meanshift_bwd.dy")
+    N, H, W, _ = dy.shape
+    dx = torch.empty_like(dy) if need_dx else None
+    dw = torch.empty((3, 3, 1, 1), dtype=torch.float32, device=dy.device)
+    db = torch.empty((3,), dtype=torch.float32, device=dy.device)
+    ws = workspace(1024 * 12 * 4, dy.device)
+    rc = _lib.lib().pesr_meanshift_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), N, H, W, int(x_nchw), _p(ws),
+                                       ws.numel(), _stream())
+    _lib.check(rc, "pesr_meanshift_bwd")
+    return dx, dw, db
+
+
+def pixel_shuffle_fwd(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, "pixel_shuffle_fwd.x")
+    N, H, W, C4 = x.shape
+    y = torch.empty((N, 2 * H, 2 * W, C4 // 4), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pesr_pixel_shuffle_fwd(_p(x), _p(y), N, H, W, C4 // 4, _stream()), "pesr_pixel_shuffle_fwd")
+    return y
+
+
+def pixel_shuffle_bwd(dy: torch.Tensor) -> torch.Tensor:
+    _chk(dy, "pixel_shuffle_bwd.dy")
+    N, H2, W2, C = dy.shape
+    dx = torch.empty((N, H2 // 2, W2 // 2, 4 * C), dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().pesr_pixel_shuffle_bwd(_p(dy), _p(dx), N, H2 // 2, W2 // 2, C, _stream()), "pesr_pixel_shuffle_bwd")
+    return dx
+
+
+def relu_mask(g: torch.Tensor, ref: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
+              alpha: float = 1.0) -> torch.Tensor:
+    _chk(g, "relu_mask.g")
+    out = torch.empty_like(g)
+    _lib.check(_lib.lib().pesr_relu_mask(_p(g), _p(ref), _p(add), _p(out), g.numel(), alpha, _stream()), "pesr_relu_mask")
+    return out
+
+
+def maxpool2x2_fwd(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, "maxpool2x2_fwd.x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pesr_maxpool2x2_fwd(_p(x), _p(y), N, H, W, C, _stream()), "pesr_maxpool2x2_fwd")
+    return y
+
+
+def maxpool2x2_bwd(x: torch.Tensor, dy: torch.Tensor, relu_in: bool) -> torch.Tensor:
+    _chk(dy, "maxpool2x2_bwd.dy")
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().pesr_maxpool2x2_bwd(_p(x), _p(dy), _p(dx), N, H, W, C, int(relu_in), _stream()), "pesr_maxpool2x2_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm(train) + LeakyReLU
+# ------------------------------------------------------------------------------------------------
+def bn_lrelu_fwd(x, gamma, beta, running_mean, running_var, num_batches, eps=1e-5, momentum=0.1, slope=0.2,
+                 y_nchw=False):
+    _chk(x, "bn_lrelu_fwd.x")
+    N, H, W, C = x.shape
+    L = _lib.lib()
+    ws = workspace(L.pesr_bn_workspace_bytes(N * H * W, C), x.device)
+    y = torch.empty((N, C, H, W) if y_nchw else (N, H, W, C), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    rc = L.pesr_bn_lrelu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(running_mean), _p(running_var),
+                             _p(num_batches), N, H, W, C, eps, momentum, slope, int(y_nchw), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "pesr_bn_lrelu_fwd")
+    return y, stats
+
+
+def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param_grads=True):
+    _chk(dy, "bn_lrelu_bwd.dy")
+    N, H, W, C = x.shape
+    L = _lib.lib()
+    ws = workspace(L.pesr_bn_workspace_bytes(N * H * W, C), x.device)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if need_param_grads else None
+    dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if need_param_grads else None
+    rc = L.pesr_bn_lrelu_bwd(_p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), N, H, W, C, slope,
+                             int(dy_nchw), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "pesr_bn_lrelu_bwd")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear
+# ------------------------------------------------------------------------------------------------
+def linear_fwd(x, w, b, act=ACT_NONE, slope=0.0):
+    _chk(x, "linear_fwd.x")
+    M, K = x.shape
+    Nf = w.shape[0]
+    L = _lib.lib()
+    ws = workspace(L.pesr_linear_workspace_bytes(M, Nf, K), x.device)
+    y = torch.empty((M, Nf), dtype=torch.float32, device=x.device)
+    _lib.check(L.pesr_linear_fwd(_p(x), _p(w), _p(b), _p(y), M, Nf, K, act, slope, _p(ws), ws.numel(), _stream()), "pesr_linear_fwd")
+    return y
+
+
+def linear_dgrad(dy, w):
+    _chk(dy, "linear_dgrad.dy")
+    M, Nf = dy.shape
+    K = w.shape[1]
+    L = _lib.lib()
+    ws = workspace(L.pesr_linear_workspace_bytes(M, Nf, K), dy.device)
+    dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    _lib.check(L.pesr_linear_dgrad(_p(dy), _p(w), _p(dx), M, Nf, K, _p(ws), ws.numel(), _stream()), "pesr_linear_dgrad")
+    return dx
+
+
+def linear_wgrad(dy, x, want_bias=True):
+    _chk(dy, "linear_wgrad.dy")
+    M, Nf = dy.shape
+    K = x.shape[1]
+    dw = torch.empty((Nf, K), dtype=torch.float32, device=dy.device)
+    db = torch.empty((Nf,), dtype=torch.float32, device=dy.device) if want_bias else None
+    _lib.check(_lib.lib().pesr_linear_wgrad(_p(dy), _p(x), _p(dw), _p(db), M, Nf, K, _stream()), "pesr_linear_wgrad")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------------------
+# losses / optimizer
+# ------------------------------------------------------------------------------------------------
+def loss_l1_tv(sr, hr, g_l1: float, g_tv: float, need_grad=True):
+    """-> (out2 device tensor [l1_mean, tv_sum], grad [N,H,W,3] | None)"""
+    _chk(sr, "loss_l1_tv.sr")
+    _chk(hr, "loss_l1_tv.hr")
+    N, H, W, _ = sr.shape
+    out = torch.empty((2,), dtype=torch.float32, device=sr.device)
+    grad = torch.empty_like(sr) if need_grad else None
+    ws = workspace(8192, sr.device)
+    rc = _lib.lib().pesr_loss_l1_tv_fwd_bwd(_p(sr), _p(hr), _p(grad), _p(out), N, H, W, g_l1, g_tv, _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "pesr_loss_l1_tv_fwd_bwd")
+    return out, grad
+
+
+def loss_mse(a, b, gscale: float, need_grad=True):
+    _chk(a, "loss_mse.a")
+    _chk(b, "loss_mse.b")
+    out = torch.empty((1,), dtype=torch.float32, device=a.device)
+    grad = torch.empty_like(a) if need_grad else None
+    ws = workspace(8192, a.device)
+    rc = _lib.lib().pesr_mse_fwd_bwd(_p(a), _p(b), _p(grad), _p(out), a.numel(), gscale, _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "pesr_mse_fwd_bwd")
+    return out, grad
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, f"adam_step.{n}")
+    rc = _lib.lib().pesr_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream())
+    _lib.check(rc, "pesr_adam_step")

@@ -1,0 +1,164 @@
+"""GPU parity of the non-MFMA kernels (through the C ABI) vs torch-CPU restatements (oracle/ops.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detrand
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, lo=-1.0, hi=1.0):
+    return detrand.uniform(shape, seed, lo, hi)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _nchw(y):
+    return y.permute(0, 3, 1, 2).cpu()
+
+
+def _close(a, b, rel, what=""):
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e} > {rel})"
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 12, 12, 64), (1, 9, 7, 256)])
+def test_rgb_convs(N, H, W, C):
+    """3 -> C and C -> 3 convs (zero-padded onto the MFMA kernel) and their grads."""
+    from pesr_amd import ops
+    x3 = detrand.image_batch((N, 3, H, W), 3)
+    w = _rand(C, 3, 3, 3, seed=2, lo=-0.2, hi=0.2)
+    b = _rand(C, seed=4)
+    # forward 3 -> C
+    wp = ops.pack_conv3x3(w.cuda(), 0)
+    y = ops.conv3x3_fwd(_nhwc(x3), wp, b.cuda(), C, act=ops.ACT_RELU)
+    _close(_nchw(y), torch.relu(O.conv3x3(x3, w, b)), 1e-5, "fwd 3->C")
+    dy = _rand(N, C, H, W, seed=5)
+    dx_ref, dw_ref, db_ref = O.conv3x3_grads(x3, w, dy)
+    wpd = ops.pack_conv3x3(w.cuda(), 1)
+    dx = ops.conv3x3_dgrad(_nhwc(dy), wpd, (N, H, W, 3))
+    _close(_nchw(dx), dx_ref, 1e-5, "dgrad C->3")
+    dw, db = ops.conv3x3_wgrad_rgb(_nhwc(dy), _nhwc(x3), 0)
+    _close(dw.cpu(), dw_ref, 1e-5, "wgrad 3->C")
+    _close(db.cpu(), db_ref, 1e-5, "bgrad 3->C")
+    # forward C -> 3
+    xc = _rand(N, C, H, W, seed=6)
+    w2 = _rand(3, C, 3, 3, seed=7, lo=-0.1, hi=0.1)
+    b2 = _rand(3, seed=8)
+    wp2 = ops.pack_conv3x3(w2.cuda(), 0)
+    y2 = ops.conv3x3_fwd(_nhwc(xc), wp2, b2.cuda(), 3)
+    assert y2.shape == (N, H, W, 3)
+    _close(_nchw(y2), O.conv3x3(xc, w2, b2), 1e-5, "fwd C->3")
+    dy3 = _rand(N, 3, H, W, seed=9)
+    dx_ref, dw_ref, db_ref = O.conv3x3_grads(xc, w2, dy3)
+    dx2 = ops.conv3x3_dgrad(_nhwc(dy3), ops.pack_conv3x3(w2.cuda(), 1), (N, H, W, C))
+    _close(_nchw(dx2), dx_ref, 1e-5, "dgrad 3->C")
+    dw2, db2 = ops.conv3x3_wgrad_rgb(_nhwc(xc), _nhwc(dy3), 1)
+    _close(dw2.cpu(), dw_ref, 1e-5, "wgrad C->3")
+    _close(db2.cpu(), db_ref, 1e-5, "bgrad C->3")
+
+
+def test_meanshift():
+    from pesr_amd import ops
+    x = detrand.image_batch((2, 3, 10, 14), 1)
+    w = (torch.eye(3) + _rand(3, 3, seed=2, lo=-0.1, hi=0.1)).view(3, 3, 1, 1)
+    b = _rand(3, seed=3, lo=-100, hi=100)
+    ref = F.conv2d(x, w, b)
+    y = ops.meanshift_fwd(x.cuda().contiguous(), w.cuda(), b.cuda(), x_nchw=True)      # NCHW in -> NHWC out
+    _close(_nchw(y), ref, 1e-6, "meanshift fwd nchw-in")
+    y2 = ops.meanshift_fwd(_nhwc(x), w.cuda(), b.cuda(), y_nchw=True)                   # NHWC in -> NCHW out
+    _close(y2.cpu(), ref, 1e-6, "meanshift fwd nchw-out")
+    dy = _rand(2, 3, 10, 14, seed=4)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    F.conv2d(xr, wr, br).backward(dy)
+    dx, dw, db = ops.meanshift_bwd(_nhwc(dy), x.cuda().contiguous(), w.cuda(), x_nchw=True)
+    _close(_nchw(dx), xr.grad, 1e-6); _close(dw.cpu(), wr.grad, 1e-5); _close(db.cpu(), br.grad, 1e-5)
+
+
+def test_pixel_shuffle_bit_exact():
+    from pesr_amd import ops
+    x = torch.arange(2 * 16 * 3 * 5, dtype=torch.float32).reshape(2, 16, 3, 5)
+    y = ops.pixel_shuffle_fwd(_nhwc(x))
+    assert torch.equal(_nchw(y), O.pixel_shuffle(x))
+    gy = torch.arange(y.numel(), dtype=torch.float32).reshape(2, 4, 6, 10) * 0.5
+    gx = ops.pixel_shuffle_bwd(_nhwc(gy))
+    assert torch.equal(_nchw(gx), O.pixel_unshuffle(gy))
+
+
+def test_maxpool_and_relu_mask():
+    from pesr_amd import ops
+    x = torch.relu(_rand(2, 8, 6, 10, seed=1))
+    y = ops.maxpool2x2_fwd(_nhwc(x))
+    assert torch.equal(_nchw(y), F.max_pool2d(x, 2, 2))
+    xr = _rand(2, 8, 6, 10, seed=1).requires_grad_(True)
+    dy = _rand(2, 8, 3, 5, seed=2)
+    F.max_pool2d(torch.relu(xr), 2, 2).backward(dy)
+    dx = ops.maxpool2x2_bwd(_nhwc(x), _nhwc(dy), relu_in=True)       # pool backward + ReLU mask in one pass
+    _close(_nchw(dx), xr.grad, 1e-7)
+    g = _rand(2, 8, 6, 10, seed=3)
+    out = ops.relu_mask(_nhwc(g), _nhwc(x), _nhwc(g), alpha=0.5)
+    _close(_nchw(out), 0.5 * g * (x > 0) + g, 1e-7)
+
+
+@pytest.mark.parametrize("N,C,H,W,nchw", [(4, 64, 16, 16, False), (4, 512, 2, 2, True), (3, 128, 5, 7, False)])
+def test_bn_lrelu(N, C, H, W, nchw):
+    from pesr_amd import ops
+    x = _rand(N, C, H, W, seed=1, lo=-2, hi=3)
+    gamma = _rand(C, seed=2, lo=0.5, hi=1.5); beta = _rand(C, seed=3, lo=-0.3, hi=0.3)
+    rm = torch.zeros(C); rv = torch.ones(C)
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    ref = F.leaky_relu(F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5), 0.2)
+    rmg = torch.zeros(C).cuda(); rvg = torch.ones(C).cuda(); nb = torch.zeros((), dtype=torch.long).cuda()
+    y, stats = ops.bn_lrelu_fwd(_nhwc(x), gamma.cuda(), beta.cuda(), rmg, rvg, nb, y_nchw=nchw)
+    yy = y.cpu() if nchw else _nchw(y)
+    _close(yy, ref.detach(), 2e-5, "bn fwd")
+    _close(rmg.cpu(), rm, 1e-5, "running_mean"); _close(rvg.cpu(), rv, 1e-4, "running_var"); assert int(nb) == 1
+    dy = _rand(N, C, H, W, seed=4)
+    ref.backward(dy)
+    dyg = dy.cuda().contiguous() if nchw else _nhwc(dy)
+    dx, dg, db = ops.bn_lrelu_bwd(_nhwc(x), dyg, gamma.cuda(), beta.cuda(), stats, dy_nchw=nchw)
+    _close(_nchw(dx), xr.grad, 5e-5, "bn dx"); _close(dg.cpu(), gr.grad, 5e-5, "dgamma"); _close(db.cpu(), br.grad, 5e-5, "dbeta")
+
+
+@pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (16, 1024, 73728)])
+def test_linear(M, N, K):
+    from pesr_amd import ops
+    x = _rand(M, K, seed=1); w = _rand(N, K, seed=2, lo=-0.01, hi=0.01); b = _rand(N, seed=3)
+    ref = F.leaky_relu(F.linear(x, w, b), 0.2)
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), ops.ACT_LRELU, 0.2)
+    _close(y.cpu(), ref, 2e-5, "linear fwd")
+    dy = _rand(M, N, seed=4)
+    dx = ops.linear_dgrad(dy.cuda(), w.cuda())
+    _close(dx.cpu(), dy @ w, 2e-5, "linear dgrad")
+    dw, db = ops.linear_wgrad(dy.cuda(), x.cuda())
+    _close(dw.cpu(), dy.t() @ x, 2e-5, "linear wgrad"); _close(db.cpu(), dy.sum(0), 1e-5, "linear bgrad")
+
+
+def test_losses_and_adam():
+    from pesr_amd import ops
+    from oracle import step as OS
+    sr = (detrand.image_batch((2, 3, 10, 12), 51) + _rand(2, 3, 10, 12, seed=52, lo=-0.5, hi=0.5)).requires_grad_(True)
+    hr = detrand.image_batch((2, 3, 10, 12), 53)
+    l1 = F.l1_loss(sr, hr); tv = OS.tv_loss(sr)
+    (0.3 * l1 + 1e-3 * tv).backward()
+    out, grad = ops.loss_l1_tv(_nhwc(sr.detach()), _nhwc(hr), 0.3 / sr.numel(), 1e-3)
+    _close(out.cpu(), torch.stack([l1.detach(), tv.detach()]), 1e-6, "l1/tv")
+    _close(_nchw(grad), sr.grad, 1e-6, "l1/tv grad")
+    a = _rand(2, 512, 3, 3, seed=1).requires_grad_(True); b = _rand(2, 512, 3, 3, seed=2)
+    m = F.mse_loss(a, b); (50 * m).backward()
+    out, g = ops.loss_mse(_nhwc(a.detach()), _nhwc(b), 50 * 2.0 / a.numel())
+    _close(out.cpu(), m.detach().reshape(1), 1e-6, "mse"); _close(_nchw(g), a.grad, 1e-6, "mse grad")
+    # Adam: 3 steps vs torch.optim.Adam
+    p = _rand(4096, seed=3).requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=5e-5, betas=(0.9, 0.999))
+    pg = p.detach().clone().cuda(); mg = torch.zeros(4096).cuda(); vg = torch.zeros(4096).cuda()
+    for it in range(1, 4):
+        gr = _rand(4096, seed=10 + it, lo=-3, hi=3)
+        p.grad = gr.clone(); opt.step()
+        ops.adam_step(pg, gr.cuda(), mg, vg, 5e-5, 0.9, 0.999, 1e-8, it)
+    _close(pg.cpu(), p.detach(), 1e-6, "adam")
