@@ -85,8 +85,10 @@ int pesr_meanshift_bwd(const float* dy, const float* x, const float* w, float* d
 int pesr_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int pesr_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 
-/* out = (ref > 0 ? alpha*g : 0) + add : ReLU threshold_backward (+ residual fan-in); ref/add may be NULL */
-int pesr_relu_mask(const float* g, const float* ref, const float* add, float* out, long n, float alpha, void* stream);
+/* out = (ref > 0 ? alpha*g : slope*alpha*g) + add : ReLU (slope 0) / LeakyReLU backward (+ residual fan-in);
+ * ref/add may be NULL */
+int pesr_relu_mask(const float* g, const float* ref, const float* add, float* out, long n, float alpha, float slope,
+                   void* stream);
 
 /* ---- 2x2/2 max-pool (torchvision vgg19 features, reference model/vgg.py:8-10) ------------------ */
 int pesr_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);

@@ -34,7 +34,7 @@ SIGNATURES.update({
     "pesr_meanshift_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "pesr_pixel_shuffle_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "pesr_pixel_shuffle_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
-    "pesr_relu_mask": (c_int, [_P, _P, _P, _P, c_long, c_float, _P]),
+    "pesr_relu_mask": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, _P]),
     "pesr_maxpool2x2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "pesr_maxpool2x2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pesr_bn_workspace_bytes": (c_size_t, [c_long, c_int]),

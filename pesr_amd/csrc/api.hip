@@ -70,8 +70,9 @@ PESR_API int pesr_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int 
 PESR_API int pesr_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
     return pesr_pixel_shuffle_launch(dy, dx, N, H, W, C, 1, (hipStream_t)stream);
 }
-PESR_API int pesr_relu_mask(const float* g, const float* ref, const float* add, float* out, long n, float alpha, void* stream) {
-    return pesr_relu_mask_launch(g, ref, add, out, n, alpha, (hipStream_t)stream);
+PESR_API int pesr_relu_mask(const float* g, const float* ref, const float* add, float* out, long n, float alpha, float slope,
+                            void* stream) {
+    return pesr_relu_mask_launch(g, ref, add, out, n, alpha, slope, (hipStream_t)stream);
 }
 PESR_API int pesr_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
     return pesr_maxpool2x2_fwd_launch(x, y, N, H, W, C, (hipStream_t)stream);

@@ -12,7 +12,8 @@
 // segment the 3-row input halo and the dy row segment are staged through registers into LDS (double
 // buffered, one barrier per segment).  Split-K partial blocks go to a workspace slab and a second
 // kernel reduces them in a fixed order (bitwise reproducible, no atomics) into the OIHW parameter
-// layout, applying alpha and the pixel-shuffle channel un-permutation.
+// layout, applying alpha and the pixel-shuffle channel un-permutation.  Channel counts need only be
+// multiples of 4: tiles that overhang Cin / Cout load zeros and skip their stores.
 #include "common.h"
 #include "launchers.h"
 
@@ -68,8 +69,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
     f32x4 xreg[XL], dreg[DL];
 
     // dy channel base for this workgroup's co tile (ps_in: packed channel p = sub*C + cc)
-    int d_sub = 0, d_cc0 = co0, d_C = a.Cout;
-    if (a.ps_in) { d_C = a.Cout >> 2; d_sub = co0 / d_C; d_cc0 = co0 - d_sub * d_C; }
+    const int d_C = a.ps_in ? (a.Cout >> 2) : a.Cout;
 
     auto load_seg = [&](int seg) {
         const int xs = seg % a.segs_x;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
             const int pix = e / (CI_T / 4);
             const int hx = pix % TWX, hy = pix / TWX;
             const int iy = oy * S - 1 + hy, ix = ox0 * S - 1 + hx;
-            const bool ok = (e < X_F4) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const bool ok = (e < X_F4) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci0 + q * 4 < a.Cin;
             const size_t off = ok ? ((size_t)iy * a.W + ix) * a.Cin + ci0 + q * 4 : 0;
             f32x4 v = *(const f32x4*)(xi + off);
             xreg[k] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -95,12 +95,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
             const int q = e % (CO_T / 4);
             const int px = e / (CO_T / 4);
             const int ox = ox0 + px;
-            const bool ok = (e < D_F4) && ox < a.OW;
+            const bool ok = (e < D_F4) && ox < a.OW && co0 + q * 4 < a.Cout;
             size_t off = 0;
             if (ok) {
-                if (a.ps_in)
-                    off = (((size_t)img * (2 * a.OH) + 2 * oy + (d_sub >> 1)) * (2 * a.OW) + 2 * ox + (d_sub & 1)) * d_C + d_cc0 + q * 4;
-                else
+                if (a.ps_in) {  // packed channel p = sub*Cq + cc lives at shuffled pixel (2oy + sub/2, 2ox + sub%2), channel cc
+                    const int pch = co0 + q * 4;
+                    const int sub = pch / d_C, cc = pch - sub * d_C;
+                    off = (((size_t)img * (2 * a.OH) + 2 * oy + (sub >> 1)) * (2 * a.OW) + 2 * ox + (sub & 1)) * d_C + cc;
+                } else
                     off = (((size_t)img * a.OH + oy) * a.OW + ox) * a.Cout + co0 + q * 4;
             }
             f32x4 v = *(const f32x4*)(a.dy + off);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
             for (int jj = 0; jj < 4; ++jj) {
                 const int co = co0 + (co_half * COW + i) * 16 + g * 4 + jj;
                 const int ci = ci0 + ci_tile * 16 + r;
-                out[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[t][i][jj];
+                if (co < a.Cout && ci < a.Cin) out[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[t][i][jj];
             }
 }
 
@@ -269,12 +271,12 @@ namespace {
 struct WgradPlan { int cow, two, co_tiles, ci_tiles, segs_x, total_segs, split, segs_per_split; size_t slab_bytes, total_bytes; int colsum_blocks; };
 
 static bool wgrad_plan(int N, int H, int W, int Cin, int Cout, int stride, WgradPlan* p) {
-    if (Cin % 64 || Cout % 64 || (stride != 1 && stride != 2)) return false;
+    if (Cin % 4 || Cout % 4 || (stride != 1 && stride != 2)) return false;
     const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
     p->cow = (Cout % 128 == 0) ? 4 : 2;
     p->two = stride == 1 ? 48 : 24;
-    p->co_tiles = Cout / (32 * p->cow);
-    p->ci_tiles = Cin / 64;
+    p->co_tiles = (Cout + 32 * p->cow - 1) / (32 * p->cow);
+    p->ci_tiles = (Cin + 63) / 64;
     p->segs_x = (OW + p->two - 1) / p->two;
     p->total_segs = N * OH * p->segs_x;
     const int out_tiles = p->co_tiles * p->ci_tiles;
@@ -321,7 +323,7 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     WgradPlan p;
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return PESR_EINVAL;
     if (ws_bytes < p.total_bytes || !ws) return PESR_EWORKSPACE;
-    if (ps_in && (stride != 1 || (Cout / 4) % (32 * p.cow))) return PESR_EINVAL;
+    if (ps_in && (stride != 1 || Cout % 16)) return PESR_EINVAL;
     WgradArgs a{};
     a.x = x; a.dy = dy; a.slab = (float*)ws;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;

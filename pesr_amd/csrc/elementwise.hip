@@ -112,25 +112,25 @@ int pesr_pixel_shuffle_launch(const float* in, float* out, int N, int H, int W, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// out = (ref > 0) ? alpha*g : 0   (+ add)   : ReLU's threshold_backward with optional scale / fan-in add
+// out = (ref > 0) ? alpha*g : slope*alpha*g   (+ add) : (Leaky)ReLU backward with optional scale / fan-in add
 // ------------------------------------------------------------------------------------------------
 __global__ void relu_mask_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ ref, const f32x4* __restrict__ add,
-                                 f32x4* __restrict__ out, long n4, float alpha) {
+                                 f32x4* __restrict__ out, long n4, float alpha, float slope) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
         f32x4 v = g[e] * alpha;
         if (ref) {
             const f32x4 r = ref[e];
-            v.x = r.x > 0.f ? v.x : 0.f; v.y = r.y > 0.f ? v.y : 0.f; v.z = r.z > 0.f ? v.z : 0.f; v.w = r.w > 0.f ? v.w : 0.f;
+            v.x = r.x > 0.f ? v.x : v.x * slope; v.y = r.y > 0.f ? v.y : v.y * slope; v.z = r.z > 0.f ? v.z : v.z * slope; v.w = r.w > 0.f ? v.w : v.w * slope;
         }
         if (add) v += add[e];
         out[e] = v;
     }
 }
-int pesr_relu_mask_launch(const float* g, const float* ref, const float* add, float* out, long n, float alpha, hipStream_t stream) {
+int pesr_relu_mask_launch(const float* g, const float* ref, const float* add, float* out, long n, float alpha, float slope, hipStream_t stream) {
     if (n % 4) return PESR_EINVAL;
     const long n4 = n / 4;
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)g, (const f32x4*)ref, (const f32x4*)add, (f32x4*)out, n4, alpha);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)g, (const f32x4*)ref, (const f32x4*)add, (f32x4*)out, n4, alpha, slope);
     return pesr_launch_status();
 }
 

@@ -27,7 +27,7 @@ int pesr_meanshift_fwd_launch(const float* x, const float* w, const float* b, fl
 int pesr_meanshift_bwd_launch(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int N, int H,
                               int W, long xsn, long xsc, long xsp, void* ws, size_t ws_bytes, hipStream_t stream);
 int pesr_pixel_shuffle_launch(const float* in, float* out, int N, int H, int W, int C, int inverse, hipStream_t stream);
-int pesr_relu_mask_launch(const float* g, const float* ref, const float* add, float* out, long n, float alpha, hipStream_t stream);
+int pesr_relu_mask_launch(const float* g, const float* ref, const float* add, float* out, long n, float alpha, float slope, hipStream_t stream);
 int pesr_maxpool2x2_fwd_launch(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream);
 int pesr_maxpool2x2_bwd_launch(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int relu_in, hipStream_t stream);
 

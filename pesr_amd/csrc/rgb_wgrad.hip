@@ -28,9 +28,11 @@ __global__ void pad_rgb_kernel(const float* __restrict__ b3, float* __restrict__
 __global__ __launch_bounds__(64) void corr_rgb_kernel(const float* __restrict__ A, const float* __restrict__ b3p,
                                                       float* __restrict__ part, int NH, int H, int W, int C,
                                                       int rows_per_split) {
-    const int cg = blockIdx.x % (C >> 6);
-    const int sp = blockIdx.x / (C >> 6);
+    const int ngroups = (C + 63) >> 6;
+    const int cg = blockIdx.x % ngroups;
+    const int sp = blockIdx.x / ngroups;
     const int c = cg * 64 + threadIdx.x;
+    if (c >= C) return;
     const int r0 = sp * rows_per_split;
     int r1 = r0 + rows_per_split; if (r1 > NH) r1 = NH;
     float acc[27];
@@ -101,9 +103,9 @@ __global__ void colsum3_final_kernel(const float* __restrict__ part, float* __re
 namespace {
 struct RgbPlan { int nsplit, rows_per_split; size_t pad_bytes, part_bytes, bias_bytes, total; };
 static bool rgb_plan(int N, int H, int W, int C, RgbPlan* p) {
-    if (C % 64) return false;
+    if (C < 1) return false;
     const int NH = N * H;
-    int want = 4096 / (C / 64);
+    int want = 4096 / ((C + 63) / 64);
     if (want > NH) want = NH;
     if (want < 1) want = 1;
     p->rows_per_split = (NH + want - 1) / want;
@@ -131,12 +133,12 @@ int pesr_conv3x3_wgrad_rgb_launch(const float* A, const float* b3, float* dw, fl
     float* bpart = (float*)((char*)ws + p.pad_bytes + p.part_bytes);
     const long padn = (long)N * (H + 2) * (W + 2) * 3;
     hipLaunchKernelGGL(pad_rgb_kernel, dim3((unsigned)((padn + 255) / 256 < 2048 ? (padn + 255) / 256 : 2048)), dim3(256), 0, stream, b3, b3p, N, H, W);
-    hipLaunchKernelGGL(corr_rgb_kernel, dim3((C / 64) * p.nsplit), dim3(64), 0, stream, A, (const float*)b3p, part, N * H, H, W, C, p.rows_per_split);
+    hipLaunchKernelGGL(corr_rgb_kernel, dim3(((C + 63) / 64) * p.nsplit), dim3(64), 0, stream, A, (const float*)b3p, part, N * H, H, W, C, p.rows_per_split);
     hipLaunchKernelGGL(corr_rgb_final_kernel, dim3((C * 27 + 255) / 256), dim3(256), 0, stream, (const float*)part, dw, p.nsplit, C, mode, alpha);
     int rc = pesr_launch_status();
     if (rc || !db) return rc;
     const long P = (long)N * H * W;
-    if (mode == 0) return pesr_bias_grad_launch(A, db, P, C, W, alpha, 0, bpart, p.bias_bytes, stream);
+    if (mode == 0) return pesr_bias_grad_launch(A, db, P, C, W, alpha, 0, bpart, p.bias_bytes, stream);  // needs C % 4 == 0
     const int nb = 512;
     hipLaunchKernelGGL(colsum3_kernel, dim3(nb), dim3(256), 0, stream, b3, bpart, P);
     hipLaunchKernelGGL(colsum3_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)bpart, db, nb, alpha);

@@ -1,0 +1,333 @@
+"""Autograd glue over the HIP ops: one torch.autograd.Function per fused block of the reference graph.
+
+Tensors crossing these functions are NHWC-contiguous fp32 GPU tensors ([N, H, W, C]); the nn.Modules in
+pesr_amd/model convert from/to the logical NCHW view at the network boundary only.  Nothing here does
+arithmetic in torch except scalar-sized glue (gradient fan-in adds are autograd's own).
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+# Bumped whenever weights may have been changed behind torch's back (our fused Adam writes through raw
+# pointers and cannot bump Tensor._version).  Part of every packed-weight cache key.
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch() -> None:
+    _WEIGHT_EPOCH[0] += 1
+
+
+class PackedConvWeights:
+    """Per-parameter cache of the kernel-side weight layouts (forward / dgrad packing, PS-permuted bias)."""
+
+    def __init__(self, ps: bool = False):
+        self.ps = ps
+        self._fwd = self._dgrad = self._bias = None
+        self._kf = self._kd = self._kb = None
+
+    @staticmethod
+    def _key(t: torch.Tensor):
+        return (t.data_ptr(), t._version, _WEIGHT_EPOCH[0])
+
+    def fwd(self, w: torch.Tensor) -> torch.Tensor:
+        k = self._key(w)
+        if self._kf != k:
+            self._fwd = ops.pack_conv3x3(w.detach(), 0, self.ps)
+            self._kf = k
+        return self._fwd
+
+    def dgrad(self, w: torch.Tensor) -> torch.Tensor:
+        k = self._key(w)
+        if self._kd != k:
+            self._dgrad = ops.pack_conv3x3(w.detach(), 1, self.ps)
+            self._kd = k
+        return self._dgrad
+
+    def bias(self, b):
+        if b is None or not self.ps:
+            return None if b is None else b.detach()
+        k = self._key(b)
+        if self._kb != k:
+            self._bias = ops.pack_bias_ps(b.detach())
+            self._kb = k
+        return self._bias
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# generic 3x3 conv (+bias, +ReLU, fused PixelShuffle)          reference model/basic.py:4-7, 56-60
+# ------------------------------------------------------------------------------------------------
+class Conv3x3Fn(Function):
+    """y = act(conv(x, w) + b) [pixel-shuffled].
+
+    relu_in:  x is the output of a ReLU whose backward this function applies to its grad_input
+              (mask by x > 0, fused in the dgrad epilogue).
+    relu_grad_by_consumer: with act=relu, the consumer of y applies the ReLU mask (it set relu_in);
+              otherwise this function masks grad_output itself.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache: PackedConvWeights, stride, act, relu_in, relu_grad_by_consumer):
+        x = _c(x)
+        cout = weight.shape[0]
+        y = ops.conv3x3_fwd(x, cache.fwd(weight), cache.bias(bias), cout, stride, act=act, ps_out=cache.ps)
+        ctx.cache, ctx.stride, ctx.act, ctx.relu_in = cache, stride, act, relu_in
+        ctx.mask_here = act == ops.ACT_RELU and not relu_grad_by_consumer
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y if ctx.mask_here else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = _c(gy)
+        if ctx.mask_here:
+            gy = ops.relu_mask(gy, y)
+        cin, ps = x.shape[3], ctx.cache.ps
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3x3_dgrad(gy, ctx.cache.dgrad(weight), tuple(x.shape), ctx.stride,
+                                   mask=x if ctx.relu_in else None, ps_in=ps)
+        if ctx.needs_input_grad[1]:
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            if cin == 3:
+                dw, db = ops.conv3x3_wgrad_rgb(gy, x, 0, want_bias=want_b)
+            elif weight.shape[0] == 3:
+                dw, db = ops.conv3x3_wgrad_rgb(x, gy, 1, want_bias=want_b)
+            else:
+                dw, db = ops.conv3x3_wgrad(x, gy, ctx.stride, want_bias=want_b, ps_in=ps)
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv3x3(x, weight, bias, cache, stride=1, act=ops.ACT_NONE, relu_in=False, relu_grad_by_consumer=False):
+    return Conv3x3Fn.apply(x, weight, bias, cache, stride, act, relu_in, relu_grad_by_consumer)
+
+
+# ------------------------------------------------------------------------------------------------
+# conv + residual add (body tail: `res += x`, reference model/pesr.py:32-33)
+# ------------------------------------------------------------------------------------------------
+class ConvAddFn(Function):
+    """y = conv(x, w) + b + skip"""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias, cache):
+        x, skip = _c(x), _c(skip)
+        y = ops.conv3x3_fwd(x, cache.fwd(weight), cache.bias(bias), weight.shape[0], 1, skip=skip)
+        ctx.cache = cache
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _c(gy)
+        dx = ops.conv3x3_dgrad(gy, ctx.cache.dgrad(weight), tuple(x.shape), 1) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[2]:
+            dw, db = ops.conv3x3_wgrad(x, gy, 1, want_bias=True)
+        return dx, gy, dw, db, None
+
+
+# ------------------------------------------------------------------------------------------------
+# ResBlock: x + res_scale * conv2(relu(conv1(x)))             reference model/basic.py:33-52
+# ------------------------------------------------------------------------------------------------
+class ResBlockFn(Function):
+    """Four MFMA kernels forward+backward per conv pair, no standalone elementwise pass:
+    forward : r = relu(conv1(x)+b1) ; y = res_scale*(conv2(r)+b2) + x        (ReLU / scale / skip in epilogues)
+    backward: dr = res_scale * dgrad2(gy) masked by r>0 ; dx = dgrad1(dr) + gy  (mask / fan-in add in epilogues)
+    """
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, c1: PackedConvWeights, c2: PackedConvWeights, res_scale):
+        x = _c(x)
+        C = w1.shape[0]
+        r = ops.conv3x3_fwd(x, c1.fwd(w1), b1.detach(), C, 1, act=ops.ACT_RELU)
+        y = ops.conv3x3_fwd(r, c2.fwd(w2), b2.detach(), C, 1, alpha=res_scale, skip=x)
+        ctx.c1, ctx.c2, ctx.res_scale = c1, c2, res_scale
+        ctx.save_for_backward(x, r, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, r, w1, w2 = ctx.saved_tensors
+        gy = _c(gy)
+        s = ctx.res_scale
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        dr = ops.conv3x3_dgrad(gy, ctx.c2.dgrad(w2), tuple(r.shape), 1, alpha=s, mask=r)
+        dw1 = db1 = dw2 = db2 = None
+        if need_w:
+            dw2, db2 = ops.conv3x3_wgrad(r, gy, 1, alpha=s)
+            dw1, db1 = ops.conv3x3_wgrad(x, dr, 1)
+        dx = ops.conv3x3_dgrad(dr, ctx.c1.dgrad(w1), tuple(x.shape), 1, skip=gy) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# MeanShift (trainable 1x1 conv 3->3)                         reference model/basic.py:9-17
+# ------------------------------------------------------------------------------------------------
+class MeanShiftFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, x_nchw, y_nchw):
+        x = _c(x)
+        y = ops.meanshift_fwd(x, weight.detach(), bias.detach(), x_nchw, y_nchw)
+        ctx.x_nchw, ctx.y_nchw = x_nchw, y_nchw
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        if ctx.y_nchw:  # gradient arrives in the (NCHW) layout of y; the kernel wants NHWC
+            gy = gy.permute(0, 2, 3, 1)
+        gy = _c(gy)
+        need_dx = ctx.needs_input_grad[0]
+        dx, dw, db = ops.meanshift_bwd(gy, x, weight, ctx.x_nchw, need_dx)
+        if need_dx and ctx.x_nchw:
+            dx = dx.permute(0, 3, 1, 2)
+        return dx, dw, db, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# Discriminator BasicBlock: conv(no bias) -> BatchNorm2d(train) -> LeakyReLU(0.2)   reference model/basic.py:19-31
+# ------------------------------------------------------------------------------------------------
+class ConvBnLReluFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, num_batches, cache, stride, eps, momentum,
+                slope, y_nchw):
+        x = _c(x)
+        z = ops.conv3x3_fwd(x, cache.fwd(weight), None, weight.shape[0], stride)
+        y, stats = ops.bn_lrelu_fwd(z, gamma.detach(), beta.detach(), running_mean, running_var, num_batches, eps,
+                                    momentum, slope, y_nchw)
+        ctx.cache, ctx.stride, ctx.slope, ctx.y_nchw = cache, stride, slope, y_nchw
+        ctx.save_for_backward(x, z, weight, gamma, beta, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, z, weight, gamma, beta, stats = ctx.saved_tensors
+        gy = _c(gy)
+        need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        dz, dgamma, dbeta = ops.bn_lrelu_bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3x3_dgrad(dz, ctx.cache.dgrad(weight), tuple(x.shape), ctx.stride)
+        if ctx.needs_input_grad[1]:
+            if x.shape[3] == 3:
+                dw, _ = ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=False)
+            else:
+                dw, _ = ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=False)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear (+LeakyReLU)                                          reference model/pesr.py:69-74
+# ------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        x = _c(x)
+        y = ops.linear_fwd(x, weight.detach(), bias.detach(), act, slope)
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(x, weight, y if act != ops.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = _c(gy)
+        if ctx.act != ops.ACT_NONE:
+            if gy.numel() % 4 == 0:
+                gy = ops.relu_mask(gy, y, slope=ctx.slope if ctx.act == ops.ACT_LRELU else 0.0)
+            else:  # scalar-sized tail case
+                gy = torch.where(y > 0, gy, gy * (ctx.slope if ctx.act == ops.ACT_LRELU else 0.0))
+        dx = ops.linear_dgrad(gy, weight.detach()) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw, db = ops.linear_wgrad(gy, x, want_bias=True)
+        return dx, dw, db, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# 2x2 max-pool behind a ReLU                                   torchvision vgg19 features (reference model/vgg.py:8-10)
+# ------------------------------------------------------------------------------------------------
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, relu_in):
+        x = _c(x)
+        ctx.relu_in = relu_in
+        ctx.save_for_backward(x)
+        return ops.maxpool2x2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool2x2_bwd(x, _c(gy), ctx.relu_in), None
+
+
+# ------------------------------------------------------------------------------------------------
+# losses                                                       reference train.py:131-140
+# ------------------------------------------------------------------------------------------------
+class L1LossFn(Function):
+    """nn.L1Loss() (mean) on NHWC 3-channel tensors; the gradient is produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, sr, hr):
+        sr, hr = _c(sr), _c(hr)
+        out, grad = ops.loss_l1_tv(sr, hr, 1.0 / sr.numel(), 0.0, need_grad=sr.requires_grad)
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+class TVLossFn(Function):
+    """Sum of absolute horizontal + vertical differences (reference train.py:137-140)."""
+
+    @staticmethod
+    def forward(ctx, sr):
+        sr = _c(sr)
+        out, grad = ops.loss_l1_tv(sr, sr, 0.0, 1.0, need_grad=sr.requires_grad)
+        ctx.save_for_backward(grad)
+        return out[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g
+
+
+class MSELossFn(Function):
+    """F.mse_loss(a, b) (mean); only `a` gets a gradient (b is the no_grad branch, reference model/vgg.py:24-26)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        out, grad = ops.loss_mse(a, b, 2.0 / a.numel(), need_grad=a.requires_grad)
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def l1_loss(sr, hr):
+    return L1LossFn.apply(sr, hr)
+
+
+def tv_loss(sr):
+    return TVLossFn.apply(sr)
+
+
+def mse_loss(a, b):
+    return MSELossFn.apply(a, b)

@@ -1,0 +1,165 @@
+"""Building blocks with the reference's constructors and state_dict schema (reference model/basic.py),
+running on the HIP kernels of libpesr_hip.so.
+
+Every module takes and returns logical NCHW fp32 tensors; outputs are in torch.channels_last memory
+format (NHWC physically), so chaining modules never copies.  CPU tensors raise: there is no fallback.
+Parameters keep the reference's names, shapes (OIHW) and default initialisation (drawn through the very
+torch initialisers the reference's nn.Conv2d / nn.Linear would call, in the same order, so a seeded
+construction consumes the RNG identically).
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as PF
+from .. import ops
+
+
+def nhwc(x: torch.Tensor) -> torch.Tensor:
+    """logical NCHW -> NHWC view (zero-copy for channels_last inputs)."""
+    return x.permute(0, 2, 3, 1)
+
+
+def nchw(y: torch.Tensor) -> torch.Tensor:
+    """NHWC tensor -> logical NCHW view (channels_last strides)."""
+    return y.permute(0, 3, 1, 2)
+
+
+def spectral_norm(*_a, **_k):
+    # reference model/basic.py:25 calls an undefined name (NameError when --spectral_norm true)
+    raise NotImplementedError("spectral_norm=True is unreachable in the reference (NameError); not supported")
+
+
+class Conv(nn.Module):
+    """3x3 conv, padding k//2 (reference model/basic.py:4-7).  kernel_size 3 only on the HIP path."""
+
+    def __init__(self, in_planes, out_planes, kernel_size, stride=1, bias=True):
+        super().__init__()
+        if kernel_size != 3:
+            raise NotImplementedError("pesr_amd Conv implements the reference's only case, kernel_size=3")
+        init = nn.Conv2d(in_planes, out_planes, kernel_size, padding=kernel_size // 2, stride=stride, bias=bias)
+        self.weight = nn.Parameter(init.weight.data)
+        self.bias = nn.Parameter(init.bias.data) if bias else None
+        self.in_channels, self.out_channels, self.stride = in_planes, out_planes, stride
+        self.packed = PF.PackedConvWeights(ps=False)
+
+    def forward(self, x, act=ops.ACT_NONE, relu_in=False, relu_grad_by_consumer=False):
+        return nchw(PF.conv3x3(nhwc(x), self.weight, self.bias, self.packed, self.stride, act, relu_in,
+                               relu_grad_by_consumer))
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, kernel_size=3, stride={self.stride}, bias={self.bias is not None}"
+
+
+class MeanShift(nn.Module):
+    """1x1 conv 3->3 initialised to (x -/+ rgb_range*mean)/std (reference model/basic.py:9-17).  As in the
+    reference, `self.requires_grad = False` is a no-op: weight and bias ARE trainable."""
+
+    def __init__(self, rgb_range, rgb_mean, rgb_std, sign=-1):
+        super().__init__()
+        init = nn.Conv2d(3, 3, kernel_size=1)  # draws (then discards) an init, as the reference does
+        std = torch.Tensor(rgb_std)
+        w = torch.eye(3).view(3, 3, 1, 1)
+        w.div_(std.view(3, 1, 1, 1))
+        b = sign * rgb_range * torch.Tensor(rgb_mean)
+        b.div_(std)
+        self.weight = nn.Parameter(init.weight.data.copy_(w))
+        self.bias = nn.Parameter(init.bias.data.copy_(b))
+        self.requires_grad = False
+
+    def forward(self, x):
+        if x.dim() == 4 and x.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last):
+            # NCHW-contiguous network input: the layout change is folded into the kernel
+            return nchw(PF.MeanShiftFn.apply(x, self.weight, self.bias, True, False))
+        return nchw(PF.MeanShiftFn.apply(nhwc(x), self.weight, self.bias, False, False))
+
+
+class PixelShuffle(nn.Module):
+    """nn.PixelShuffle(2) as a standalone kernel (Upsampler fuses it into the conv epilogue instead)."""
+
+    def __init__(self, upscale_factor=2):
+        super().__init__()
+        assert upscale_factor == 2
+        self.upscale_factor = upscale_factor
+
+    def forward(self, x):
+        return nchw(_PixelShuffleFn.apply(nhwc(x)))
+
+
+class _PixelShuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.pixel_shuffle_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ops.pixel_shuffle_bwd(gy.contiguous())
+
+
+class BasicBlock(nn.Sequential):
+    """conv (no bias) -> BatchNorm2d -> act (reference model/basic.py:19-31); the Discriminator's unit.
+    Fused path: bn=True with LeakyReLU; BatchNorm always uses batch statistics in training mode."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, bias=False, bn=True, act=nn.ReLU(True),
+                 sn=True):
+        if sn:
+            conv = spectral_norm(Conv(in_channels, out_channels, kernel_size, stride, bias))
+        else:
+            conv = Conv(in_channels, out_channels, kernel_size, stride, bias)
+        m = [conv]
+        if bn:
+            m.append(nn.BatchNorm2d(out_channels))
+        if act is not None:
+            m.append(act)
+        super().__init__(*m)
+        self._fused = bn and isinstance(act, nn.LeakyReLU) and not bias
+        self.flatten_output = False  # set by Discriminator on its last block: emit NCHW-contiguous for .view(B, -1)
+
+    def forward(self, x):
+        if not self._fused:
+            raise NotImplementedError("BasicBlock: only conv(no bias)+BatchNorm2d+LeakyReLU is implemented (the Discriminator's use)")
+        conv, bn, act = self[0], self[1], self[2]
+        if not bn.training:
+            raise NotImplementedError("BasicBlock: eval-mode BatchNorm is never used by the reference (D stays in train mode)")
+        y = PF.ConvBnLReluFn.apply(nhwc(x), conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, conv.packed, conv.stride, bn.eps, bn.momentum,
+                                   act.negative_slope, self.flatten_output)
+        return y if self.flatten_output else nchw(y)
+
+
+class ResBlock(nn.Module):
+    """x + res_scale * conv(relu(conv(x))) (reference model/basic.py:33-52), one fused autograd node."""
+
+    def __init__(self, n_feats, kernel_size, bias=True, bn=False, act=nn.ReLU(True), res_scale=1):
+        super().__init__()
+        if bn or not bias or not isinstance(act, nn.ReLU):
+            raise NotImplementedError("ResBlock: the reference only uses bias=True, bn=False, act=ReLU")
+        modules_body = []
+        for i in range(2):
+            modules_body.append(Conv(n_feats, n_feats, kernel_size, bias=bias))
+            if i == 0:
+                modules_body.append(act)
+        self.body = nn.Sequential(*modules_body)
+        self.res_scale = res_scale
+
+    def forward(self, x):
+        c1, c2 = self.body[0], self.body[2]
+        return nchw(PF.ResBlockFn.apply(nhwc(x), c1.weight, c1.bias, c2.weight, c2.bias, c1.packed, c2.packed,
+                                        float(self.res_scale)))
+
+
+class Upsampler(nn.Sequential):
+    """conv C->4C, PixelShuffle(2), conv C->4C, PixelShuffle(2), conv C->3 (reference model/basic.py:54-60).
+    Both PixelShuffles are fused into the conv epilogue (forward) and the dgrad/wgrad loaders (backward)."""
+
+    def __init__(self, n_feats):
+        super().__init__(Conv(n_feats, 4 * n_feats, 3), PixelShuffle(2), Conv(n_feats, 4 * n_feats, 3), PixelShuffle(2),
+                         Conv(n_feats, 3, 3))
+        self[0].packed = PF.PackedConvWeights(ps=True)
+        self[2].packed = PF.PackedConvWeights(ps=True)
+
+    def forward(self, x):
+        h = nhwc(x)
+        h = PF.conv3x3(h, self[0].weight, self[0].bias, self[0].packed)   # -> [N, 2H, 2W, C]
+        h = PF.conv3x3(h, self[2].weight, self[2].bias, self[2].packed)   # -> [N, 4H, 4W, C]
+        h = PF.conv3x3(h, self[4].weight, self[4].bias, self[4].packed)   # -> [N, 4H, 4W, 3]
+        return nchw(h)

@@ -192,10 +192,10 @@ def pixel_shuffle_bwd(dy: torch.Tensor) -> torch.Tensor:
 
 
 def relu_mask(g: torch.Tensor, ref: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
-              alpha: float = 1.0) -> torch.Tensor:
+              alpha: float = 1.0, slope: float = 0.0) -> torch.Tensor:
     _chk(g, "relu_mask.g")
     out = torch.empty_like(g)
-    _lib.check(_lib.lib().pesr_relu_mask(_p(g), _p(ref), _p(add), _p(out), g.numel(), alpha, _stream()), "pesr_relu_mask")
+    _lib.check(_lib.lib().pesr_relu_mask(_p(g), _p(ref), _p(add), _p(out), g.numel(), alpha, slope, _stream()), "pesr_relu_mask")
     return out
 
 

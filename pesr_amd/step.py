@@ -1,0 +1,99 @@
+"""The two train steps of the reference (train.py:164-173 pretrain, :194-259 GAN), device-side.
+
+Same loss expressions, same order of forward passes (one G forward, four D forwards with their own
+BatchNorm batch statistics, two VGG passes), same requires_grad toggling and optimizer steps.  Differences
+that do not change results: losses stay on the device (one host sync per log interval instead of five per
+step, train.py:262-266); gradients are all-reduced across ranks inside the optimizers (optim.py) instead of
+through nn.DataParallel's gather / reduce_add.
+Data-parallel loss scaling: every mean-type loss is the local mean and gradients are averaged
+over ranks - identical to the reference's global mean for equal shards - but the TV term is a SUM over the
+global batch (train.py:137-140), so its local value is multiplied by world_size before the averaging.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import functional as PF
+from .model.basic import nhwc
+from .model.focal_loss import FocalLoss
+
+
+def _img(x: torch.Tensor) -> torch.Tensor:
+    """logical NCHW image batch -> NHWC-contiguous view/copy for the loss kernels"""
+    return nhwc(x).contiguous()
+
+
+class Trainer:
+    def __init__(self, G, D=None, vgg=None, optim_G=None, optim_D=None, *, gan_type="RSGAN", focal_loss=True, fl_gamma=1.0,
+                 alpha_vgg=50.0, alpha_gan=1.0, alpha_tv=1e-6, alpha_l1=0.0, world_size=1):
+        self.G, self.D, self.vgg = G, D, vgg
+        self.optim_G, self.optim_D = optim_G, optim_D
+        self.gan_type, self.use_focal = gan_type, focal_loss
+        self.f_loss_fn = FocalLoss(fl_gamma)
+        self.alpha_vgg, self.alpha_gan, self.alpha_tv, self.alpha_l1 = alpha_vgg, alpha_gan, alpha_tv, alpha_l1
+        self.world_size = world_size
+        self._targets = {}
+
+    def _target(self, batch, value, device):
+        key = (batch, value, device)
+        if key not in self._targets:
+            self._targets[key] = torch.full((batch, 1), float(value), device=device)
+        return self._targets[key]
+
+    # ---- reference train.py:164-173 -----------------------------------------------------------------
+    def pretrain_step(self, lr, hr):
+        sr = self.G(lr)
+        self.optim_G.zero_grad()
+        loss = PF.l1_loss(nhwc(sr), _img(hr))
+        loss.backward()
+        self.optim_G.step()
+        return {"l1": loss.detach()}
+
+    # ---- reference train.py:194-259 -----------------------------------------------------------------
+    def gan_step(self, lr, hr):
+        G, D = self.G, self.D
+        B, dev = lr.size(0), lr.device
+        target_real, target_fake = self._target(B, 1.0, dev), self._target(B, 0.0, dev)
+        hr_cl = hr.contiguous(memory_format=torch.channels_last)
+
+        # discriminator phase: hr real, sr fake
+        for p in D.parameters():
+            p.requires_grad = True
+        self.optim_D.zero_grad()
+        pred_real = D(hr_cl)
+        sr = G(lr)
+        pred_fake = D(sr.detach())
+        if self.gan_type == "SGAN":
+            total_D_loss = F.binary_cross_entropy_with_logits(pred_real, target_real) + \
+                F.binary_cross_entropy_with_logits(pred_fake, target_fake)
+        elif self.gan_type == "RSGAN":
+            total_D_loss = F.binary_cross_entropy_with_logits(pred_real - pred_fake, target_real)
+        else:
+            raise ValueError(f"unknown gan_type {self.gan_type}")
+        total_D_loss.backward()
+        self.optim_D.step()
+
+        # generator phase
+        for p in D.parameters():
+            p.requires_grad = False
+        self.optim_G.zero_grad()
+        pred_fake = D(sr)
+        with torch.no_grad():          # D's parameters are frozen and hr needs no grad: a pure forward, as in the reference
+            pred_real = D(hr_cl)
+        sr_nhwc, hr_nhwc = nhwc(sr), nhwc(hr_cl)
+        l1_loss = PF.l1_loss(sr_nhwc, hr_nhwc) * self.alpha_l1
+        vgg_sr, vgg_hr = self.vgg(sr, hr_cl)
+        vgg_loss = PF.mse_loss(nhwc(vgg_sr), nhwc(vgg_hr)) * self.alpha_vgg
+        tv_local = PF.tv_loss(sr_nhwc) * self.alpha_tv
+        z = pred_fake if self.gan_type == "SGAN" else pred_fake - pred_real
+        if self.use_focal:
+            G_loss = self.f_loss_fn(z, target_real)
+        else:
+            G_loss = F.binary_cross_entropy_with_logits(z, target_real)
+        G_loss = G_loss * self.alpha_gan
+        total_G_loss = l1_loss + vgg_loss + G_loss + tv_local * float(self.world_size)
+        total_G_loss.backward()
+        self.optim_G.step()
+        return {"l1": l1_loss.detach(), "vgg": vgg_loss.detach(), "g": G_loss.detach(), "tv": tv_local.detach(),
+                "d": total_D_loss.detach()}

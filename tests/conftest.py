@@ -20,3 +20,5 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -1,0 +1,171 @@
+"""GPU parity of the drop-in `model` package + train steps vs golden vectors from the imported reference
+(tests/golden/*.npz) and vs the CPU oracle.  Tolerances (stated on the 0..255 image scale):
+G forward atol 2e-3 / rtol 1e-5; per-tensor grads max-abs error <= 1e-4 x max-abs of the reference grad;
+scalar losses rtol 1e-5 (2e-5 after two optimizer steps)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import close, dis_sd, gen_sd, load_golden, vgg_sd
+from oracle import detrand
+from oracle import model as OM
+from oracle import step as OS
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore", message=".*pretrained vgg19.*")
+
+
+def _G(C, depth, sd):
+    from model import Generator
+    G = Generator({"num_channels": C, "depth": depth, "res_scale": 0.1})
+    G.load_state_dict(sd)
+    return G.cuda()
+
+
+def test_gv1_generator_small_fwd_bwd():
+    from pesr_amd import functional as PF
+    from pesr_amd.model.basic import nhwc
+    g = load_golden("gv1_generator_small")
+    G = _G(16, 2, gen_sd(16, 2))
+    assert list(G.state_dict().keys()) == [str(k) for k in g["keys"]]
+    lr = detrand.image_batch((2, 3, 12, 12), 1234).cuda()
+    hr = detrand.image_batch((2, 3, 48, 48), 1235).cuda()
+    sr = G(lr)
+    assert sr.shape == (2, 3, 48, 48)
+    close(sr, g["sr"], 1e-5, 2e-3, "sr")
+    loss = PF.l1_loss(nhwc(sr), nhwc(hr.contiguous(memory_format=torch.channels_last)))
+    close(loss, g["loss"], 1e-5, what="l1")
+    loss.backward()
+    for k, p in G.named_parameters():
+        close(p.grad, g["grad." + k], 1e-4, what="grad " + k)
+
+
+def test_gv2_generator_full_sampled():
+    from pesr_amd import functional as PF
+    from pesr_amd.model.basic import nhwc
+    g = load_golden("gv2_generator_full")
+    G = _G(256, 32, gen_sd(256, 32))
+    lr = detrand.image_batch((2, 3, 48, 48), 1234).cuda()
+    hr = detrand.image_batch((2, 3, 192, 192), 1235).cuda()
+    sr = G(lr)
+    flat = sr.contiguous().reshape(-1)            # logical NCHW order, as the golden indices
+    close(flat[torch.from_numpy(g["sr_idx"]).cuda()], g["sr_val"], 1e-5, 2e-3, "sr samples")
+    close(sr.sum(), g["sr_sum"], 1e-5, what="sr sum")
+    loss = PF.l1_loss(nhwc(sr), nhwc(hr.contiguous(memory_format=torch.channels_last)))
+    close(loss, g["loss"], 1e-5, what="l1")
+    loss.backward()
+    params = dict(G.named_parameters())
+    for key in [k[5:] for k in g.files if k.startswith("gidx.")]:
+        gr = params[key].grad.reshape(-1)[torch.from_numpy(g["gidx." + key]).cuda()]
+        close(gr, g["gval." + key], 0.0, 1e-4 * float(g["gmax." + key]), "grad " + key)
+
+
+def test_gv4_discriminator_small():
+    from model import Discriminator
+    g = load_golden("gv4_discriminator_small")
+    D = Discriminator({"patch_size": 8, "spectral_norm": False})
+    D.load_state_dict(dis_sd(8))
+    D = D.cuda()
+    a = detrand.image_batch((4, 3, 32, 32), 21).cuda()
+    b = detrand.image_batch((4, 3, 32, 32), 22).cuda().requires_grad_(True)
+    o1, o2 = D(a), D(b)
+    close(o1, g["o1"], 2e-5, what="o1"); close(o2, g["o2"], 2e-5, what="o2")
+    l = F.binary_cross_entropy_with_logits(o1 - o2, torch.ones(4, 1, device="cuda"))
+    close(l, g["loss"], 1e-5, what="bce")
+    l.backward()
+    close(b.grad, g["gin"], 2e-4, what="grad input")
+    for k, p in D.named_parameters():
+        gr = p.grad.reshape(-1)[torch.from_numpy(g["gidx." + k]).cuda()]
+        close(gr, g["gval." + k], 0.0, 2e-4 * float(g["gmax." + k]), "grad " + k)
+    for k, v in D.state_dict().items():
+        if "running" in k:
+            close(v, g["buf." + k], 1e-4, what=k)
+        elif "num_batches" in k:
+            assert int(v) == 2
+
+
+def test_gv7_vgg_small():
+    from model import VGG
+    from pesr_amd import functional as PF
+    from pesr_amd.model.basic import nhwc
+    g = load_golden("gv7_vgg_small")
+    V = VGG()
+    assert sorted(V.state_dict().keys()) == sorted(str(k) for k in g["keys"])
+    V.load_state_dict(vgg_sd())
+    V = V.cuda()
+    a = detrand.image_batch((2, 3, 32, 32), 31).cuda().requires_grad_(True)
+    b = detrand.image_batch((2, 3, 32, 32), 32).cuda()
+    fa, fb = V(a, b)
+    close(fa, g["f_sr"], 2e-5, what="f_sr"); close(fb, g["f_hr"], 2e-5, what="f_hr")
+    assert not fb.requires_grad
+    m = PF.mse_loss(nhwc(fa), nhwc(fb))
+    close(m, g["mse"], 2e-5, what="mse")
+    m.backward()
+    close(a.grad, g["gin"], 2e-4, what="grad input")
+
+
+def _trainer(C, depth, ps, lr=5e-5):
+    from model import Discriminator, Generator, VGG
+    from pesr_amd.optim import FlatAdam
+    from pesr_amd.step import Trainer
+    G = Generator({"num_channels": C, "depth": depth, "res_scale": 0.1}); G.load_state_dict(gen_sd(C, depth)); G.cuda()
+    D = Discriminator({"patch_size": ps, "spectral_norm": False}); D.load_state_dict(dis_sd(ps)); D.cuda()
+    V = VGG(); V.load_state_dict(vgg_sd()); V.cuda()
+    oG = FlatAdam([p for p in G.parameters() if p.requires_grad], lr=lr, betas=(0.9, 0.999))
+    oD = FlatAdam(D.parameters(), lr=lr, betas=(0.9, 0.999))
+    return Trainer(G, D, V, oG, oD), G, D
+
+
+def test_gv8_two_gan_steps_vs_reference():
+    """Two full GAN steps (losses + post-Adam parameters) against the run made with the reference's modules."""
+    g = load_golden("gv8_gan_steps_small")
+    tr, G, D = _trainer(16, 2, 8)
+    for it in range(2):
+        lr = detrand.image_batch((4, 3, 8, 8), 100 + it).cuda()
+        hr = detrand.image_batch((4, 3, 32, 32), 200 + it).cuda()
+        log = tr.gan_step(lr, hr)
+        got = [float(log[k]) for k in ("l1", "vgg", "g", "tv", "d")]
+        close(np.array(got), g["losses"][it], 5e-5, what=f"losses step {it}")
+    # Adam's m/sqrt(v) turns every gradient into a step of magnitude ~lr whatever its size, so fp32 summation-
+    # order noise on near-zero gradients shows up as a fraction of lr: allow 0.1*lr per step (a parameter that
+    # is not trained at all, or trained with a wrong-sign gradient, is off by >= 1*lr per step).
+    atol = 0.1 * 5e-5 * 2
+    for k, v in G.state_dict().items():
+        close(v.reshape(-1)[torch.from_numpy(g["G.idx." + k]).cuda()], g["G.val." + k], 2e-5, atol, what="G." + k)
+    for k, v in D.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            close(v.reshape(-1).float()[torch.from_numpy(g["D.idx." + k]).cuda()], g["D.val." + k], 1e-4, what="D." + k)
+        else:
+            close(v.reshape(-1)[torch.from_numpy(g["D.idx." + k]).cuda()], g["D.val." + k], 2e-5, atol, what="D." + k)
+
+
+def test_pretrain_step_vs_oracle():
+    from model import Generator
+    from pesr_amd.optim import FlatAdam
+    from pesr_amd.step import Trainer
+    sd = gen_sd(64, 3)
+    G = Generator({"num_channels": 64, "depth": 3, "res_scale": 0.1}); G.load_state_dict(sd); G.cuda()
+    tr = Trainer(G, optim_G=FlatAdam(G.parameters(), lr=1e-4))
+    st = OS.TrainState(sd, None, None, {"depth": 3, "res_scale": 0.1, "learning_rate": 1e-4})
+    for it in range(2):
+        lr = detrand.image_batch((2, 3, 24, 24), 300 + it)
+        hr = detrand.image_batch((2, 3, 96, 96), 400 + it)
+        ref = OS.pretrain_step(st, lr, hr)
+        log = tr.pretrain_step(lr.cuda(), hr.cuda())
+        close(log["l1"], np.float32(ref["l1"]), 2e-5, what=f"l1 step {it}")
+    for k, v in G.state_dict().items():
+        close(v, st.g[k], 2e-5, 0.1 * 1e-4 * 2, what=k)
+
+
+def test_state_dict_roundtrip_and_no_cpu_path():
+    from model import Generator
+    sd = gen_sd(64, 1)
+    G = Generator({"num_channels": 64, "depth": 1, "res_scale": 0.1})
+    G.load_state_dict(sd)
+    for k, v in G.state_dict().items():
+        assert torch.equal(v, sd[k]) and v.shape == sd[k].shape
+    with pytest.raises(Exception, match="no CPU fallback"):
+        G(torch.zeros(1, 3, 8, 8))

@@ -10,28 +10,8 @@ from oracle import detrand
 from oracle import model as OM
 from oracle import step as OS
 
-G = os.path.join(os.path.dirname(__file__), "golden")
-
-
-def load(name):
-    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
-
-
-def gen_sd(C, depth, seed=0):
-    shapes = {k: v for k, v in OM.generator_shapes(C, depth).items() if not k.startswith(("sub_mean", "add_mean"))}
-    sd = detrand.fill_state_dict(shapes, seed)
-    OM.set_meanshift(sd, "G")
-    return {k: sd[k] for k in OM.generator_shapes(C, depth)}
-
-
-def dis_sd(ps, seed=1):
-    return detrand.fill_state_dict(OM.discriminator_shapes(ps), seed)
-
-
-def vgg_sd(seed=2):
-    shapes = {k: v for k, v in OM.vgg_shapes().items() if not k.startswith("sub_mean")}
-    sd = detrand.fill_state_dict(shapes, seed, "vgg")
-    return OM.set_meanshift(sd, "V")
+from helpers import dis_sd, gen_sd, vgg_sd  # noqa: E402
+from helpers import load_golden as load  # noqa: E402
 
 
 def close(a, b, rtol=1e-6, atol=0.0):
