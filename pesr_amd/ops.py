@@ -33,6 +33,30 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class _KernelEvents:
+    """Optional HIP-event bracket around every launch of ONE conv shape (bench.py's live roofline figure).
+    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.shape, self.pairs = None, []
+
+    def enable(self, shape):
+        self.shape, self.pairs = tuple(shape), []
+
+    def match(self, N, H, W, Cin, Cout, stride):
+        return self.shape is not None and self.shape == (N, H, W, Cin, Cout, stride)
+
+    def drain(self):
+        """-> (average milliseconds per launch, launches); disables recording."""
+        pairs, self.pairs, self.shape = self.pairs, [], None
+        if not pairs:
+            return 0.0, 0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs), len(pairs)
+
+
+KERNEL_EVENTS = _KernelEvents()
+
 _workspaces = {}
 
 
@@ -84,8 +108,15 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         if t is not None:
             _chk(t, f"conv3x3_fwd.{n}")
             assert t.shape == y.shape, (t.shape, y.shape)
+    timed = KERNEL_EVENTS.match(N, H, W, Cin, cout, stride)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = _lib.lib().pesr_conv3x3_fwd(_p(x), _p(wp), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, stride,
                                      alpha, act, slope, int(ps_out), _stream())
+    if timed:
+        e1.record()
+        KERNEL_EVENTS.pairs.append((e0, e1))
     _lib.check(rc, f"pesr_conv3x3_fwd[{N}x{H}x{W}x{Cin}->{cout},s{stride}]")
     return y
 
