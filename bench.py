@@ -58,10 +58,23 @@ def synth_batch(batch, patch, seed, device):
     return lr.to(device), hr.to(device)
 
 
+def host_cores() -> int:
+    """Cores this process may really use: CPU affinity capped by the cgroup CPU quota (the GPU box exposes 256
+    logical CPUs under a 16-CPU quota; oversubscribing torch's pool there is 50x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, G, D, vgg):
     """The same train step on the host cores through the CPU oracle (oracle/step.py), on a bounded sample."""
     from oracle import step as OS
-    nthreads = os.cpu_count() or 1
+    nthreads = host_cores()
     torch.set_num_threads(nthreads)
     B = args.cpu_batch
     cfg = {"depth": args.num_blocks, "res_scale": 0.1, "learning_rate": 5e-5}
@@ -89,7 +102,7 @@ def main():
     ap.add_argument("--patch_size", type=int, default=48)
     ap.add_argument("--num_channels", type=int, default=256)
     ap.add_argument("--num_blocks", type=int, default=32)
-    ap.add_argument("--cpu_batch", type=int, default=2)
+    ap.add_argument("--cpu_batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()

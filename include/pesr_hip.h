@@ -76,7 +76,7 @@ int pesr_conv3x3_wgrad_rgb(const float* a, const float* b3, float* dw, float* db
  * change of the network's RGB input/output into this kernel). */
 int pesr_meanshift_fwd(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int x_nchw, int y_nchw,
                        void* stream);
-/* dy, dx NHWC; dx may be NULL.  dw [3][3], db [3].  workspace >= 1024*12*4 bytes. */
+/* dy, dx NHWC; dx may be NULL.  dw [3][3], db [3].  workspace >= 1024*12*4 + 128 bytes. */
 int pesr_meanshift_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int N, int H, int W,
                        int x_nchw, void* workspace, size_t ws_bytes, void* stream);
 
@@ -116,7 +116,7 @@ int pesr_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int
 
 /* ---- losses, fused forward + gradient (reference train.py:131-140) --------------------------------- */
 /* sr, hr, grad: [N][H][W][3].  out2[0] = mean|sr-hr|, out2[1] = TV sum.  grad = g_l1*sign(sr-hr) + g_tv*dTV/dsr
- * (caller folds alpha_l1/numel and alpha_tv into g_l1, g_tv); grad may be NULL.  workspace >= 8 KiB. */
+ * (caller folds alpha_l1/numel and alpha_tv into g_l1, g_tv); grad may be NULL.  workspace >= 8 KiB + 64 B. */
 int pesr_loss_l1_tv_fwd_bwd(const float* sr, const float* hr, float* grad, float* out2, int N, int H, int W, float g_l1,
                             float g_tv, void* workspace, size_t ws_bytes, void* stream);
 /* out1[0] = mean (a-b)^2 ; grad = gscale*(a-b) (caller passes 2*alpha/numel); grad may be NULL */

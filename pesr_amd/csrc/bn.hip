@@ -64,14 +64,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, int C, long M, float eps, float momentum,
+__global__ void bn_finalize_kernel(const double* __restrict__ dsum, int C, long M, float eps, float momentum,
                                    float* __restrict__ mean_invstd, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, long long* __restrict__ num_batches) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && num_batches) *num_batches += 1;
     if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < nb; ++k) { s += (double)part[((size_t)k * 2) * C + c]; ss += (double)part[((size_t)k * 2 + 1) * C + c]; }
+    const double s = dsum[c], ss = dsum[C + c];
     const double mean = s / (double)M;
     double var = ss / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -85,13 +84,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, int C
 }
 
 // second-stage reduce for backward: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat
-__global__ void bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums) {
+__global__ void bn_bwd_sums_kernel(const double* __restrict__ dsum, int C, float* __restrict__ sums) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * C) return;
-    const int which = e / C, c = e - which * C;
-    double s = 0.0;
-    for (int k = 0; k < nb; ++k) s += (double)part[((size_t)k * 2 + which) * C + c];
-    sums[e] = (float)s;
+    if (e < 2 * C) sums[e] = (float)dsum[e];
 }
 
 __global__ void bn_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
@@ -146,7 +141,7 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const float* __
 
 namespace {
 static void bn_grid(long M, long* nb, long* rpb) {
-    long b = (M + 63) / 64; if (b > 1024) b = 1024; if (b < 1) b = 1;
+    long b = (M + 63) / 64; if (b > 512) b = 512; if (b < 1) b = 1;
     *rpb = (M + b - 1) / b;
     *nb = (M + *rpb - 1) / *rpb;
 }
@@ -154,7 +149,7 @@ static void bn_grid(long M, long* nb, long* rpb) {
 
 size_t pesr_bn_ws_bytes(long M, int C) {
     long nb, rpb; bn_grid(M, &nb, &rpb);
-    return (size_t)nb * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(float);
+    return (size_t)nb * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(float) + 2 * (size_t)C * sizeof(double) + 512;
 }
 
 // forward: x [M][C] (M = N*H*W) -> y; saves mean_invstd [2][C]
@@ -163,11 +158,15 @@ int pesr_bn_lrelu_fwd_launch(const float* x, const float* gamma, const float* be
                              float momentum, float slope, int y_nchw, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (C % 4) return PESR_EINVAL;
     long nb, rpb; bn_grid(M, &nb, &rpb);
-    if (!ws || ws_bytes < (size_t)nb * 2 * C * sizeof(float)) return PESR_EWORKSPACE;
-    float* part = (float*)ws;
+    const size_t dsum_bytes = ((size_t)2 * C * sizeof(double) + 255) / 256 * 256;
+    if (!ws || ws_bytes < dsum_bytes + (size_t)nb * 2 * C * sizeof(float)) return PESR_EWORKSPACE;
+    double* dsum = (double*)ws;
+    float* part = (float*)((char*)ws + dsum_bytes);
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, part, M, C, rpb, slope, 0L, 1L, 0L, HW);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)part, (int)nb, C, M, eps, momentum,
+    int rc0 = pesr_reduce_rows_launch(part, dsum, (int)nb, 2 * C, stream);
+    if (rc0) return rc0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)dsum, C, M, eps, momentum,
                        mean_invstd, running_mean, running_var, num_batches);
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -185,14 +184,18 @@ int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma
     if (C % 4) return PESR_EINVAL;
     long nb, rpb; bn_grid(M, &nb, &rpb);
     const size_t part_bytes = (size_t)nb * 2 * C * sizeof(float);
-    if (!ws || ws_bytes < part_bytes + 2 * (size_t)C * sizeof(float)) return PESR_EWORKSPACE;
-    float* part = (float*)ws;
-    float* sums = (float*)((char*)ws + part_bytes);
+    const size_t dsum_bytes = ((size_t)2 * C * sizeof(double) + 255) / 256 * 256;
+    if (!ws || ws_bytes < dsum_bytes + part_bytes + 2 * (size_t)C * sizeof(float)) return PESR_EWORKSPACE;
+    double* dsum = (double*)ws;
+    float* part = (float*)((char*)ws + dsum_bytes);
+    float* sums = (float*)((char*)ws + dsum_bytes + part_bytes);
     long sn = HW * C, sc = 1, sp = C;
     if (dy_nchw) { sn = HW * C; sc = HW; sp = 1; }
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb, slope,
                        sn, sc, sp, HW);
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)part, (int)nb, C, sums);
+    int rc0 = pesr_reduce_rows_launch(part, dsum, (int)nb, 2 * C, stream);
+    if (rc0) return rc0;
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const double*)dsum, C, sums);
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, dy, mean_invstd, gamma, beta, (const float*)sums,

@@ -237,17 +237,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         __syncthreads();
     }
 }
-// ps == 0: db[c] = alpha * sum_b part[b][0][c].   ps == 1 (C = 2*Cq): db[4*cc + 2*si + sj] = alpha * sum_b part[b][si][sj*Cq + cc]
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nblocks, int C, float alpha, int ps) {
+// dsum: [2][C] column sums per row class (reduce.hip).  ps == 0: db[c] = alpha * dsum[0][c].
+// ps == 1 (C = 2*Cq): db[4*cc + 2*si + sj] = alpha * dsum[si][sj*Cq + cc]
+__global__ void colsum_final_kernel(const double* __restrict__ dsum, float* __restrict__ db, int C, float alpha, int ps) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = ps ? 2 * C : C;
     if (e >= total) return;
     const int si = e / C, col = e - si * C;
-    double s = 0.0;
-    for (int k = 0; k < nblocks; ++k) s += (double)part[((size_t)k * 2 + si) * C + col];
     int o = col;
     if (ps) { const int Cq = C >> 1; const int sj = col / Cq, cc = col - sj * Cq; o = 4 * cc + 2 * si + sj; }
-    db[o] = alpha * (float)s;
+    db[o] = alpha * (float)dsum[e];
 }
 
 int pesr_bias_grad_launch(const float* dy, float* db, long pixels, int Cout, int OW, float alpha, int ps_in, float* part,
@@ -257,13 +256,19 @@ int pesr_bias_grad_launch(const float* dy, float* db, long pixels, int Cout, int
     if (!ps_in) { M = pixels; C = Cout; class_div = (1L << 62); }
     else { M = pixels * 2; C = Cout / 2; class_div = OW; }  // [N*2OH*OW][2*Cq]
     if (C % 4) return PESR_EINVAL;
-    long nb = (M + 63) / 64; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
+    long nb = (M + 63) / 64; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
     long rpb = (M + nb - 1) / nb;
     nb = (M + rpb - 1) / rpb;
-    if (part_bytes < (size_t)nb * 2 * C * sizeof(float)) return PESR_EWORKSPACE;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, dy, part, M, C, rpb, class_div);
+    // workspace: [2*C doubles of sums][nb][2][C] partials
+    const size_t dsum_bytes = (size_t)2 * C * sizeof(double);
+    if (part_bytes < dsum_bytes + (size_t)nb * 2 * C * sizeof(float)) return PESR_EWORKSPACE;
+    double* dsum = (double*)part;
+    float* pp = (float*)((char*)part + dsum_bytes);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, dy, pp, M, C, rpb, class_div);
+    int rc = pesr_reduce_rows_launch(pp, dsum, (int)nb, 2 * C, stream);
+    if (rc) return rc;
     const int total = ps_in ? 2 * C : C;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const float*)part, db, (int)nb, C, alpha, ps_in);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const double*)dsum, db, C, alpha, ps_in);
     return pesr_launch_status();
 }
 
@@ -285,10 +290,10 @@ static bool wgrad_plan(int N, int H, int W, int Cin, int Cout, int stride, Wgrad
     if (split < 1) split = 1;
     p->segs_per_split = (p->total_segs + split - 1) / split;
     p->split = (p->total_segs + p->segs_per_split - 1) / p->segs_per_split;
-    p->slab_bytes = (size_t)p->split * 9 * Cout * Cin * sizeof(float);
+    p->slab_bytes = ((size_t)p->split * 9 * Cout * Cin * sizeof(float) + 255) / 256 * 256;
     (void)OH;
     p->colsum_blocks = 2048;
-    const size_t part_bytes = (size_t)p->colsum_blocks * 2 * Cout * sizeof(float);
+    const size_t part_bytes = (size_t)p->colsum_blocks * 2 * Cout * sizeof(float) + 2 * (size_t)Cout * sizeof(double) + 256;
     p->total_bytes = p->slab_bytes + part_bytes;
     return true;
 }

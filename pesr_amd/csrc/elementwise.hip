@@ -62,10 +62,9 @@ __global__ __launch_bounds__(256) void meanshift_bwd_kernel(const float* __restr
     __syncthreads();
     if (threadIdx.x < 12) part[blockIdx.x * 12 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void meanshift_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nb) {
+__global__ void meanshift_bwd_final_kernel(const double* __restrict__ dsum, float* __restrict__ dw, float* __restrict__ db) {
     if (threadIdx.x < 12) {
-        double s = 0.0;
-        for (int k = 0; k < nb; ++k) s += (double)part[k * 12 + threadIdx.x];
+        const double s = dsum[threadIdx.x];
         if (threadIdx.x < 9) dw[threadIdx.x] = (float)s; else db[threadIdx.x - 9] = (float)s;
     }
 }
@@ -80,9 +79,13 @@ int pesr_meanshift_fwd_launch(const float* x, const float* w, const float* b, fl
 int pesr_meanshift_bwd_launch(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int N, int H,
                               int W, long xsn, long xsc, long xsp, void* ws, size_t ws_bytes, hipStream_t stream) {
     const int nb = 1024;
-    if (!ws || ws_bytes < (size_t)nb * 12 * sizeof(float)) return PESR_EWORKSPACE;
-    hipLaunchKernelGGL(meanshift_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, x, w, dx, (float*)ws, N, (long)H * W, xsn, xsc, xsp);
-    hipLaunchKernelGGL(meanshift_bwd_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, dw, db, nb);
+    if (!ws || ws_bytes < 128 + (size_t)nb * 12 * sizeof(float)) return PESR_EWORKSPACE;
+    double* dsum = (double*)ws;                 // 12 doubles (padded to 128 B), then the partials
+    float* part = (float*)((char*)ws + 128);
+    hipLaunchKernelGGL(meanshift_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, x, w, dx, part, N, (long)H * W, xsn, xsc, xsp);
+    const int rc = pesr_reduce_rows_launch(part, dsum, nb, 12, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(meanshift_bwd_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)dsum, dw, db);
     return pesr_launch_status();
 }
 

@@ -52,3 +52,6 @@ int pesr_loss_mse_launch(const float* a, const float* b, float* grad, float* out
                          hipStream_t stream);
 int pesr_adam_launch(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
                      float gscale, hipStream_t stream);
+
+// dsum[col] = sum_k part[k*ncols + col] in double, fixed order (reduce.hip)
+int pesr_reduce_rows_launch(const float* part, double* dsum, int nb, int ncols, hipStream_t stream);

@@ -38,12 +38,8 @@ __global__ __launch_bounds__(256) void l1_tv_kernel(const float* __restrict__ sr
     __syncthreads();
     if (threadIdx.x < 2) part[blockIdx.x * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void l1_tv_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, double inv_numel) {
-    if (threadIdx.x < 2) {
-        double s = 0.0;
-        for (int k = 0; k < nb; ++k) s += (double)part[k * 2 + threadIdx.x];
-        out[threadIdx.x] = (float)(threadIdx.x == 0 ? s * inv_numel : s);   // out[0] = L1 mean, out[1] = TV sum
-    }
+__global__ void l1_tv_final_kernel(const double* __restrict__ dsum, float* __restrict__ out, double inv_numel) {
+    if (threadIdx.x < 2) out[threadIdx.x] = (float)(threadIdx.x == 0 ? dsum[0] * inv_numel : dsum[1]);   // L1 mean, TV sum
 }
 
 __global__ __launch_bounds__(256) void mse_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ grad,
@@ -60,28 +56,32 @@ __global__ __launch_bounds__(256) void mse_kernel(const f32x4* __restrict__ a, c
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void mse_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, double inv_numel) {
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int k = 0; k < nb; ++k) s += (double)part[k];
-        out[0] = (float)(s * inv_numel);
-    }
+__global__ void mse_final_kernel(const double* __restrict__ dsum, float* __restrict__ out, double inv_numel) {
+    if (threadIdx.x == 0) out[0] = (float)(dsum[0] * inv_numel);
 }
 
 int pesr_loss_l1_tv_launch(const float* sr, const float* hr, float* grad, float* out2, int N, int H, int W, float g_l1, float g_tv,
                            void* ws, size_t ws_bytes, hipStream_t stream) {
     const int nb = 1024;
-    if (!ws || ws_bytes < (size_t)nb * 2 * sizeof(float)) return PESR_EWORKSPACE;
-    hipLaunchKernelGGL(l1_tv_kernel, dim3(nb), dim3(256), 0, stream, sr, hr, grad, (float*)ws, N, H, W, g_l1, g_tv);
-    hipLaunchKernelGGL(l1_tv_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, out2, nb, 1.0 / ((double)N * H * W * 3));
+    if (!ws || ws_bytes < 64 + (size_t)nb * 2 * sizeof(float)) return PESR_EWORKSPACE;
+    double* dsum = (double*)ws;
+    float* part = (float*)((char*)ws + 64);
+    hipLaunchKernelGGL(l1_tv_kernel, dim3(nb), dim3(256), 0, stream, sr, hr, grad, part, N, H, W, g_l1, g_tv);
+    const int rc = pesr_reduce_rows_launch(part, dsum, nb, 2, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(l1_tv_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)dsum, out2, 1.0 / ((double)N * H * W * 3));
     return pesr_launch_status();
 }
 int pesr_loss_mse_launch(const float* a, const float* b, float* grad, float* out1, long n, float gscale, void* ws, size_t ws_bytes,
                          hipStream_t stream) {
     if (n % 4) return PESR_EINVAL;
     const int nb = 512;
-    if (!ws || ws_bytes < (size_t)nb * sizeof(float)) return PESR_EWORKSPACE;
-    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, stream, (const f32x4*)a, (const f32x4*)b, (f32x4*)grad, (float*)ws, n / 4, gscale);
-    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, out1, nb, 1.0 / (double)n);
+    if (!ws || ws_bytes < 64 + (size_t)nb * sizeof(float)) return PESR_EWORKSPACE;
+    double* dsum = (double*)ws;
+    float* part = (float*)((char*)ws + 64);
+    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, stream, (const f32x4*)a, (const f32x4*)b, (f32x4*)grad, part, n / 4, gscale);
+    const int rc = pesr_reduce_rows_launch(part, dsum, nb, 1, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)dsum, out1, 1.0 / (double)n);
     return pesr_launch_status();
 }

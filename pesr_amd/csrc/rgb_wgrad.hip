@@ -64,12 +64,10 @@ __global__ __launch_bounds__(64) void corr_rgb_kernel(const float* __restrict__ 
     for (int i = 0; i < 27; ++i) o[i] = acc[i];
 }
 
-__global__ void corr_rgb_final_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int C, int mode,
-                                      float alpha) {
+__global__ void corr_rgb_final_kernel(const double* __restrict__ dsum, float* __restrict__ dw, int C, int mode, float alpha) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // e = c*27 + oy*9 + ox*3 + k
     if (e >= C * 27) return;
-    double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += (double)part[(size_t)k * C * 27 + e];
+    const double s = dsum[e];
     const int c = e / 27, rem = e - c * 27;
     const int oy = rem / 9, ox = (rem - oy * 9) / 3, k = rem % 3;
     const float v = alpha * (float)s;
@@ -92,16 +90,12 @@ __global__ __launch_bounds__(256) void colsum3_kernel(const float* __restrict__ 
     __syncthreads();
     if (threadIdx.x < 3) part[blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void colsum3_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nb, float alpha) {
-    if (threadIdx.x < 3) {
-        double s = 0.0;
-        for (int k = 0; k < nb; ++k) s += (double)part[k * 3 + threadIdx.x];
-        db[threadIdx.x] = alpha * (float)s;
-    }
+__global__ void colsum3_final_kernel(const double* __restrict__ dsum, float* __restrict__ db, float alpha) {
+    if (threadIdx.x < 3) db[threadIdx.x] = alpha * (float)dsum[threadIdx.x];
 }
 
 namespace {
-struct RgbPlan { int nsplit, rows_per_split; size_t pad_bytes, part_bytes, bias_bytes, total; };
+struct RgbPlan { int nsplit, rows_per_split; size_t pad_bytes, part_bytes, dsum_bytes, bias_bytes, total; };
 static bool rgb_plan(int N, int H, int W, int C, RgbPlan* p) {
     if (C < 1) return false;
     const int NH = N * H;
@@ -112,8 +106,9 @@ static bool rgb_plan(int N, int H, int W, int C, RgbPlan* p) {
     p->nsplit = (NH + p->rows_per_split - 1) / p->rows_per_split;
     p->pad_bytes = ((size_t)N * (H + 2) * (W + 2) * 3 * sizeof(float) + 255) / 256 * 256;
     p->part_bytes = ((size_t)p->nsplit * C * 27 * sizeof(float) + 255) / 256 * 256;
-    p->bias_bytes = (size_t)2048 * 2 * (C > 4 ? C : 4) * sizeof(float);
-    p->total = p->pad_bytes + p->part_bytes + p->bias_bytes;
+    p->dsum_bytes = ((size_t)C * 27 * sizeof(double) + 255) / 256 * 256;
+    p->bias_bytes = (size_t)1024 * 2 * (C > 4 ? C : 4) * sizeof(float) + 2 * (size_t)(C > 4 ? C : 4) * sizeof(double) + 256;
+    p->total = p->pad_bytes + p->part_bytes + p->dsum_bytes + p->bias_bytes;
     return true;
 }
 }  // namespace
@@ -130,17 +125,24 @@ int pesr_conv3x3_wgrad_rgb_launch(const float* A, const float* b3, float* dw, fl
     if (!ws || ws_bytes < p.total) return PESR_EWORKSPACE;
     float* b3p = (float*)ws;
     float* part = (float*)((char*)ws + p.pad_bytes);
-    float* bpart = (float*)((char*)ws + p.pad_bytes + p.part_bytes);
+    double* dsum = (double*)((char*)ws + p.pad_bytes + p.part_bytes);
+    float* bpart = (float*)((char*)ws + p.pad_bytes + p.part_bytes + p.dsum_bytes);
     const long padn = (long)N * (H + 2) * (W + 2) * 3;
     hipLaunchKernelGGL(pad_rgb_kernel, dim3((unsigned)((padn + 255) / 256 < 2048 ? (padn + 255) / 256 : 2048)), dim3(256), 0, stream, b3, b3p, N, H, W);
     hipLaunchKernelGGL(corr_rgb_kernel, dim3(((C + 63) / 64) * p.nsplit), dim3(64), 0, stream, A, (const float*)b3p, part, N * H, H, W, C, p.rows_per_split);
-    hipLaunchKernelGGL(corr_rgb_final_kernel, dim3((C * 27 + 255) / 256), dim3(256), 0, stream, (const float*)part, dw, p.nsplit, C, mode, alpha);
-    int rc = pesr_launch_status();
+    int rc = pesr_reduce_rows_launch(part, dsum, p.nsplit, C * 27, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(corr_rgb_final_kernel, dim3((C * 27 + 255) / 256), dim3(256), 0, stream, (const double*)dsum, dw, C, mode, alpha);
+    rc = pesr_launch_status();
     if (rc || !db) return rc;
     const long P = (long)N * H * W;
     if (mode == 0) return pesr_bias_grad_launch(A, db, P, C, W, alpha, 0, bpart, p.bias_bytes, stream);  // needs C % 4 == 0
     const int nb = 512;
-    hipLaunchKernelGGL(colsum3_kernel, dim3(nb), dim3(256), 0, stream, b3, bpart, P);
-    hipLaunchKernelGGL(colsum3_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)bpart, db, nb, alpha);
+    double* bsum = (double*)bpart;
+    float* bp = bpart + 8;   // 32 B of sums, then the partials
+    hipLaunchKernelGGL(colsum3_kernel, dim3(nb), dim3(256), 0, stream, b3, bp, P);
+    rc = pesr_reduce_rows_launch(bp, bsum, nb, 3, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum3_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)bsum, db, alpha);
     return pesr_launch_status();
 }

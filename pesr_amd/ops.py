@@ -199,7 +199,7 @@ def meanshift_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, x_nchw: bo
     dx = torch.empty_like(dy) if need_dx else None
     dw = torch.empty((3, 3, 1, 1), dtype=torch.float32, device=dy.device)
     db = torch.empty((3,), dtype=torch.float32, device=dy.device)
-    ws = workspace(1024 * 12 * 4, dy.device)
+    ws = workspace(1024 * 12 * 4 + 128, dy.device)
     rc = _lib.lib().pesr_meanshift_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), N, H, W, int(x_nchw), _p(ws),
                                        ws.numel(), _stream())
     _lib.check(rc, "pesr_meanshift_bwd")
@@ -322,7 +322,7 @@ def loss_l1_tv(sr, hr, g_l1: float, g_tv: float, need_grad=True):
     N, H, W, _ = sr.shape
     out = torch.empty((2,), dtype=torch.float32, device=sr.device)
     grad = torch.empty_like(sr) if need_grad else None
-    ws = workspace(8192, sr.device)
+    ws = workspace(16384, sr.device)
     rc = _lib.lib().pesr_loss_l1_tv_fwd_bwd(_p(sr), _p(hr), _p(grad), _p(out), N, H, W, g_l1, g_tv, _p(ws), ws.numel(), _stream())
     _lib.check(rc, "pesr_loss_l1_tv_fwd_bwd")
     return out, grad
@@ -333,7 +333,7 @@ def loss_mse(a, b, gscale: float, need_grad=True):
     _chk(b, "loss_mse.b")
     out = torch.empty((1,), dtype=torch.float32, device=a.device)
     grad = torch.empty_like(a) if need_grad else None
-    ws = workspace(8192, a.device)
+    ws = workspace(16384, a.device)
     rc = _lib.lib().pesr_mse_fwd_bwd(_p(a), _p(b), _p(grad), _p(out), a.numel(), gscale, _p(ws), ws.numel(), _stream())
     _lib.check(rc, "pesr_mse_fwd_bwd")
     return out, grad
