@@ -1,0 +1,92 @@
+"""CPU, world_size 2 (gloo): the data-parallel path - flat gradient buckets all-reduced from backward hooks, and the
+loss scaling that reproduces nn.DataParallel's full-batch losses (mean-type losses averaged, TV summed)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from helpers import gen_sd
+from oracle import detrand
+from oracle import model as OM
+from oracle import step as OS
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pesr_amd.optim import FlatParams, GradBuckets
+        torch.set_num_threads(2)
+        sd = gen_sd(16, 1)
+        params = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+        names = list(sd.keys())
+        flat = FlatParams(params)
+        buckets = GradBuckets(flat, bucket_bytes=8 << 10)      # many small buckets -> exercises the hook path
+        assert buckets.enabled and len(buckets.bounds) > 3
+        leaves = dict(zip(names, params))
+        B = 4
+        lr = detrand.image_batch((B, 3, 8, 8), 11); hr = detrand.image_batch((B, 3, 32, 32), 12)
+        sh = slice(rank * B // world, (rank + 1) * B // world)           # contiguous shard, as DataParallel's scatter
+        for _ in range(2):                                               # two rounds: reset() must re-arm the hooks
+            flat.zero_grad(); buckets.reset()
+            sr = OM.generator_forward(leaves, lr[sh], 1, 0.1)
+            loss = F.l1_loss(sr, hr[sh]) + OS.tv_loss(sr) * 1e-3 * world   # local mean + (sum-type term) x world
+            loss.backward()
+            scale = buckets.finish()
+            assert scale == 1.0 / world
+        g_avg = flat.flat_g * scale
+        # replicas hold identical averaged gradients
+        other = [torch.zeros_like(g_avg) for _ in range(world)]
+        dist.all_gather(other, g_avg)
+        assert all(torch.equal(o, other[0]) for o in other)
+        if rank == 0:
+            q.put((names, [p.shape for p in params], flat.offsets, g_avg.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradients_equal_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    names, shapes, offsets, g_avg = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # single-process full-batch reference: the reference computes its losses on the gathered batch (train.py:240-242)
+    sd = gen_sd(16, 1)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lr = detrand.image_batch((4, 3, 8, 8), 11); hr = detrand.image_batch((4, 3, 32, 32), 12)
+    sr = OM.generator_forward(leaves, lr, 1, 0.1)
+    (F.l1_loss(sr, hr) + OS.tv_loss(sr) * 1e-3).backward()
+    for n, shp, off in zip(names, shapes, offsets):
+        ref = leaves[n].grad
+        got = g_avg[off:off + ref.numel()].view(shp)
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-6 * ref.abs().max().item()), n
+
+
+def test_flat_params_views_and_zero_grad():
+    from pesr_amd.optim import FlatParams
+    ps = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7))]
+    vals = [p.detach().clone() for p in ps]
+    flat = FlatParams(ps)
+    assert flat.numel == 16 + 8 and all(o % 4 == 0 for o in flat.offsets)
+    for p, v in zip(ps, vals):
+        assert torch.equal(p.detach(), v) and p.grad is not None and p.data_ptr() >= flat.flat_p.data_ptr()
+    (ps[0].sum() * 2 + ps[1].sum()).backward()
+    assert torch.equal(flat.flat_g[:15], torch.full((15,), 2.0)) and torch.equal(flat.flat_g[16:23], torch.ones(7))
+    ps[1].grad = None                        # someone dropped a grad: attach_grads restores the view
+    flat.zero_grad()
+    assert ps[1].grad is not None and float(flat.flat_g.abs().sum()) == 0.0
