@@ -1,0 +1,79 @@
+"""CPU: plumbing of the kept entry points (utils.py, test.py x8 ensemble, data.py, train.py flags) - reference
+utils.py known answers (golden GV9), x8 self-ensemble vs the oracle's numpy restatement (GV10)."""
+import importlib.util
+import os
+
+import numpy as np
+import torch
+
+from helpers import load_golden
+from oracle import detrand
+from oracle import image as OI
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location("entry_" + name, os.path.join(ROOT, name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_utils_known_answers_gv9():
+    U = _load("utils")
+    g = load_golden("gv9_utils")
+    a = detrand.image_batch((1, 3, 16, 20), 41)
+    b = a + detrand.uniform((1, 3, 16, 20), 42, -20, 20)
+    assert abs(U.compute_PSNR(a.clone(), b.clone()) - float(g["psnr"])) < 1e-9
+    assert abs(OI.psnr_y(a, b) - float(g["psnr"])) < 1e-9
+    [img] = U.tensors_to_imgs([b * 1.1 - 5])
+    assert np.array_equal(img, g["img"]) and np.array_equal(OI.tensor_to_img(b * 1.1 - 5), g["img"])
+    assert np.allclose(U.rgb2y(img.astype(np.float64)), g["y"], rtol=0, atol=1e-12)
+    [t] = U.imgs_to_tensors([img], torch.device("cpu"))
+    assert t.shape == (1, 3, 16, 20) and t.dtype == torch.float32 and torch.equal(t[0].permute(1, 2, 0).to(torch.uint8), torch.from_numpy(img))
+
+
+def test_x8_self_ensemble_matches_reference_semantics_gv10():
+    T = _load("test")
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(3, 3, 3, padding=1)          # asymmetric toy "model": not equivariant to flips
+
+    def model(x):
+        return torch.nn.functional.interpolate(conv(x), scale_factor=2, mode="nearest")
+
+    img = detrand.image_batch((1, 3, 6, 9), 7)            # non-square: transposes change the shape
+    with torch.no_grad():
+        got = T.x8_forward(img, model)
+        ref = OI.x8_forward(img, model)
+    assert got.shape == (1, 3, 12, 18)
+    assert torch.allclose(got, ref, rtol=0, atol=1e-5)
+    # an equivariant model is a fixed point of the ensemble
+    ident = lambda x: x * 2.0                              # noqa: E731
+    assert torch.allclose(T.x8_forward(img, ident), img * 2.0)
+
+
+def test_data_augment_and_shapes():
+    D = _load("data")
+    ds = D.SyntheticSRDataset(4, 12)
+    lr, hr = ds[1]
+    assert lr.shape == (3, 12, 12) and hr.shape == (3, 48, 48) and lr.min() >= 0 and lr.max() <= 255
+    assert torch.equal(ds[1][0], lr)                       # deterministic per index
+    a = np.arange(2 * 3 * 3).reshape(2, 3, 3)
+    seen = set()
+    for idx in range(8):
+        l, h = D.augment(a, a, idx)
+        seen.add(l.tobytes() + bytes(l.shape))
+        assert np.array_equal(l, h)
+    assert len(seen) == 8                                  # the 8 dihedral variants are distinct
+
+
+def test_train_flags_match_reference_defaults():
+    Tm = _load("train")
+    a = Tm.build_parser().parse_args([])
+    expect = dict(scale=4, num_channels=256, num_blocks=32, res_scale=0.1, phase="train", batch_size=16, learning_rate=5e-5,
+                  lr_step=120, num_epochs=200, num_repeats=20, patch_size=24, snapshot_every=10, gan_type="RSGAN", GP=False,
+                  spectral_norm=False, focal_loss=True, fl_gamma=1, alpha_vgg=50, alpha_gan=1, alpha_tv=1e-6, alpha_l1=0)
+    for k, v in expect.items():
+        assert getattr(a, k) == v, k
+    assert Tm.build_parser().parse_args(["--focal_loss", "false"]).focal_loss is False

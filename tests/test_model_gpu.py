@@ -169,3 +169,34 @@ def test_state_dict_roundtrip_and_no_cpu_path():
         assert torch.equal(v, sd[k]) and v.shape == sd[k].shape
     with pytest.raises(Exception, match="no CPU fallback"):
         G(torch.zeros(1, 3, 8, 8))
+
+
+def test_generator_ragged_image_and_x8_ensemble():
+    """Validation / test.py path: batch 1, arbitrary H x W (partial tiles everywhere), x8 self-ensemble on device."""
+    import importlib.util, os
+    from oracle import image as OI
+    spec = importlib.util.spec_from_file_location("entry_test", os.path.join(os.path.dirname(os.path.dirname(__file__)), "test.py"))
+    T = importlib.util.module_from_spec(spec); spec.loader.exec_module(T)
+    sd = gen_sd(64, 2)
+    G = _G(64, 2, sd)
+    img = detrand.image_batch((1, 3, 37, 53), 77)
+    with torch.no_grad():
+        sr = G(img.cuda())
+        ref = OM.generator_forward(sd, img, 2, 0.1)
+        close(sr, ref, 1e-5, 2e-3, "ragged sr")
+        ens = T.x8_forward(img.cuda(), G)
+        ens_ref = OI.x8_forward(img, lambda t: OM.generator_forward(sd, t, 2, 0.1))
+        close(ens, ens_ref, 1e-5, 2e-3, "x8 ensemble")
+
+
+def test_train_entrypoint_runs(tmp_path):
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("entry_train", os.path.join(os.path.dirname(os.path.dirname(__file__)), "train.py"))
+    Tm = importlib.util.module_from_spec(spec); spec.loader.exec_module(Tm)
+    common = ["--synthetic", "8", "--num_channels", "64", "--num_blocks", "2", "--patch_size", "8", "--batch_size", "4",
+              "--num_epochs", "1", "--max_iters", "2", "--check_point", str(tmp_path / "ck"), "--snapshot_every", "1"]
+    Tm.main(common + ["--phase", "pretrain"])
+    assert (tmp_path / "ck" / "pretrain" / "best_model.pt").exists()
+    Tm.main(common + ["--phase", "train", "--pretrained_model", str(tmp_path / "ck" / "pretrain" / "best_model.pt")])
+    sd = torch.load(tmp_path / "ck" / "train" / "model_1.pt", map_location="cpu")
+    assert list(sd.keys()) == list(OM.generator_shapes(64, 2).keys())      # the reference's checkpoint schema

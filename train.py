@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Training entry point (counterpart of reference train.py) on the MI355X-native model package.
+
+Same flags and defaults as the reference (train.py:21-77) plus `--synthetic N` (random DIV2K-shaped crops instead of
+the DIV2K cache, which is out of scope here).  One process per GPU: run plainly for one GPU, or under
+`python -m torch.distributed.run --nproc-per-node N train.py ...` for N (RCCL gradient all-reduce inside the
+optimizers replaces nn.DataParallel; --batch_size stays the GLOBAL batch as in the reference, each rank takes 1/N).
+tensorboardX is optional.  Checkpoints keep the reference's format: torch.save(G.state_dict()).
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.optim.lr_scheduler as lr_scheduler
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
+
+
+def str2bool(x):
+    return str(x).lower() == "true"
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="PIRM 2018")
+    p.add_argument("--scale", type=int, default=4)
+    p.add_argument("--train_dataset", type=str, default="DIV2K")
+    p.add_argument("--valid_dataset", type=str, default="PIRM")
+    p.add_argument("--num_valids", type=int, default=10)
+    p.add_argument("--num_channels", type=int, default=256)
+    p.add_argument("--num_blocks", type=int, default=32)
+    p.add_argument("--res_scale", type=float, default=0.1)
+    p.add_argument("--phase", type=str, default="train", help="pretrain or train")
+    p.add_argument("--pretrained_model", type=str, default="")
+    p.add_argument("--batch_size", type=int, default=16)
+    p.add_argument("--learning_rate", type=float, default=5e-5)
+    p.add_argument("--lr_step", type=int, default=120)
+    p.add_argument("--num_epochs", type=int, default=200)
+    p.add_argument("--num_repeats", type=int, default=20)
+    p.add_argument("--patch_size", type=int, default=24)
+    p.add_argument("--check_point", type=str, default="check_point/my_model")
+    p.add_argument("--snapshot_every", type=int, default=10)
+    p.add_argument("--gan_type", type=str, default="RSGAN")
+    p.add_argument("--GP", type=str2bool, default=False)
+    p.add_argument("--spectral_norm", type=str2bool, default=False)
+    p.add_argument("--focal_loss", type=str2bool, default=True)
+    p.add_argument("--fl_gamma", type=float, default=1)
+    p.add_argument("--alpha_vgg", type=float, default=50)
+    p.add_argument("--alpha_gan", type=float, default=1)
+    p.add_argument("--alpha_tv", type=float, default=1e-6)
+    p.add_argument("--alpha_l1", type=float, default=0)
+    # additions
+    p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic samples per epoch instead of a dataset folder")
+    p.add_argument("--vgg_weights", type=str, default="", help="state_dict file of torchvision vgg19 (offline pretrained weights)")
+    p.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (smoke runs)")
+    return p
+
+
+def make_loaders(args, rank, world):
+    from data import FolderSRDataset, SyntheticSRDataset
+    if args.synthetic:
+        train_set = SyntheticSRDataset(args.synthetic, args.patch_size)
+        val_set = SyntheticSRDataset(min(args.num_valids, 2), args.patch_size, seed=99)
+    else:
+        train_set = FolderSRDataset(os.path.join("data/origin/train", args.train_dataset), args.patch_size, args.num_repeats, True)
+        val_set = FolderSRDataset(os.path.join("data/origin/valid", args.valid_dataset), None, 1, False, fixed_length=10)
+    sampler = DistributedSampler(train_set, world, rank, shuffle=True, drop_last=True) if world > 1 else None
+    train_loader = DataLoader(train_set, batch_size=args.batch_size // world, shuffle=sampler is None, sampler=sampler,
+                              num_workers=4, pin_memory=True, drop_last=True)
+    val_loader = DataLoader(val_set, batch_size=1, shuffle=False, num_workers=1, pin_memory=True)
+    return train_loader, val_loader, sampler
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.GP:
+        raise NotImplementedError("--GP true needs double-backward through the conv kernels (not built; reference default is false)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    if rank == 0:
+        print("_____________YOUR SETTINGS_____________")
+        for k, v in vars(args).items():
+            print("%20s: %s" % (k, v))
+
+    from model import Discriminator, Generator, VGG
+    from pesr_amd.optim import FlatAdam
+    from pesr_amd.step import Trainer
+    from utils import compute_PSNR
+
+    train_loader, val_loader, sampler = make_loaders(args, rank, world)
+    opt = {"patch_size": args.patch_size, "num_channels": args.num_channels, "depth": args.num_blocks,
+           "res_scale": args.res_scale, "spectral_norm": args.spectral_norm}
+    G = Generator(opt)
+    if args.pretrained_model:
+        G.load_state_dict(torch.load(args.pretrained_model, map_location="cpu"))
+    G = G.to(device)
+    gan = args.phase != "pretrain"
+    D = Discriminator(opt).to(device) if gan else None
+    vgg = VGG(args.vgg_weights or None).to(device) if gan else None
+
+    optim_G = FlatAdam([p for p in G.parameters() if p.requires_grad], lr=args.learning_rate, betas=(0.9, 0.999))
+    optim_D = FlatAdam(D.parameters(), lr=args.learning_rate, betas=(0.9, 0.999)) if gan else None
+    if world > 1:  # replicas start identical
+        dist.broadcast(optim_G.flat.flat_p, 0)
+        if gan:
+            dist.broadcast(optim_D.flat.flat_p, 0)
+    scheduler_G = lr_scheduler.StepLR(optim_G, step_size=args.lr_step, gamma=0.5)
+    scheduler_D = lr_scheduler.StepLR(optim_D, step_size=args.lr_step, gamma=0.5) if gan else None
+    trainer = Trainer(G, D, vgg, optim_G, optim_D, gan_type=args.gan_type, focal_loss=args.focal_loss, fl_gamma=args.fl_gamma,
+                      alpha_vgg=args.alpha_vgg, alpha_gan=args.alpha_gan, alpha_tv=args.alpha_tv, alpha_l1=args.alpha_l1,
+                      world_size=world)
+
+    check_point = os.path.join(args.check_point, args.phase)
+    tb = None
+    if rank == 0:
+        os.makedirs(check_point, exist_ok=True)
+        try:
+            from tensorboardX import SummaryWriter
+            tb = SummaryWriter(check_point)
+        except ImportError:
+            pass
+    best_psnr = 0.0
+    keys = ("l1", "vgg", "g", "tv", "d") if gan else ("l1",)
+
+    for epoch in range(1, args.num_epochs + 1):
+        # the reference steps its schedulers at epoch START (train.py:156,185-186): epoch e trains at lr*0.5^(e//lr_step)
+        scheduler_G.step()
+        if gan:
+            scheduler_D.step()
+        cur_lr = optim_G.param_groups[0]["lr"]
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        running = torch.zeros(len(keys), device=device)      # accumulated on the device: one host sync per epoch
+        iters = 0
+        for lr_img, hr_img in train_loader:
+            lr_img, hr_img = lr_img.to(device, non_blocking=True), hr_img.to(device, non_blocking=True)
+            logs = trainer.gan_step(lr_img, hr_img) if gan else trainer.pretrain_step(lr_img, hr_img)
+            running += torch.stack([logs[k].float() for k in keys])
+            iters += 1
+            if args.max_iters and iters >= args.max_iters:
+                break
+        if world > 1:
+            dist.all_reduce(running)
+            running /= world
+            if gan:  # the TV term is a sum over the global batch
+                running[keys.index("tv")] *= world
+        avg = (running / max(iters, 1)).tolist()
+        if rank == 0:
+            print("Epoch [%d/%d] lr %g  " % (epoch, args.num_epochs, cur_lr) + "  ".join("%s %.4f" % kv for kv in zip(keys, avg)))
+            if tb is not None:
+                tb.add_scalar("Learning rate", cur_lr, epoch)
+                names = {"l1": "L1 Loss", "vgg": "VGG Loss", "g": "G Loss", "tv": "TV Loss", "d": "D Loss"}
+                for k, v in zip(keys, avg):
+                    tb.add_scalar(names[k] if gan else "Pretrain Loss", v, epoch)
+
+        # validation on rank 0 (full images, batch 1, no_grad), reference train.py:281-295
+        if rank == 0:
+            psnr = []
+            with torch.no_grad():
+                for lr_img, hr_img in val_loader:
+                    sr = G(lr_img.to(device))
+                    psnr.append(compute_PSNR(hr_img, sr))
+            val_psnr = float(np.mean(psnr)) if psnr else 0.0
+            print("Finish valid [%d/%d]. PSNR: %.4fdB" % (epoch, args.num_epochs, val_psnr))
+            if tb is not None:
+                tb.add_scalar("Validate PSNR", val_psnr, epoch)
+            if not gan and val_psnr > best_psnr:
+                best_psnr = val_psnr
+                torch.save(G.state_dict(), os.path.join(check_point, "best_model.pt"))
+            elif gan and epoch % args.snapshot_every == 0:
+                torch.save(G.state_dict(), os.path.join(check_point, "model_%d.pt" % epoch))
+        if world > 1:
+            dist.barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
