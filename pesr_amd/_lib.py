@@ -10,7 +10,7 @@ import os
 from ctypes import c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpesr_hip.so")
+LIB_PATH = os.environ.get("PESR_HIP_LIB") or os.path.join(_HERE, "libpesr_hip.so")   # override: experiment builds only
 
 _P = c_void_p  # every device pointer / stream crosses the ABI as void*
 

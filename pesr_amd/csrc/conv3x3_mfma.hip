@@ -12,12 +12,22 @@
 //   * every lane feeds 4 consecutive k-steps of the MFMA from ONE ds_read_b128 per operand:
 //     lane l holds A[pixel = l&15][k = l>>4]; we let MFMA k-slot g of step kk stand for channel
 //     4*g + kk of the chunk, so the lane's four A values (and four B values) are contiguous.
-//   * global -> LDS staging goes through registers, issued one slab ahead (loads before the MFMA
-//     block, ds_write after it), one barrier per slab.
+//   * global -> LDS staging goes through registers two slabs ahead (loads before the MFMA block,
+//     ds_write after it); the MFMA fragments are read from LDS one slab ahead into a second register
+//     set, so ds_read latency and bank conflicts hide under the previous slab's MFMAs; one barrier per slab.
 // fp32 MFMA is an exact k-ordered fmaf chain, so results differ from a CPU conv only by
 // summation order.
 #include "common.h"
 #include "launchers.h"
+#include <stdlib.h>
+
+// PESR_DBG: timing-only experiment builds (scripts/exp_variants.sh); results are WRONG for != 0.
+//   1: no per-slab barrier   2: also no staging ds_writes   3: also no fragment ds_reads (MFMA only)
+//   4: also no epilogue (one store per lane)   5: also no global loads in the loop
+//   6: like 2 (no barrier, no staging writes) but the fragment reads go to registers the MFMAs do not use
+#ifndef PESR_DBG
+#define PESR_DBG 0
+#endif
 
 struct ConvArgs {
     const float* x;     // [N][H][W][Cin]
@@ -33,8 +43,11 @@ struct ConvArgs {
     int HT, WT;                 // halo tile extent (rows, cols)
     int out_my, out_ay, out_mx, out_ax;  // output coordinate = g*out_m + out_a
     int ntaps;
-    int tap_dy[9], tap_dx[9];   // position of the tap inside the halo tile
-    int tap_w[9];               // tap index into the packed weights
+    // per tap one byte: dy | dx << 2 | weight_tap << 4 (dy, dx: position inside the halo tile).  Kept in two
+    // scalars instead of arrays: an indexed kernarg read is an s_load, whose lgkmcnt(0) wait would also drain
+    // the LDS reads that are deliberately left in flight across the MFMA block.
+    unsigned long long tap_lo;  // taps 0..7
+    unsigned tap_hi;            // tap 8
     float alpha, slope;
     int act;
     int ps;                     // 1: output channels are stored pixel-shuffled (r=2), Cout = 4*C
@@ -44,7 +57,11 @@ struct ConvArgs {
                                 //    un-shuffled, sub-pixel-major [N][H][W][Cin] view (dgrad of a PS conv)
 };
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL>
+__device__ __forceinline__ unsigned tap_code(const ConvArgs& a, int t) {
+    return t < 8 ? (unsigned)(a.tap_lo >> (8 * t)) & 0xffu : a.tap_hi;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL, bool PREFETCH>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(const ConvArgs a) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BN = WAVES_N * WN * 16;
@@ -156,52 +173,118 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
         }
     };
 
-    // prologue: chunk 0 halo + slab (chunk 0, tap 0)
+    // ---- software pipeline ---------------------------------------------------------------------
+    // global -> registers -> LDS runs TWO slabs ahead, LDS -> fragment registers ONE slab ahead: the
+    // ds_reads of slab s+1 are issued before the MFMA block of slab s and land under it, so after each
+    // barrier the matrix pipe restarts at once on operands that are already in registers.
+    f32x4 fa0[WM], fb0[WN], fa1[WM], fb1[WN];   // two fragment sets, statically indexed (kept in VGPRs)
+
+#define PESR_READ_FRAGS(FA, FB, C_, T_, SL_)                                                    \
+    {                                                                                          \
+        const char* const hb_ = ((C_) & 1) ? halo1 : halo0;                                    \
+        const char* const wb_ = ((SL_) & 1) ? wb1 : wb0;                                       \
+        const unsigned tc_ = tap_code(a, T_);                                                  \
+        const int toff_ = ((int)(tc_ & 3u) * a.WT + (int)((tc_ >> 2) & 3u)) * 64;              \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) FA[i] = *(const f32x4*)(hb_ + a_off[i] + toff_); \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) FB[j] = *(const f32x4*)(wb_ + b_off[j]); \
+    }
+#define PESR_MFMA_BLOCK(FA, FB)                                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                            \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i)                                          \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j)                                      \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[i][kk], FB[j][kk], acc[i][j], 0, 0, 0);
+
+    const int nslab = C16 * a.ntaps;
+    // PREFETCH = false (host picks it when ntaps == 1, one parity class of the stride-2 dgrad): the next chunk's
+    // halo is staged in the same iteration that would prefetch from it, so fragments are read in-iteration.
+
+    // prologue: chunk 0 halo, slabs 0 and 1
     load_halo(0);
-    load_w(0, a.tap_w[0]);
+    load_w(0, tap_code(a, 0) >> 4);
     store_halo(halo0);
     store_w(wb0);
+    if (nslab > 1) {
+        int t1 = 1, c1 = 0;
+        if (t1 == a.ntaps) { t1 = 0; c1 = 1; }
+        load_w(c1, tap_code(a, t1) >> 4);
+        store_w(wb1);
+    }
     __syncthreads();
 
-    int s = 0;
-#pragma unroll 1
-    for (int c = 0; c < C16; ++c) {
-        const char* const hb = (c & 1) ? halo1 : halo0;
-        char* const hb_next = (c & 1) ? halo0 : halo1;
-        const bool halo_next = (c + 1 < C16);
-#pragma unroll 1
-        for (int t = 0; t < a.ntaps; ++t, ++s) {
-            const char* const wb = (s & 1) ? wb1 : wb0;
-            char* const wb_next = (s & 1) ? wb0 : wb1;
-            // prefetch the next slab (wraps to a harmless re-read at the very end)
-            int tn = t + 1, cn = c;
-            if (tn == a.ntaps) { tn = 0; cn = c + 1; }
-            if (cn == C16) { cn = 0; }
-            load_w(cn, a.tap_w[tn]);
-            if (t == 0 && halo_next) load_halo(c + 1);
+    if (PREFETCH) PESR_READ_FRAGS(fa0, fb0, 0, 0, 0)
 
-            const int toff = (a.tap_dy[t] * a.WT + a.tap_dx[t]) * 64;
-            f32x4 av[WM], bv[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) av[i] = *(const f32x4*)(hb + a_off[i] + toff);
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bv[j] = *(const f32x4*)(wb + b_off[j]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
-
-            store_w(wb_next);
-            if (t == 0 && halo_next) store_halo(hb_next);
-            __syncthreads();
-        }
+    int c = 0, t = 0;
+#define PESR_STEP(CA, CB, NA, NB, SL)                                                           \
+    {                                                                                          \
+        /* (c1,t1) = slab SL+1, (c2,t2) = slab SL+2; past the end they wrap to harmless re-reads */ \
+        int t1 = t + 1, c1 = c;                                                                \
+        if (t1 == a.ntaps) { t1 = 0; c1 = c + 1; }                                             \
+        if (c1 == C16) c1 = 0;                                                                 \
+        int t2 = t1 + 1, c2 = c1;                                                              \
+        if (t2 == a.ntaps) { t2 = 0; c2 = c1 + 1; }                                            \
+        if (c2 == C16) c2 = 0;                                                                 \
+        const bool halo_now = (t == 0) && (c + 1 < C16);                                       \
+        if (PESR_DBG < 5) {                                                                    \
+            load_w(c2, tap_code(a, t2) >> 4);                                                  \
+            if (halo_now) load_halo(c + 1);                                                    \
+        }                                                                                      \
+        if (PESR_DBG == 6) {                                                                   \
+            f32x4 xa_[WM], xb_[WN];                                                            \
+            PESR_READ_FRAGS(xa_, xb_, c1, t1, (SL) + 1)                                        \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) asm volatile("" :: "v"(xa_[i]));    \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j) asm volatile("" :: "v"(xb_[j]));    \
+        } else if (PESR_DBG < 3) {                                                             \
+            if (PREFETCH) PESR_READ_FRAGS(NA, NB, c1, t1, (SL) + 1)                            \
+            else PESR_READ_FRAGS(CA, CB, c, t, (SL))                                           \
+        }                                                                                      \
+        PESR_MFMA_BLOCK(CA, CB)                                                                \
+        if (PREFETCH && PESR_DBG < 3 && PESR_DBG != 6) {                                       \
+            /* spread the WM+WN fragment reads of the next slab evenly over this slab's MFMAs: issued as one \
+               burst right after the barrier, the 8 waves' reads back up the LDS queue and (being in-order) \
+               hold back the MFMAs queued behind them */                                       \
+            constexpr int NRD = WM + WN, NMF = 4 * WM * WN, PER = NMF / (NRD + 1);             \
+            _Pragma("unroll") for (int r_ = 0; r_ < NRD; ++r_) {                               \
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                           \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+            }                                                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER * NRD, 0);                   \
+        }                                                                                      \
+        /* keep the staging ds_writes (and their vmcnt waits) BEHIND the MFMA block: hipcc otherwise hoists  \
+           them to the top of the block, exposing the global-load latency once per slab */     \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (PESR_DBG < 2) {                                                                    \
+            store_w(((SL) & 1) ? wb1 : wb0); /* slab SL+2 reuses slab SL's buffer */            \
+            if (halo_now) store_halo((c & 1) ? halo0 : halo1);                                 \
+        } else { asm volatile("" :: "v"(wreg[0]), "v"(hreg[0])); }                             \
+        if (PESR_DBG < 1) __syncthreads(); /* also drains this wave's LDS reads/writes */      \
+        c = c1; t = t1;                                                                        \
     }
+#pragma unroll 1
+    for (int sl = 0; sl < nslab; sl += 2) {
+        PESR_STEP(fa0, fb0, fa1, fb1, sl)
+        if (sl + 1 < nslab) PESR_STEP(fa1, fb1, fa0, fb0, sl + 1)
+    }
+#undef PESR_STEP
+#undef PESR_MFMA_BLOCK
+#undef PESR_READ_FRAGS
 
+    if (PESR_DBG >= 4) {   // timing experiment: keep the accumulators live with a single store
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        a.y[(size_t)blockIdx.x * NT + tid] = sacc;
+        return;
+    }
     // epilogue: D layout of the 16x16 tile: col = lane&15 (channel), row = (lane>>4)*4 + reg (pixel)
     const size_t img_out = (size_t)img * a.OH * a.OW;
+    float bias_r[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int co = n0 + (wave_n * WN + j) * 16 + r;
+        bias_r[j] = (a.bias && co < a.cout_store) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -216,7 +299,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
                 const int co = n0 + (wave_n * WN + j) * 16 + r;
                 if (co >= a.cout_store) continue;
                 float v = acc[i][j][jj];
-                if (a.bias) v += a.bias[co];
+                v += bias_r[j];
                 v *= a.alpha;
                 size_t idx;
                 if (a.ps) {
@@ -241,6 +324,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
 // host side
 // ---------------------------------------------------------------------------------------------
 namespace {
+
+static void set_tap(ConvArgs& a, int t, int dy, int dx, int w) {
+    const unsigned long long code = (unsigned)(dy | (dx << 2) | (w << 4));
+    if (t < 8) a.tap_lo |= code << (8 * t); else a.tap_hi = (unsigned)code;
+}
 
 struct TileChoice { int TH, TW; };
 
@@ -277,14 +365,24 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
     const int halo_bytes = ((a.HT * a.WT * 64 + 255) / 256) * 256;
     const size_t lds = 2 * (size_t)halo_bytes + 2 * (size_t)BN * 64;
     if (lds > 160 * 1024) return PESR_EINVAL;
-    auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL>;
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     const long grid = (long)a.N * a.tiles_y * a.tiles_x * a.n_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    if (a.ntaps > 1) {
+        auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, true>;
+        static bool attr_set = false;  // benign race: idempotent
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    } else {
+        auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, false>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    }
     return pesr_launch_status();
 }
 
@@ -295,6 +393,8 @@ static int dispatch(ConvArgs& a, int hext, int wext, hipStream_t stream) {
     if (a.Cout % 256 == 0) {
         // enough tiles to fill 256 CUs with the big tile?
         const long tiles_big = (M / 144) * (a.Cout / 256);
+        static const bool four_waves = getenv("PESR_CONV_4W") != nullptr;   // experiment: 1 wave per SIMD, 144 accumulators
+        if (tiles_big >= 192 && four_waves && S == 1) return launch_cfg<1, 4, 9, 4, 1, 4>(a, hext, wext, stream);
         if (tiles_big >= 192) return launch_cfg<1, 8, 9, 2, S, (S == 1 ? 2 : 6)>(a, hext, wext, stream);
     }
     if (a.Cout % 128 == 0) {
@@ -328,7 +428,7 @@ int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, cons
     a.in_oy = -1; a.in_ox = -1;
     a.out_my = 1; a.out_ay = 0; a.out_mx = 1; a.out_ax = 0;
     a.ntaps = 9;
-    for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3; a.tap_dx[t] = t % 3; a.tap_w[t] = flip ? 8 - t : t; }
+    for (int t = 0; t < 9; ++t) set_tap(a, t, t / 3, t % 3, flip ? 8 - t : t);
     a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
     a.cin_real = cin_real; a.cout_store = cout_store;
     return stride == 1 ? dispatch<1>(a, 3, 3, stream) : dispatch<2>(a, 3, 3, stream);
@@ -360,7 +460,7 @@ int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* 
             a.ntaps = 0;
             for (int i = 0; i < nky; ++i)
                 for (int j = 0; j < nkx; ++j) {
-                    a.tap_dy[a.ntaps] = dys[i]; a.tap_dx[a.ntaps] = dxs[j]; a.tap_w[a.ntaps] = kys[i] * 3 + kxs[j];
+                    set_tap(a, a.ntaps, dys[i], dxs[j], kys[i] * 3 + kxs[j]);
                     ++a.ntaps;
                 }
             a.alpha = alpha; a.slope = 0.f; a.act = PESR_ACT_NONE; a.ps = 0; a.ps_in = 0;

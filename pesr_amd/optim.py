@@ -69,7 +69,10 @@ class GradBuckets:
     def __init__(self, flat: FlatParams, group=None, bucket_bytes: int = 32 << 20):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.enabled = self.world > 1
+        # PESR_FORCE_DP=1 runs the bucket / hook / all-reduce machinery even with a single rank (lets the RCCL
+        # path be exercised on a 1-GPU box)
+        import os
+        self.enabled = self.world > 1 or (os.environ.get("PESR_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized())
         self.bounds, self.members = [], []
         start, acc, cur = 0, 0, []
         esz = flat.flat_g.element_size()
