@@ -63,6 +63,11 @@ size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout
 int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                        int stride, float alpha, int ps_in, void* workspace, size_t ws_bytes, void* stream);
 
+/* Forward 3x3 conv from a 3-channel input, stride 1 (reference `embed` model/pesr.py:23, Discriminator features.0
+ * model/pesr.py:53, vgg19 features.0): x [N][H][W][3], w OIHW [Cout][3][3][3] (NOT packed), y [N][H][W][Cout]. */
+int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
+                         float slope, void* stream);
+
 /* Weight gradient of the RGB-boundary convs (one operand has 3 channels): reference `embed`
  * (model/pesr.py:23), Discriminator features.0 (model/pesr.py:53), Upsampler's last conv (model/basic.py:60).
  * a: the C-channel tensor [N][H][W][C], b3: the 3-channel tensor [N][H][W][3].

@@ -120,3 +120,8 @@ PESR_API int pesr_adam_step(float* p, const float* g, float* m, float* v, long n
                             int step, float grad_scale, void* stream) {
     return pesr_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
 }
+
+PESR_API int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout,
+                                  int act, float slope, void* stream) {
+    return pesr_conv_rgb_in_launch(x, w, bias, y, N, H, W, Cout, act, slope, (hipStream_t)stream);
+}

@@ -28,6 +28,11 @@
 #ifndef PESR_DBG
 #define PESR_DBG 0
 #endif
+// PESR_VAR: schedule variants for same-session A/B (scripts/ab_variants.py): 0 burst reads, 1 spread reads, 2 burst + setprio,
+//   3 (WRONG results, timing only) full pipeline but the MFMAs read loop-invariant registers instead of the fragments
+#ifndef PESR_VAR
+#define PESR_VAR 0
+#endif
 
 struct ConvArgs {
     const float* x;     // [N][H][W][Cin]
@@ -178,6 +183,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     // ds_reads of slab s+1 are issued before the MFMA block of slab s and land under it, so after each
     // barrier the matrix pipe restarts at once on operands that are already in registers.
     f32x4 fa0[WM], fb0[WN], fa1[WM], fb1[WN];   // two fragment sets, statically indexed (kept in VGPRs)
+    f32x4 fza[WM], fzb[WN];                     // PESR_VAR == 3 only
+    if (PESR_VAR == 3) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) { const float q = 0.37f * lane + i; fza[i] = (f32x4){q, q * 0.5f, -q, q + 1.f}; asm volatile("" : "+v"(fza[i])); }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) { const float q = 0.11f * lane - j; fzb[j] = (f32x4){q, -q * 0.25f, q + 2.f, -q}; asm volatile("" : "+v"(fzb[j])); }
+    }
 
 #define PESR_READ_FRAGS(FA, FB, C_, T_, SL_)                                                    \
     {                                                                                          \
@@ -237,8 +249,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
             if (PREFETCH) PESR_READ_FRAGS(NA, NB, c1, t1, (SL) + 1)                            \
             else PESR_READ_FRAGS(CA, CB, c, t, (SL))                                           \
         }                                                                                      \
+        if (PESR_VAR == 2) __builtin_amdgcn_s_setprio(1);                                      \
+        if (PESR_VAR == 3) {                                                                   \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) asm volatile("" :: "v"(CA[i]));     \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j) asm volatile("" :: "v"(CB[j]));     \
+            PESR_MFMA_BLOCK(fza, fzb)                                                          \
+        } else                                                                                 \
         PESR_MFMA_BLOCK(CA, CB)                                                                \
-        if (PREFETCH && PESR_DBG < 3 && PESR_DBG != 6) {                                       \
+        if (PESR_VAR == 2) __builtin_amdgcn_s_setprio(0);                                      \
+        if (PREFETCH && PESR_DBG < 3 && PESR_DBG != 6 && PESR_VAR == 1) {                      \
             /* spread the WM+WN fragment reads of the next slab evenly over this slab's MFMAs: issued as one \
                burst right after the barrier, the 8 waves' reads back up the LDS queue and (being in-order) \
                hold back the MFMAs queued behind them */                                       \

@@ -55,3 +55,6 @@ int pesr_adam_launch(float* p, const float* g, float* m, float* v, long n, float
 
 // dsum[col] = sum_k part[k*ncols + col] in double, fixed order (reduce.hip)
 int pesr_reduce_rows_launch(const float* part, double* dsum, int nb, int ncols, hipStream_t stream);
+
+int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
+                            float slope, hipStream_t stream);

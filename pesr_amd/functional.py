@@ -76,7 +76,8 @@ class Conv3x3Fn(Function):
     def forward(ctx, x, weight, bias, cache: PackedConvWeights, stride, act, relu_in, relu_grad_by_consumer):
         x = _c(x)
         cout = weight.shape[0]
-        y = ops.conv3x3_fwd(x, cache.fwd(weight), cache.bias(bias), cout, stride, act=act, ps_out=cache.ps)
+        y = ops.conv3x3_fwd(x, lambda: cache.fwd(weight), cache.bias(bias), cout, stride, act=act, ps_out=cache.ps,
+                            w_oihw=weight.detach())
         ctx.cache, ctx.stride, ctx.act, ctx.relu_in = cache, stride, act, relu_in
         ctx.mask_here = act == ops.ACT_RELU and not relu_grad_by_consumer
         ctx.has_bias = bias is not None
@@ -201,7 +202,7 @@ class ConvBnLReluFn(Function):
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, num_batches, cache, stride, eps, momentum,
                 slope, y_nchw):
         x = _c(x)
-        z = ops.conv3x3_fwd(x, cache.fwd(weight), None, weight.shape[0], stride)
+        z = ops.conv3x3_fwd(x, lambda: cache.fwd(weight), None, weight.shape[0], stride, w_oihw=weight.detach())
         y, stats = ops.bn_lrelu_fwd(z, gamma.detach(), beta.detach(), running_mean, running_var, num_batches, eps,
                                     momentum, slope, y_nchw)
         ctx.cache, ctx.stride, ctx.slope, ctx.y_nchw = cache, stride, slope, y_nchw

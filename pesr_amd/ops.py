@@ -96,7 +96,9 @@ def pack_bias_ps(b: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout: int, stride: int = 1,
                 alpha: float = 1.0, act: int = ACT_NONE, slope: float = 0.0, skip: Optional[torch.Tensor] = None,
-                mask: Optional[torch.Tensor] = None, ps_out: bool = False) -> torch.Tensor:
+                mask: Optional[torch.Tensor] = None, ps_out: bool = False,
+                w_oihw: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """wp: packed weights (callable returning them is accepted, so the pack is skipped when the direct RGB kernel runs)."""
     _chk(x, "conv3x3_fwd.x")
     N, H, W, Cin = x.shape
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -108,10 +110,18 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         if t is not None:
             _chk(t, f"conv3x3_fwd.{n}")
             assert t.shape == y.shape, (t.shape, y.shape)
+    if Cin == 3 and stride == 1 and skip is None and mask is None and not ps_out and alpha == 1.0 and w_oihw is not None \
+            and cout % 4 == 0 and 256 % (cout // 4) == 0:
+        # RGB input layer: dedicated HBM-bound direct kernel on the un-packed OIHW weights
+        rc = _lib.lib().pesr_conv3x3_rgb_fwd(_p(x), _p(w_oihw), _p(bias), _p(y), N, H, W, cout, act, slope, _stream())
+        _lib.check(rc, f"pesr_conv3x3_rgb_fwd[{N}x{H}x{W}x3->{cout}]")
+        return y
     timed = KERNEL_EVENTS.match(N, H, W, Cin, cout, stride)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if callable(wp):
+        wp = wp()
     rc = _lib.lib().pesr_conv3x3_fwd(_p(x), _p(wp), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, stride,
                                      alpha, act, slope, int(ps_out), _stream())
     if timed:

@@ -1,0 +1,34 @@
+"""Same-session interleaved A/B of conv-kernel builds (each a separate libpesr_hip*.so loaded through ctypes)."""
+import ctypes, sys, os, statistics
+import torch
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from pesr_amd import _lib
+libs = sys.argv[1:]
+N, H, W, C = 16, 48, 48, 256
+x = torch.rand(N, H, W, C, device="cuda") - 0.5
+w = (torch.rand(C, C, 3, 3, device="cuda") - 0.5) * 0.1
+b = torch.rand(C, device="cuda"); y = torch.empty(N, H, W, C, device="cuda")
+wp = torch.empty(9 * C * C, device="cuda")
+handles = []
+for path in libs:
+    l = ctypes.CDLL(os.path.join(R, path))
+    for name, (res, args) in _lib.SIGNATURES.items():
+        f = getattr(l, name); f.restype = res; f.argtypes = args
+    handles.append(l)
+s = torch.cuda.current_stream().cuda_stream
+handles[0].pesr_pack_conv3x3(w.data_ptr(), wp.data_ptr(), C, C, 0, 0, s)
+def run(l, iters=20):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        l.pesr_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1, 1.0, 1, 0.0, 0, s)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+for l in handles: run(l, 5)
+res = {p: [] for p in libs}
+for rnd in range(6):
+    for p, l in zip(libs, handles):
+        res[p].append(run(l))
+for p in libs:
+    print(f"{p:28s} median {statistics.median(res[p]):7.1f} us  min {min(res[p]):7.1f}  all {[round(v) for v in res[p]]}")

@@ -38,6 +38,10 @@ def test_rgb_convs(N, H, W, C):
     wp = ops.pack_conv3x3(w.cuda(), 0)
     y = ops.conv3x3_fwd(_nhwc(x3), wp, b.cuda(), C, act=ops.ACT_RELU)
     _close(_nchw(y), torch.relu(O.conv3x3(x3, w, b)), 1e-5, "fwd 3->C")
+    y_direct = ops.conv3x3_fwd(_nhwc(x3), None, b.cuda(), C, act=ops.ACT_RELU, w_oihw=w.cuda())   # direct RGB-input kernel
+    _close(_nchw(y_direct), torch.relu(O.conv3x3(x3, w, b)), 1e-5, "fwd 3->C direct")
+    y_nb = ops.conv3x3_fwd(_nhwc(x3), None, None, C, w_oihw=w.cuda())
+    _close(_nchw(y_nb), O.conv3x3(x3, w, None), 1e-5, "fwd 3->C direct, no bias")
     dy = _rand(N, C, H, W, seed=5)
     dx_ref, dw_ref, db_ref = O.conv3x3_grads(x3, w, dy)
     wpd = ops.pack_conv3x3(w.cuda(), 1)
