@@ -46,16 +46,20 @@ int pesr_pack_bias_ps(const float* b, float* out, int O, void* stream);
  * ps_out=1 writes y pixel-shuffled: [N][2*OH][2*OW][Cout/4] (fuses nn.PixelShuffle(2)).
  * Fused epilogues stand in for relu_ (model/basic.py:43), .mul(res_scale) and `res += x`
  * (model/basic.py:49-50, model/pesr.py:33). */
+/* workspace (may be NULL / 0): scratch for split-K on layers too small to fill 256 CUs; size from
+ * pesr_conv3x3_workspace_bytes(N, OH, OW, Cout) (0 for large layers). */
+size_t pesr_conv3x3_workspace_bytes(int N, int OH, int OW, int Cout);
 int pesr_conv3x3_fwd(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask,
                      float* y, int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act, float slope,
-                     int ps_out, void* stream);
+                     int ps_out, void* workspace, size_t ws_bytes, void* stream);
 
 /* dx = alpha * conv_transpose(dy, w) [masked by mask > 0] + skip.  dx [N][H][W][Cin], dy [N][OH][OW][Cout].
  * w_packed_dgrad from pesr_pack_conv3x3(mode 1).  mask fuses ReLU's threshold_backward (the conv's
  * own input was a ReLU output); skip fuses the residual fan-in add.  ps_in=1: dy is the gradient of
  * the pixel-shuffled output, [N][2*OH][2*OW][Cout/4] (fuses pixel_unshuffle; stride 1 only). */
 int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float* mask, const float* skip, float* dx,
-                       int N, int H, int W, int Cin, int Cout, int stride, float alpha, int ps_in, void* stream);
+                       int N, int H, int W, int Cin, int Cout, int stride, float alpha, int ps_in, void* workspace,
+                       size_t ws_bytes, void* stream);
 
 /* dw[O][I][3][3] (OIHW, the parameter's own layout) = alpha * sum_pixels dy (x) x ;  db[O] = alpha * sum dy.
  * db may be NULL.  ps_in as above.  Workspace: pesr_conv3x3_wgrad_workspace_bytes. */

@@ -19,9 +19,11 @@ SIGNATURES = {
     "pesr_abi_version": (c_int, []),
     "pesr_pack_conv3x3": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "pesr_pack_bias_ps": (c_int, [_P, _P, c_int, _P]),
+    "pesr_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pesr_conv3x3_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
-                                 c_float, c_int, _P]),
-    "pesr_conv3x3_dgrad": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+                                 c_float, c_int, _P, c_size_t, _P]),
+    "pesr_conv3x3_dgrad": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P,
+                                   c_size_t, _P]),
     "pesr_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "pesr_conv3x3_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P,
                                    c_size_t, _P]),

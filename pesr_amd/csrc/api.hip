@@ -18,19 +18,26 @@ PESR_API int pesr_pack_bias_ps(const float* b, float* out, int O, void* stream) 
 
 PESR_API int pesr_conv3x3_fwd(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask,
                               float* y, int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act,
-                              float slope, int ps_out, void* stream) {
+                              float slope, int ps_out, void* workspace, size_t ws_bytes, void* stream) {
     return pesr_conv3x3_launch(x, w_packed, bias, skip, mask, y, N, H, W, pad16(Cin), pad64(Cout), stride, alpha, act, slope,
-                               ps_out, 0, 0, Cin, Cout, (hipStream_t)stream);
+                               ps_out, 0, 0, Cin, Cout, workspace, ws_bytes, (hipStream_t)stream);
 }
 
 PESR_API int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float* mask, const float* skip, float* dx,
-                                int N, int H, int W, int Cin, int Cout, int stride, float alpha, int ps_in, void* stream) {
+                                int N, int H, int W, int Cin, int Cout, int stride, float alpha, int ps_in, void* workspace,
+                                size_t ws_bytes, void* stream) {
     if (stride == 1)  // a stride-1 conv over dy with Cin/Cout swapped and the taps flipped
         return pesr_conv3x3_launch(dy, w_packed_dgrad, nullptr, skip, mask, dx, N, H, W, pad16(Cout), pad64(Cin), 1, alpha,
-                                   PESR_ACT_NONE, 0.f, 0, ps_in, 1, Cout, Cin, (hipStream_t)stream);
+                                   PESR_ACT_NONE, 0.f, 0, ps_in, 1, Cout, Cin, workspace, ws_bytes, (hipStream_t)stream);
     if (stride == 2 && !ps_in && !skip)
         return pesr_conv3x3_s2_dgrad_launch(dy, w_packed_dgrad, mask, dx, N, H, W, Cout, Cin, alpha, (hipStream_t)stream);
     return PESR_EINVAL;
+}
+
+// split-K scratch for layers whose tiles cannot fill the chip: up to 8 partial copies of a (small) output
+PESR_API size_t pesr_conv3x3_workspace_bytes(int N, int OH, int OW, int Cout) {
+    const long tiles = ((long)N * OH * OW + 143) / 144 * ((Cout + 63) / 64);
+    return tiles < 640 ? (size_t)8 * N * OH * OW * Cout * sizeof(float) : 0;
 }
 
 PESR_API size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride) {

@@ -58,6 +58,10 @@ struct ConvArgs {
     int ps;                     // 1: output channels are stored pixel-shuffled (r=2), Cout = 4*C
     int cin_real;               // channels physically present in x (3 for the RGB layers; Cin is then 16, zero padded)
     int cout_store;             // channels physically present in y (3 for the ->RGB layers; Cout is then 64, zero padded)
+    int ksplit;                 // > 1: the Cin chunks are split over ksplit workgroups per tile; raw partial sums go to
+    int chunks_per_split;       //      slab[ks][...] and conv_splitk_finish_kernel applies the epilogue (small-M layers)
+    float* slab;
+    size_t slab_bytes;
     int ps_in;                  // 1: x is a pixel-shuffled tensor [N][2H][2W][Cin/4] read as its
                                 //    un-shuffled, sub-pixel-major [N][H][W][Cin] view (dgrad of a PS conv)
 };
@@ -84,14 +88,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int r = lane & 15, g = lane >> 4;
 
-    int bid = blockIdx.x;
+    const int tiles_total = a.n_tiles * a.tiles_x * a.tiles_y * a.N;
+    const int ks = blockIdx.x / tiles_total;            // split-K slice (0 when ksplit == 1)
+    int bid = blockIdx.x - ks * tiles_total;
     const int nt = bid % a.n_tiles;  bid /= a.n_tiles;
     const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
     const int gy0 = ty * a.TH, gx0 = tx * a.TW;
     const int n0 = nt * BN;
-    const int C16 = a.Cin >> 4;
+    const int C16T = a.Cin >> 4;                          // chunks in the packed weights
+    const int CB = ks * a.chunks_per_split;               // this workgroup's chunk range [CB, CB + C16)
+    const int C16 = (C16T - CB) < a.chunks_per_split ? (C16T - CB) : a.chunks_per_split;
 
     // per-lane LDS offsets of the A (pixel) and B (channel) fragments
     int a_off[WM], b_off[WN];
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     f32x4 hreg[HL], wreg[WL];
 
     auto load_halo = [&](int c) {
-        int coff = c * 16;
+        int coff = (CB + c) * 16;
         if (a.ps_in) {  // chunk c covers packed channels (2*si+sj)*C + cc0 .. +15
             const int C = a.Cin >> 2;
             const int sub = coff / C, cc0 = coff - sub * C;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
             if (h_src[k] != -2) *(f32x4*)(hb + (tid + k * NT) * 16) = hreg[k];
     };
     auto load_w = [&](int c, int tw) {
-        const float* src = wn + ((size_t)tw * C16 + c) * slab_stride;
+        const float* src = wn + ((size_t)tw * C16T + CB + c) * slab_stride;
 #pragma unroll
         for (int k = 0; k < WL; ++k) {
             const int e = tid + k * NT;
@@ -321,6 +329,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
                 v += bias_r[j];
                 v *= a.alpha;
                 size_t idx;
+                if (a.ksplit > 1) {   // raw partial sum; bias / scale / mask / skip / activation happen in the finish kernel
+                    idx = (img_out + (size_t)oy * a.OW + ox) * a.cout_store + co;
+                    a.slab[(size_t)ks * ((size_t)a.N * a.OH * a.OW * a.cout_store) + idx] = acc[i][j][jj];
+                    continue;
+                }
                 if (a.ps) {
                     // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
                     const int C = a.Cout >> 2;
@@ -336,6 +349,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
                 a.y[idx] = v;
             }
         }
+    }
+}
+
+// y = act(alpha * (sum_ks slab[ks] + bias) [masked] + skip): fixed-order sum of the split-K partials + the epilogue
+__global__ void conv_splitk_finish_kernel(const float* __restrict__ slab, const float* __restrict__ bias, const float* __restrict__ skip,
+                                          const float* __restrict__ mask, float* __restrict__ y, long total, int C, int ksplit,
+                                          float alpha, int act, float slope) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        float v = slab[e];
+        for (int k = 1; k < ksplit; ++k) v += slab[(size_t)k * total + e];
+        if (bias) v += bias[e % C];
+        v *= alpha;
+        if (mask) v = mask[e] > 0.f ? v : 0.f;
+        if (skip) v += skip[e];
+        if (act == PESR_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == PESR_ACT_LRELU) v = v > 0.f ? v : v * slope;
+        y[e] = v;
     }
 }
 
@@ -384,7 +414,23 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
     const int halo_bytes = ((a.HT * a.WT * 64 + 255) / 256) * 256;
     const size_t lds = 2 * (size_t)halo_bytes + 2 * (size_t)BN * 64;
     if (lds > 160 * 1024) return PESR_EINVAL;
-    const long grid = (long)a.N * a.tiles_y * a.tiles_x * a.n_tiles;
+    const long tiles = (long)a.N * a.tiles_y * a.tiles_x * a.n_tiles;
+    // split-K over the Cin chunks when the tiles alone cannot fill the 256 CUs (12x12 / 24x24 512-channel layers)
+    const int C16T = a.Cin / 16;
+    a.ksplit = 1; a.chunks_per_split = C16T;
+    const size_t out_bytes = (size_t)a.N * a.OH * a.OW * a.cout_store * sizeof(float);
+    if (a.slab && tiles < 160 && a.out_my == 1 && a.out_mx == 1 && !a.ps && C16T >= 8) {
+        int want = (int)((256 + tiles - 1) / tiles);
+        if (want > 8) want = 8;
+        if (want > C16T / 4) want = C16T / 4;
+        while (want > 1 && (size_t)want * out_bytes > a.slab_bytes) --want;
+        if (want > 1) {
+            a.chunks_per_split = (C16T + want - 1) / want;
+            a.ksplit = (C16T + a.chunks_per_split - 1) / a.chunks_per_split;
+        }
+    }
+    const long grid = tiles * a.ksplit;
+    const float* bias = a.bias; const float* skip = a.skip; const float* mask = a.mask;
     if (a.ntaps > 1) {
         auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, true>;
         static bool attr_set = false;  // benign race: idempotent
@@ -401,6 +447,12 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
             attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    }
+    if (a.ksplit > 1) {
+        const long total = (long)(out_bytes / sizeof(float));
+        const int fgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(fgrid), dim3(256), 0, stream, (const float*)a.slab, bias, skip, mask, a.y,
+                           total, a.cout_store, a.ksplit, a.alpha, a.act, a.slope);
     }
     return pesr_launch_status();
 }
@@ -430,7 +482,8 @@ static int dispatch(ConvArgs& a, int hext, int wext, hipStream_t stream) {
 // (pack.hip mode 1: Cin/Cout swapped) and flip=1 (tap t reads weight tap 8-t).
 int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask,
                         float* y, int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act,
-                        float slope, int ps, int ps_in, int flip, int cin_real, int cout_store, hipStream_t stream) {
+                        float slope, int ps, int ps_in, int flip, int cin_real, int cout_store, void* ws, size_t ws_bytes,
+                        hipStream_t stream) {
     // cin_real / cout_store: physical channel counts of x / y (0 = same as Cin / Cout).  The RGB layers
     // (3 -> N, N -> 3) run here zero-padded to Cin = 16 / Cout = 64 with 3-channel tensors in memory.
     if (cin_real == 0) cin_real = Cin;
@@ -450,6 +503,7 @@ int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, cons
     for (int t = 0; t < 9; ++t) set_tap(a, t, t / 3, t % 3, flip ? 8 - t : t);
     a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
     a.cin_real = cin_real; a.cout_store = cout_store;
+    a.slab = (float*)ws; a.slab_bytes = ws_bytes;
     return stride == 1 ? dispatch<1>(a, 3, 3, stream) : dispatch<2>(a, 3, 3, stream);
 }
 
@@ -484,6 +538,7 @@ int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* 
                 }
             a.alpha = alpha; a.slope = 0.f; a.act = PESR_ACT_NONE; a.ps = 0; a.ps_in = 0;
             a.cin_real = Cout_fwd; a.cout_store = Cin_fwd;
+            a.slab = nullptr; a.slab_bytes = 0; a.ksplit = 1;
             const int rc = dispatch<1>(a, py + 1, px + 1, stream);
             if (rc) return rc;
         }

@@ -22,27 +22,31 @@ struct WgradArgs {
     const float* dy;   // [N][OH][OW][Cout]   (or shuffled [N][2OH][2OW][Cout/4] when ps_in)
     float* slab;       // [split][9][Cout][Cin]
     int N, H, W, Cin, Cout, OH, OW;
-    int segs_x;        // segments per output row
-    int total_segs;    // N*OH*segs_x
+    int segs_x;        // segments per output row group
+    int row_groups;    // ceil(OH / R): a segment covers R output rows x (TWO / R) columns
+    int total_segs;    // N*row_groups*segs_x
     int segs_per_split;
     int co_tiles, ci_tiles;
     int ps_in;
 };
 
-template <int COW, int S, int TWO>
+// R: output rows per segment (narrow images: a 48-pixel segment is 2 x 24 or 4 x 12 instead of a mostly-empty 1 x 48)
+template <int COW, int S, int TWO, int R>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
     constexpr int NT = 512;
     constexpr int CO_T = 32 * COW;
     constexpr int CI_T = 64;
-    constexpr int TWX = (TWO - 1) * S + 3;          // halo columns
+    constexpr int CW = TWO / R;                     // segment columns
+    constexpr int TWX = (CW - 1) * S + 3;           // halo columns
+    constexpr int HR = (R - 1) * S + 3;             // halo rows
     constexpr int XPAD = (S == 1) ? 16 : 8;         // keeps the two pixel rows of a b32 read on different bank halves
     constexpr int XS = CI_T + XPAD;                 // floats per halo pixel in LDS
     constexpr int DS = CO_T + 16;                   // floats per dy pixel in LDS
-    constexpr int X_F4 = 3 * TWX * (CI_T / 4);      // float4 units of one halo segment
+    constexpr int X_F4 = HR * TWX * (CI_T / 4);     // float4 units of one halo segment
     constexpr int D_F4 = TWO * (CO_T / 4);
     constexpr int XL = (X_F4 + NT - 1) / NT;
     constexpr int DL = (D_F4 + NT - 1) / NT;
-    constexpr int X_FLOATS = 3 * TWX * XS;
+    constexpr int X_FLOATS = HR * TWX * XS;
     constexpr int BUF_FLOATS = X_FLOATS + TWO * DS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -74,8 +78,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
     auto load_seg = [&](int seg) {
         const int xs = seg % a.segs_x;
         const int rowid = seg / a.segs_x;
-        const int oy = rowid % a.OH, img = rowid / a.OH;
-        const int ox0 = xs * TWO;
+        const int oy0 = (rowid % a.row_groups) * R, img = rowid / a.row_groups;
+        const int ox0 = xs * CW;
         const float* xi = a.x + (size_t)img * a.H * a.W * a.Cin;
 #pragma unroll
         for (int k = 0; k < XL; ++k) {
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
             const int q = e % (CI_T / 4);
             const int pix = e / (CI_T / 4);
             const int hx = pix % TWX, hy = pix / TWX;
-            const int iy = oy * S - 1 + hy, ix = ox0 * S - 1 + hx;
+            const int iy = oy0 * S - 1 + hy, ix = ox0 * S - 1 + hx;
             const bool ok = (e < X_F4) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci0 + q * 4 < a.Cin;
             const size_t off = ok ? ((size_t)iy * a.W + ix) * a.Cin + ci0 + q * 4 : 0;
             f32x4 v = *(const f32x4*)(xi + off);
@@ -94,8 +98,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
             const int e = tid + k * NT;
             const int q = e % (CO_T / 4);
             const int px = e / (CO_T / 4);
-            const int ox = ox0 + px;
-            const bool ok = (e < D_F4) && ox < a.OW && co0 + q * 4 < a.Cout;
+            const int oy = oy0 + px / CW, ox = ox0 + px % CW;
+            const bool ok = (e < D_F4) && oy < a.OH && ox < a.OW && co0 + q * 4 < a.Cout;
             size_t off = 0;
             if (ok) {
                 if (a.ps_in) {  // packed channel p = sub*Cq + cc lives at shuffled pixel (2oy + sub/2, 2ox + sub%2), channel cc
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int i = 0; i < COW; ++i) av[i] = db[px * DS + i * 16];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) bv[t] = xb[((t / 3) * TWX + px * S + (t % 3)) * XS];
+            for (int t = 0; t < 9; ++t) bv[t] = xb[(((px / CW) * S + t / 3) * TWX + (px % CW) * S + (t % 3)) * XS];
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -273,7 +277,7 @@ int pesr_bias_grad_launch(const float* dy, float* db, long pixels, int Cout, int
 }
 
 namespace {
-struct WgradPlan { int cow, two, co_tiles, ci_tiles, segs_x, total_segs, split, segs_per_split; size_t slab_bytes, total_bytes; int colsum_blocks; };
+struct WgradPlan { int cow, two, rows, row_groups, co_tiles, ci_tiles, segs_x, total_segs, split, segs_per_split; size_t slab_bytes, total_bytes; int colsum_blocks; };
 
 static bool wgrad_plan(int N, int H, int W, int Cin, int Cout, int stride, WgradPlan* p) {
     if (Cin % 4 || Cout % 4 || (stride != 1 && stride != 2)) return false;
@@ -282,8 +286,13 @@ static bool wgrad_plan(int N, int H, int W, int Cin, int Cout, int stride, Wgrad
     p->two = stride == 1 ? 48 : 24;
     p->co_tiles = (Cout + 32 * p->cow - 1) / (32 * p->cow);
     p->ci_tiles = (Cin + 63) / 64;
-    p->segs_x = (OW + p->two - 1) / p->two;
-    p->total_segs = N * OH * p->segs_x;
+    p->rows = 1;
+    if (stride == 1) { if (OW <= 12) p->rows = 4; else if (OW <= 24) p->rows = 2; }
+    else if (OW <= 12) p->rows = 2;
+    const int cw = p->two / p->rows;
+    p->segs_x = (OW + cw - 1) / cw;
+    p->row_groups = (OH + p->rows - 1) / p->rows;
+    p->total_segs = N * p->row_groups * p->segs_x;
     const int out_tiles = p->co_tiles * p->ci_tiles;
     int split = (256 + out_tiles - 1) / out_tiles;     // aim at >= 256 workgroups
     if (split > p->total_segs) split = p->total_segs;
@@ -291,21 +300,21 @@ static bool wgrad_plan(int N, int H, int W, int Cin, int Cout, int stride, Wgrad
     p->segs_per_split = (p->total_segs + split - 1) / split;
     p->split = (p->total_segs + p->segs_per_split - 1) / p->segs_per_split;
     p->slab_bytes = ((size_t)p->split * 9 * Cout * Cin * sizeof(float) + 255) / 256 * 256;
-    (void)OH;
     p->colsum_blocks = 2048;
     const size_t part_bytes = (size_t)p->colsum_blocks * 2 * Cout * sizeof(float) + 2 * (size_t)Cout * sizeof(double) + 256;
     p->total_bytes = p->slab_bytes + part_bytes;
     return true;
 }
 
-template <int COW, int S, int TWO>
+template <int COW, int S, int TWO, int R>
 static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
-    constexpr int TWX = (TWO - 1) * S + 3;
+    constexpr int TWX = (TWO / R - 1) * S + 3;
+    constexpr int HR = (R - 1) * S + 3;
     constexpr int XS = 64 + (S == 1 ? 16 : 8);
     constexpr int DS = 32 * COW + 16;
-    constexpr size_t lds = 2 * (size_t)(3 * TWX * XS + TWO * DS) * sizeof(float);
+    constexpr size_t lds = 2 * (size_t)(HR * TWX * XS + TWO * DS) * sizeof(float);
     static_assert(lds <= 160 * 1024, "wgrad LDS budget");
-    auto kern = conv3x3_wgrad_kernel<COW, S, TWO>;
+    auto kern = conv3x3_wgrad_kernel<COW, S, TWO, R>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -333,11 +342,13 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     a.x = x; a.dy = dy; a.slab = (float*)ws;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
-    a.segs_x = p.segs_x; a.total_segs = p.total_segs; a.segs_per_split = p.segs_per_split;
+    a.segs_x = p.segs_x; a.row_groups = p.row_groups; a.total_segs = p.total_segs; a.segs_per_split = p.segs_per_split;
     a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.ps_in = ps_in;
     int rc;
-    if (stride == 1) rc = p.cow == 4 ? launch_wgrad<4, 1, 48>(a, p.split, stream) : launch_wgrad<2, 1, 48>(a, p.split, stream);
-    else rc = p.cow == 4 ? launch_wgrad<4, 2, 24>(a, p.split, stream) : launch_wgrad<2, 2, 24>(a, p.split, stream);
+#define PESR_WG(S_, TWO_, R_) (p.cow == 4 ? launch_wgrad<4, S_, TWO_, R_>(a, p.split, stream) : launch_wgrad<2, S_, TWO_, R_>(a, p.split, stream))
+    if (stride == 1) rc = p.rows == 4 ? PESR_WG(1, 48, 4) : (p.rows == 2 ? PESR_WG(1, 48, 2) : PESR_WG(1, 48, 1));
+    else rc = p.rows == 2 ? PESR_WG(2, 24, 2) : PESR_WG(2, 24, 1);
+#undef PESR_WG
     if (rc) return rc;
     const long total = 9L * Cout * Cin;
     const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

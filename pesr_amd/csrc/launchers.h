@@ -8,7 +8,7 @@ int pesr_pack_bias_ps_launch(const float* b, float* out, int O, hipStream_t stre
 
 int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
                         int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act, float slope, int ps,
-                        int ps_in, int flip, int cin_real, int cout_store, hipStream_t stream);
+                        int ps_in, int flip, int cin_real, int cout_store, void* ws, size_t ws_bytes, hipStream_t stream);
 int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* mask, float* dx, int N, int H, int W,
                                  int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream);
 

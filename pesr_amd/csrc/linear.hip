@@ -123,8 +123,9 @@ __global__ void linear_bgrad_kernel(const float* __restrict__ dy, float* __restr
 namespace {
 struct LinPlan { int ksplit; long kchunk; int nsplit, nchunk; };
 static void lin_plan(int M, int N, long K, LinPlan* p) {
-    // forward: waves = ceil(N/4) * ksplit ~ 4096
-    const int ngroups = (N + 3) / 4;
+    // forward: waves = ceil(N/NR) * ksplit ~ 4096  (NR = 8 for M <= 16, else 2)
+    const int nr = M <= 16 ? 8 : 2;
+    const int ngroups = (N + nr - 1) / nr;
     int ks = 4096 / ngroups; if (ks < 1) ks = 1;
     long kc = ((K + ks - 1) / ks + 255) / 256 * 256;
     if (kc < 256) kc = 256;
@@ -149,10 +150,10 @@ int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float
     if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
     LinPlan p; lin_plan(M, N, K, &p);
     if (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float)) return PESR_EWORKSPACE;
-    const int ngroups = (N + 3) / 4;
+    const int ngroups = (N + 7) / 8;
     const long waves = (long)ngroups * p.ksplit;
     const int grid = (int)((waves + 3) / 4);
-    if (M <= 16) hipLaunchKernelGGL((linear_fwd_kernel<16, 4>), dim3(grid), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+    if (M <= 16) hipLaunchKernelGGL((linear_fwd_kernel<16, 8>), dim3(grid), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
     else hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), dim3((int)(((long)((N + 1) / 2) * p.ksplit + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
     hipLaunchKernelGGL(linear_fwd_final_kernel, dim3((M * N + 255) / 256), dim3(256), 0, stream, (const float*)ws, b, y, M, N, p.ksplit, act, slope);
     return pesr_launch_status();

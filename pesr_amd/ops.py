@@ -122,8 +122,11 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         e0.record()
     if callable(wp):
         wp = wp()
-    rc = _lib.lib().pesr_conv3x3_fwd(_p(x), _p(wp), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, stride,
-                                     alpha, act, slope, int(ps_out), _stream())
+    L = _lib.lib()
+    nws = L.pesr_conv3x3_workspace_bytes(N, OH, OW, cout)
+    ws = workspace(nws, x.device) if nws else None
+    rc = L.pesr_conv3x3_fwd(_p(x), _p(wp), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, stride,
+                            alpha, act, slope, int(ps_out), _p(ws), nws, _stream())
     if timed:
         e1.record()
         KERNEL_EVENTS.pairs.append((e0, e1))
@@ -143,8 +146,11 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
         if t is not None:
             _chk(t, f"conv3x3_dgrad.{n}")
             assert t.shape == dx.shape
-    rc = _lib.lib().pesr_conv3x3_dgrad(_p(dy), _p(wpd), _p(mask), _p(skip), _p(dx), N, H, W, Cin, cout, stride, alpha,
-                                       int(ps_in), _stream())
+    L = _lib.lib()
+    nws = L.pesr_conv3x3_workspace_bytes(N, H, W, Cin) if stride == 1 else 0
+    ws = workspace(nws, dy.device) if nws else None
+    rc = L.pesr_conv3x3_dgrad(_p(dy), _p(wpd), _p(mask), _p(skip), _p(dx), N, H, W, Cin, cout, stride, alpha,
+                              int(ps_in), _p(ws), nws, _stream())
     _lib.check(rc, f"pesr_conv3x3_dgrad[{N}x{H}x{W}x{Cin}<-{cout},s{stride}]")
     return dx
 
