@@ -12,27 +12,23 @@
 //   * every lane feeds 4 consecutive k-steps of the MFMA from ONE ds_read_b128 per operand:
 //     lane l holds A[pixel = l&15][k = l>>4]; we let MFMA k-slot g of step kk stand for channel
 //     4*g + kk of the chunk, so the lane's four A values (and four B values) are contiguous.
-//   * global -> LDS staging goes through registers two slabs ahead (loads before the MFMA block,
-//     ds_write after it); the MFMA fragments are read from LDS one slab ahead into a second register
-//     set, so ds_read latency and bank conflicts hide under the previous slab's MFMAs; one barrier per slab.
+//   * global -> LDS staging is LDS-DMA (global_load_lds_dwordx4) into a 4-slot weight ring, 3-4 slabs ahead;
+//     the MFMA fragments are read from LDS one slab ahead into a second register set, so ds_read latency
+//     and bank conflicts hide under the previous slab's MFMAs; one barrier per TWO slabs; the epilogue
+//     leaves through LDS as coalesced 16-byte stores.  (Register-staged fallbacks for 1-3 tap problems
+//     and the 3-channel input.)
 // fp32 MFMA is an exact k-ordered fmaf chain, so results differ from a CPU conv only by
 // summation order.
 #include "common.h"
 #include "launchers.h"
-#include <stdlib.h>
 
-// PESR_DBG: timing-only experiment builds (scripts/exp_variants.sh); results are WRONG for != 0.
-//   1: no per-slab barrier   2: also no staging ds_writes   3: also no fragment ds_reads (MFMA only)
-//   4: also no epilogue (one store per lane)   5: also no global loads in the loop
-//   6: like 2 (no barrier, no staging writes) but the fragment reads go to registers the MFMAs do not use
-#ifndef PESR_DBG
-#define PESR_DBG 0
-#endif
-// PESR_VAR: schedule variants for same-session A/B (scripts/ab_variants.py): 0 burst reads, 1 spread reads, 2 burst + setprio,
-//   3 (WRONG results, timing only) full pipeline but the MFMAs read loop-invariant registers instead of the fragments
-#ifndef PESR_VAR
-#define PESR_VAR 0
-#endif
+__device__ __attribute__((aligned(16))) const float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // source of the zero padding for LDS-DMA
+
+__device__ __forceinline__ void lds_dma16(const float* gsrc, char* lds_wave_base) {
+    // one 1-KiB piece: lane l copies 16 B from its own gsrc to lds_wave_base + 16*l (the LDS base is wave-uniform)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 struct ConvArgs {
     const float* x;     // [N][H][W][Cin]
@@ -70,7 +66,7 @@ __device__ __forceinline__ unsigned tap_code(const ConvArgs& a, int t) {
     return t < 8 ? (unsigned)(a.tap_lo >> (8 * t)) & 0xffu : a.tap_hi;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL, bool PREFETCH>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL, int MODE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(const ConvArgs a) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BN = WAVES_N * WN * 16;
@@ -190,23 +186,40 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     // global -> registers -> LDS runs TWO slabs ahead, LDS -> fragment registers ONE slab ahead: the
     // ds_reads of slab s+1 are issued before the MFMA block of slab s and land under it, so after each
     // barrier the matrix pipe restarts at once on operands that are already in registers.
-    f32x4 fa0[WM], fb0[WN], fa1[WM], fb1[WN];   // two fragment sets, statically indexed (kept in VGPRs)
-    f32x4 fza[WM], fzb[WN];                     // PESR_VAR == 3 only
-    if (PESR_VAR == 3) {
+    // LDS-DMA variants of the two loaders: same lane -> byte mapping as the register path, no VGPR round trip
+    auto dma_w = [&](int c, int tw, char* wb) {
+        const float* src = wn + ((size_t)tw * C16T + CB + c) * slab_stride;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) { const float q = 0.37f * lane + i; fza[i] = (f32x4){q, q * 0.5f, -q, q + 1.f}; asm volatile("" : "+v"(fza[i])); }
+        for (int k = 0; k < WL; ++k) {
+            const int e = tid + k * NT;
+            if (BN * 4 % NT == 0 || e < BN * 4) lds_dma16(src + e * 4, wb + (k * NT + wave * 64) * 16);
+        }
+    };
+    auto dma_halo = [&](int c, char* hb) {
+        int coff = (CB + c) * 16;
+        if (a.ps_in) {
+            const int C = a.Cin >> 2;
+            const int sub = coff / C, cc0 = coff - sub * C;
+            coff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * C + cc0;
+        }
 #pragma unroll
-        for (int j = 0; j < WN; ++j) { const float q = 0.11f * lane - j; fzb[j] = (f32x4){q, -q * 0.25f, q + 2.f, -q}; asm volatile("" : "+v"(fzb[j])); }
-    }
+        for (int k = 0; k < HL; ++k) {
+            if (h_src[k] != -2) {
+                const float* src = h_src[k] >= 0 ? xi + h_src[k] + coff : g_zero16;
+                lds_dma16(src, hb + (k * NT + wave * 64) * 16);
+            }
+        }
+    };
 
-#define PESR_READ_FRAGS(FA, FB, C_, T_, SL_)                                                    \
+    f32x4 fa0[WM], fb0[WN], fa1[WM], fb1[WN];   // two fragment sets, statically indexed (kept in VGPRs)
+
+#define PESR_READ_FRAGS(FA, FB, C_, T_, WB_)                                                    \
     {                                                                                          \
         const char* const hb_ = ((C_) & 1) ? halo1 : halo0;                                    \
-        const char* const wb_ = ((SL_) & 1) ? wb1 : wb0;                                       \
         const unsigned tc_ = tap_code(a, T_);                                                  \
         const int toff_ = ((int)(tc_ & 3u) * a.WT + (int)((tc_ >> 2) & 3u)) * 64;              \
         _Pragma("unroll") for (int i = 0; i < WM; ++i) FA[i] = *(const f32x4*)(hb_ + a_off[i] + toff_); \
-        _Pragma("unroll") for (int j = 0; j < WN; ++j) FB[j] = *(const f32x4*)(wb_ + b_off[j]); \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) FB[j] = *(const f32x4*)((WB_) + b_off[j]); \
     }
 #define PESR_MFMA_BLOCK(FA, FB)                                                                 \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                            \
@@ -215,95 +228,90 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[i][kk], FB[j][kk], acc[i][j], 0, 0, 0);
 
     const int nslab = C16 * a.ntaps;
-    // PREFETCH = false (host picks it when ntaps == 1, one parity class of the stride-2 dgrad): the next chunk's
-    // halo is staged in the same iteration that would prefetch from it, so fragments are read in-iteration.
+    // advance a (chunk, tap) slab cursor; past the last slab it wraps to slab 0 (harmless re-reads, never used)
+    auto adv = [&](int& c_, int& t_) { if (++t_ == a.ntaps) { t_ = 0; if (++c_ == C16) c_ = 0; } };
 
-    // prologue: chunk 0 halo, slabs 0 and 1
-    load_halo(0);
-    load_w(0, tap_code(a, 0) >> 4);
-    store_halo(halo0);
-    store_w(wb0);
-    if (nslab > 1) {
-        int t1 = 1, c1 = 0;
-        if (t1 == a.ntaps) { t1 = 0; c1 = 1; }
-        load_w(c1, tap_code(a, t1) >> 4);
-        store_w(wb1);
-    }
-    __syncthreads();
-
-    if (PREFETCH) PESR_READ_FRAGS(fa0, fb0, 0, 0, 0)
-
-    int c = 0, t = 0;
-#define PESR_STEP(CA, CB, NA, NB, SL)                                                           \
-    {                                                                                          \
-        /* (c1,t1) = slab SL+1, (c2,t2) = slab SL+2; past the end they wrap to harmless re-reads */ \
-        int t1 = t + 1, c1 = c;                                                                \
-        if (t1 == a.ntaps) { t1 = 0; c1 = c + 1; }                                             \
-        if (c1 == C16) c1 = 0;                                                                 \
-        int t2 = t1 + 1, c2 = c1;                                                              \
-        if (t2 == a.ntaps) { t2 = 0; c2 = c1 + 1; }                                            \
-        if (c2 == C16) c2 = 0;                                                                 \
-        const bool halo_now = (t == 0) && (c + 1 < C16);                                       \
-        if (PESR_DBG < 5) {                                                                    \
+    if (MODE == 2) {
+        // ---- main pipeline (>= 4 taps per chunk, >= 16-channel input) -------------------------------------------
+        // Weight slabs travel global -> LDS by LDS-DMA into a 4-slot ring, three to four slabs ahead; halo chunks
+        // likewise, one chunk ahead.  MFMA fragments are read from LDS one slab ahead into the second register set,
+        // so the matrix pipe restarts right after a barrier on operands that are already in registers.  ONE barrier
+        // per TWO slabs: when a double-step starts, the ring slots of slabs s-1 and s are free (their fragments were
+        // read - and those reads retired by the barrier's lgkmcnt(0) - during the previous double-step) and receive
+        // slabs s+3 and s+4; the barrier's vmcnt(0) retires the DMA before anyone reads them.
+        char* const ring = wb0;
+        int cd = 0, td = 0, sd = 0;                         // DMA cursor: next slab to fetch
+        auto dma_next = [&]() { dma_w(cd, tap_code(a, td) >> 4, ring + (sd & 3) * (BN * 64)); adv(cd, td); ++sd; };
+        dma_halo(0, halo0);
+        dma_next(); dma_next(); dma_next();                 // slabs 0, 1, 2
+        __syncthreads();
+        int cr = 0, tr = 0, sr = 0;                         // fragment-read cursor
+        PESR_READ_FRAGS(fa0, fb0, cr, tr, ring + (sr & 3) * (BN * 64))  adv(cr, tr); ++sr;      // slab 0
+        __syncthreads();                                    // slot 0 may be refilled only after every wave has read it
+        int c = 0, t = 0;                                   // cursor of the slab being multiplied
+#pragma unroll 1
+        for (int sl = 0; sl < nslab; sl += 2) {
+            dma_next(); dma_next();                         // slabs sl+3, sl+4 -> slots of slabs sl-1, sl
+            {   // a chunk that opens in this double-step triggers the DMA of the NEXT chunk's halo
+                int c1 = c, t1 = t; adv(c1, t1);
+                const int copen = (t == 0) ? c : ((t1 == 0 && sl + 1 < nslab) ? c1 : -1);
+                if (copen >= 0 && copen + 1 < C16 && (t == 0 || c1 != 0)) dma_halo(copen + 1, ((copen + 1) & 1) ? halo1 : halo0);
+            }
+            PESR_READ_FRAGS(fa1, fb1, cr, tr, ring + (sr & 3) * (BN * 64))  adv(cr, tr); ++sr;  // slab sl+1
+            PESR_MFMA_BLOCK(fa0, fb0)                                                           // slab sl
+            adv(c, t);
+            if (sl + 1 < nslab) {
+                PESR_READ_FRAGS(fa0, fb0, cr, tr, ring + (sr & 3) * (BN * 64))  adv(cr, tr); ++sr;  // slab sl+2
+                PESR_MFMA_BLOCK(fa1, fb1)                                                           // slab sl+1
+                adv(c, t);
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- fallback pipeline: register-staged, one barrier per slab -------------------------------------------
+        // MODE 1: fragments prefetched one slab ahead (2-3 taps per chunk, or the 3-channel RGB input);
+        // MODE 0: one tap per chunk (a parity class of the stride-2 dgrad): the next chunk's halo is staged in the
+        //         same iteration that would prefetch from it, so fragments are read in-iteration.
+        load_halo(0);
+        load_w(0, tap_code(a, 0) >> 4);
+        store_halo(halo0);
+        store_w(wb0);
+        if (nslab > 1) {
+            int c1 = 0, t1 = 0; adv(c1, t1);
+            load_w(c1, tap_code(a, t1) >> 4);
+            store_w(wb1);
+        }
+        __syncthreads();
+        if (MODE == 1) PESR_READ_FRAGS(fa0, fb0, 0, 0, wb0)
+        int c = 0, t = 0;
+#define PESR_STEP(CA, CB_, NA, NB, SL)                                                          \
+        {                                                                                      \
+            int c1 = c, t1 = t; adv(c1, t1);                                                   \
+            int c2 = c1, t2 = t1; adv(c2, t2);                                                 \
+            const bool halo_now = (t == 0) && (c + 1 < C16);                                   \
             load_w(c2, tap_code(a, t2) >> 4);                                                  \
             if (halo_now) load_halo(c + 1);                                                    \
-        }                                                                                      \
-        if (PESR_DBG == 6) {                                                                   \
-            f32x4 xa_[WM], xb_[WN];                                                            \
-            PESR_READ_FRAGS(xa_, xb_, c1, t1, (SL) + 1)                                        \
-            _Pragma("unroll") for (int i = 0; i < WM; ++i) asm volatile("" :: "v"(xa_[i]));    \
-            _Pragma("unroll") for (int j = 0; j < WN; ++j) asm volatile("" :: "v"(xb_[j]));    \
-        } else if (PESR_DBG < 3) {                                                             \
-            if (PREFETCH) PESR_READ_FRAGS(NA, NB, c1, t1, (SL) + 1)                            \
-            else PESR_READ_FRAGS(CA, CB, c, t, (SL))                                           \
-        }                                                                                      \
-        if (PESR_VAR == 2) __builtin_amdgcn_s_setprio(1);                                      \
-        if (PESR_VAR == 3) {                                                                   \
-            _Pragma("unroll") for (int i = 0; i < WM; ++i) asm volatile("" :: "v"(CA[i]));     \
-            _Pragma("unroll") for (int j = 0; j < WN; ++j) asm volatile("" :: "v"(CB[j]));     \
-            PESR_MFMA_BLOCK(fza, fzb)                                                          \
-        } else                                                                                 \
-        PESR_MFMA_BLOCK(CA, CB)                                                                \
-        if (PESR_VAR == 2) __builtin_amdgcn_s_setprio(0);                                      \
-        if (PREFETCH && PESR_DBG < 3 && PESR_DBG != 6 && PESR_VAR == 1) {                      \
-            /* spread the WM+WN fragment reads of the next slab evenly over this slab's MFMAs: issued as one \
-               burst right after the barrier, the 8 waves' reads back up the LDS queue and (being in-order) \
-               hold back the MFMAs queued behind them */                                       \
-            constexpr int NRD = WM + WN, NMF = 4 * WM * WN, PER = NMF / (NRD + 1);             \
-            _Pragma("unroll") for (int r_ = 0; r_ < NRD; ++r_) {                               \
-                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                           \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
-            }                                                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER * NRD, 0);                   \
-        }                                                                                      \
-        /* keep the staging ds_writes (and their vmcnt waits) BEHIND the MFMA block: hipcc otherwise hoists  \
-           them to the top of the block, exposing the global-load latency once per slab */     \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        if (PESR_DBG < 2) {                                                                    \
+            if (MODE == 1) PESR_READ_FRAGS(NA, NB, c1, t1, (((SL) + 1) & 1) ? wb1 : wb0)       \
+            else PESR_READ_FRAGS(CA, CB_, c, t, ((SL) & 1) ? wb1 : wb0)                        \
+            PESR_MFMA_BLOCK(CA, CB_)                                                           \
+            /* keep the staging ds_writes (and their vmcnt waits) BEHIND the MFMA block: hipcc otherwise hoists   \
+               them to its top and exposes the global-load latency once per slab */            \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
             store_w(((SL) & 1) ? wb1 : wb0); /* slab SL+2 reuses slab SL's buffer */            \
             if (halo_now) store_halo((c & 1) ? halo0 : halo1);                                 \
-        } else { asm volatile("" :: "v"(wreg[0]), "v"(hreg[0])); }                             \
-        if (PESR_DBG < 1) __syncthreads(); /* also drains this wave's LDS reads/writes */      \
-        c = c1; t = t1;                                                                        \
-    }
+            __syncthreads();                                                                   \
+            c = c1; t = t1;                                                                    \
+        }
 #pragma unroll 1
-    for (int sl = 0; sl < nslab; sl += 2) {
-        PESR_STEP(fa0, fb0, fa1, fb1, sl)
-        if (sl + 1 < nslab) PESR_STEP(fa1, fb1, fa0, fb0, sl + 1)
-    }
+        for (int sl = 0; sl < nslab; sl += 2) {
+            PESR_STEP(fa0, fb0, fa1, fb1, sl)
+            if (sl + 1 < nslab) PESR_STEP(fa1, fb1, fa0, fb0, sl + 1)
+        }
 #undef PESR_STEP
+    }
 #undef PESR_MFMA_BLOCK
 #undef PESR_READ_FRAGS
 
-    if (PESR_DBG >= 4) {   // timing experiment: keep the accumulators live with a single store
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        a.y[(size_t)blockIdx.x * NT + tid] = sacc;
-        return;
-    }
     // ---- epilogue ----------------------------------------------------------------------------------
     // D layout of a 16x16 tile: col = lane&15 (channel), row = (lane>>4)*4 + reg (pixel): written straight to
     // memory that is 64-byte fragments per store.  Instead the accumulators go through LDS (the staging buffers
@@ -470,7 +478,10 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
     a.tiles_y = pesr_cdiv(a.GH, a.TH); a.tiles_x = pesr_cdiv(a.GW, a.TW);
     a.n_tiles = a.Cout / BN;
     const int halo_bytes = ((a.HT * a.WT * 64 + 255) / 256) * 256;
-    size_t lds = 2 * (size_t)halo_bytes + 2 * (size_t)BN * 64;
+    // MODE 2 (LDS-DMA, 4-slot weight ring, one barrier per two slabs) needs >= 4 taps per chunk so that a chunk's halo
+    // is resident a full double-step before its first fragment read, and a >= 16-channel input (16-byte DMA pieces)
+    const int mode = (a.ntaps >= 4 && a.cin_real != 3) ? 2 : (a.ntaps > 1 ? 1 : 0);
+    size_t lds = 2 * (size_t)halo_bytes + (mode == 2 ? 4 : 2) * (size_t)BN * 64;
     const size_t lds_out = (size_t)MT * (BN * 4 + 16);     // accumulator tile staged for the coalesced epilogue
     if (lds_out > lds) lds = lds_out;
     if (lds > 160 * 1024) return PESR_EINVAL;
@@ -491,23 +502,18 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
     }
     const long grid = tiles * a.ksplit;
     const float* bias = a.bias; const float* skip = a.skip; const float* mask = a.mask;
-    if (a.ntaps > 1) {
-        auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, true>;
-        static bool attr_set = false;  // benign race: idempotent
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
-    } else {
-        auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, false>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+#define PESR_LAUNCH_MODE(M_)                                                                              \
+    {                                                                                                      \
+        auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, M_>;                              \
+        static bool attr_set = false; /* benign race: idempotent */                                        \
+        if (!attr_set) {                                                                                   \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                               \
+        }                                                                                                  \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);                          \
     }
+    if (mode == 2) PESR_LAUNCH_MODE(2) else if (mode == 1) PESR_LAUNCH_MODE(1) else PESR_LAUNCH_MODE(0)
+#undef PESR_LAUNCH_MODE
     if (a.ksplit > 1) {
         const long total = (long)(out_bytes / sizeof(float));
         const int fgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -524,8 +530,6 @@ static int dispatch(ConvArgs& a, int hext, int wext, hipStream_t stream) {
     if (a.Cout % 256 == 0) {
         // enough tiles to fill 256 CUs with the big tile?
         const long tiles_big = (M / 144) * (a.Cout / 256);
-        static const bool four_waves = getenv("PESR_CONV_4W") != nullptr;   // experiment: 1 wave per SIMD, 144 accumulators
-        if (tiles_big >= 192 && four_waves && S == 1) return launch_cfg<1, 4, 9, 4, 1, 4>(a, hext, wext, stream);
         if (tiles_big >= 192) return launch_cfg<1, 8, 9, 2, S, (S == 1 ? 2 : 6)>(a, hext, wext, stream);
     }
     if (a.Cout % 128 == 0) {
