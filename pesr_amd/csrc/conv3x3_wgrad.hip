@@ -148,20 +148,30 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
 
         const float* xb = buf + ci_tile * 16 + r;
         const float* db = buf + X_FLOATS + (co_half * COW) * 16 + r;
-#pragma unroll 2
-        for (int k4 = 0; k4 < TWO / 4; ++k4) {
-            const int px = k4 * 4 + g;
-            float av[COW], bv[9];
-#pragma unroll
-            for (int i = 0; i < COW; ++i) av[i] = db[px * DS + i * 16];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) bv[t] = xb[(((px / CW) * S + t / 3) * TWX + (px % CW) * S + (t % 3)) * XS];
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int i = 0; i < COW; ++i)
-                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[t][i], 0, 0, 0);
+        // fragments double-buffered across the k4 steps: the 4 + 9 ds_read_b32 of step k+1 are issued before the 36
+        // MFMAs of step k, so their latency hides under the matrix pipe instead of stalling in front of every MFMA group
+        float av0[COW], bv0[9], av1[COW], bv1[9];
+#define PESR_WG_READ(AV, BV, K4)                                                                        \
+        {                                                                                              \
+            const int px_ = (K4) * 4 + g;                                                              \
+            _Pragma("unroll") for (int i = 0; i < COW; ++i) AV[i] = db[px_ * DS + i * 16];             \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t)                                              \
+                BV[t] = xb[(((px_ / CW) * S + t / 3) * TWX + (px_ % CW) * S + (t % 3)) * XS];          \
         }
+#define PESR_WG_MFMA(AV, BV)                                                                            \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                  \
+            _Pragma("unroll") for (int i = 0; i < COW; ++i)                                            \
+                acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[i], BV[t], acc[t][i], 0, 0, 0);
+        PESR_WG_READ(av0, bv0, 0)
+#pragma unroll
+        for (int k4 = 0; k4 < TWO / 4; k4 += 2) {
+            PESR_WG_READ(av1, bv1, k4 + 1)
+            PESR_WG_MFMA(av0, bv0)
+            if (k4 + 2 < TWO / 4) PESR_WG_READ(av0, bv0, k4 + 2)
+            PESR_WG_MFMA(av1, bv1)
+        }
+#undef PESR_WG_READ
+#undef PESR_WG_MFMA
         if (more) store_seg(nbuf);
         __syncthreads();
     }

@@ -4,7 +4,11 @@ import torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 from pesr_amd import _lib
-libs = sys.argv[1:]
+what = "fwd"
+args = sys.argv[1:]
+if args and args[0] in ("fwd", "wgrad"):
+    what = args.pop(0)
+libs = args
 N, H, W, C = 16, 48, 48, 256
 x = torch.rand(N, H, W, C, device="cuda") - 0.5
 w = (torch.rand(C, C, 3, 3, device="cuda") - 0.5) * 0.1
@@ -18,7 +22,19 @@ for path in libs:
     handles.append(l)
 s = torch.cuda.current_stream().cuda_stream
 handles[0].pesr_pack_conv3x3(w.data_ptr(), wp.data_ptr(), C, C, 0, 0, s)
+dy = torch.rand(N, H, W, C, device="cuda") - 0.5
+dw = torch.empty(C, C, 3, 3, device="cuda"); dbias = torch.empty(C, device="cuda")
+ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
 def run(l, iters=20):
+    if what == "wgrad":
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            l.pesr_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), dbias.data_ptr(), N, H, W, C, C, 1, 1.0, 0, ws.data_ptr(), ws.numel(), s)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+    return run_fwd(l, iters)
+def run_fwd(l, iters=20):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
