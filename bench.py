@@ -28,6 +28,24 @@ GFLOP_PER_PATCH = {"gan": 844.10, "pretrain": 694.69}   # SURVEY.md 8(d), necess
 K1_GFLOP = 2.0 * 16 * 48 * 48 * 256 * 256 * 9 / 1e9     # body conv 256->256 @48x48, batch 16: 43.487 GFLOP per launch
 
 
+def k1_hbm_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot read PMCs
+    live): 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB in the profile."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_final_k1_pmc_summary.csv")
+    try:
+        fetch = write = None
+        for r in csv.DictReader(open(path)):
+            if "conv3x3_mfma_kernel<1, 8, 9, 2, 1, 2" in r["kernel"]:
+                if r["counter"] == "FETCH_SIZE":
+                    fetch = float(r["mean_per_launch"])
+                elif r["counter"] == "WRITE_SIZE":
+                    write = float(r["mean_per_launch"])
+        return int((2 * fetch + write) * 1024) if fetch and write else None
+    except OSError:
+        return None
+
+
 def build(args, device, world):
     from model import Discriminator, Generator, VGG
     from pesr_amd.optim import FlatAdam
@@ -171,7 +189,9 @@ def main():
         ach = K1_GFLOP * (args.batch / 16) * (args.patch_size / 48) ** 2 * (args.num_channels / 256) ** 2 / kern_ms  # TFLOP/s
         out["roofline"] = {"kernel": "conv3x3_mfma_kernel<1,8,9,2,1,2> forward (G body 256->256 @48x48, 65 launches/step)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": k1_hbm_traffic_bytes(),
+                           "traffic_note": "HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in "
+                                           "profiles/r01_final_k1_pmc_summary.csv (mean of fwd and dgrad launches); algorithmic: 78-116 MB",
                            "launches_timed": kern_n, "avg_launch_us": round(kern_ms * 1e3, 2)}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, G, D, vgg)
