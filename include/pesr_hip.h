@@ -132,6 +132,12 @@ int pesr_loss_l1_tv_fwd_bwd(const float* sr, const float* hr, float* grad, float
 int pesr_mse_fwd_bwd(const float* a, const float* b, float* grad, float* out1, long n, float gscale, void* workspace,
                      size_t ws_bytes, void* stream);
 
+/* ---- training-sample assembly on the GPU (reference data.py:79-126: _crop, _aug_data, _to_tensor) ---- */
+/* pool: device uint8 HWC images back to back.  desc: B rows of 3 int64 {byte offset of the image, stride_w | y0 << 32,
+ * x0 | aug << 32} (stride_w = image width in pixels; (y0, x0) crop origin; aug bit 0 hflip, bit 1 vflip, bit 2
+ * transpose, applied transpose -> vflip -> hflip as the reference).  out: [B][3][P][P] fp32 (nhwc = 0) or [B][P][P][3]. */
+int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, void* stream);
+
 /* ---- fused Adam on one flat buffer (reference train.py:124-125; torch.optim.Adam) ---------------- */
 /* g is multiplied by grad_scale first (1/world_size after a sum all-reduce). step is 1-based. */
 int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

@@ -50,3 +50,17 @@ def psnr_y(out, lbl):
     o = rgb2y(tensor_to_img(out)).clip(0, 255).round()
     l = rgb2y(tensor_to_img(lbl)).clip(0, 255).round()
     return 20 * np.log10(255 / np.sqrt(np.mean((o - l) ** 2)))
+
+
+def crop_augment(inp, lbl, patch, y, x, aug, scale=4):
+    """reference data.py:79-126 for one sample with the random draws made explicit: _crop at LR (y, x) / HR (4y, 4x),
+    _aug_data (bit 2 transpose, bit 1 vertical flip, bit 0 horizontal flip, in that order), _to_tensor (HWC -> CHW float)."""
+    inp = inp[y:y + patch, x:x + patch, :]
+    lbl = lbl[scale * y:scale * (y + patch), scale * x:scale * (x + patch), :]
+    if (aug >> 2) & 1:
+        inp, lbl = inp.transpose((1, 0, 2)).copy(), lbl.transpose((1, 0, 2)).copy()
+    if (aug >> 1) & 1:
+        inp, lbl = inp[::-1, :, :].copy(), lbl[::-1, :, :].copy()
+    if aug & 1:
+        inp, lbl = inp[:, ::-1, :].copy(), lbl[:, ::-1, :].copy()
+    return torch.FloatTensor(inp.transpose(2, 0, 1).copy()), torch.FloatTensor(lbl.transpose(2, 0, 1).copy())

@@ -132,3 +132,7 @@ PESR_API int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* b
                                   int act, float slope, void* stream) {
     return pesr_conv_rgb_in_launch(x, w, bias, y, N, H, W, Cout, act, slope, (hipStream_t)stream);
 }
+
+PESR_API int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, void* stream) {
+    return pesr_crop_augment_launch(pool, desc, out, B, P, nhwc, (hipStream_t)stream);
+}

@@ -166,3 +166,23 @@ def test_losses_and_adam():
         p.grad = gr.clone(); opt.step()
         ops.adam_step(pg, gr.cuda(), mg, vg, 5e-5, 0.9, 0.999, 1e-8, it)
     _close(pg.cpu(), p.detach(), 1e-6, "adam")
+
+
+def test_gpu_input_pipeline_bit_exact():
+    """Device-side crop + 8-way augmentation + uint8->float vs the oracle's restatement of reference data.py:79-126."""
+    import random
+    import numpy as np
+    from oracle import image as OI
+    from pesr_amd.input_pipeline import GpuPatchSampler
+    rs = np.random.RandomState(0)
+    lrs = [rs.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((20, 31), (17, 16), (40, 23))]
+    hrs = [rs.randint(0, 256, (4 * im.shape[0], 4 * im.shape[1], 3), dtype=np.uint8) for im in lrs]
+    samp = GpuPatchSampler(lrs, hrs, torch.device("cuda"))
+    picks = [(i % 3, y, x, aug) for i, (y, x, aug) in enumerate([(0, 0, a) for a in range(8)] + [(4, 3, 5), (1, 0, 6), (0, 2, 3)])]
+    picks += samp.draw(5, 12, random.Random(3))
+    for nhwc in (False, True):
+        lr, hr = samp.assemble(picks, 12, nhwc=nhwc)
+        assert lr.shape == (len(picks), 3, 12, 12) and hr.shape == (len(picks), 3, 48, 48)
+        for b, (i, y, x, aug) in enumerate(picks):
+            rl, rh = OI.crop_augment(lrs[i], hrs[i], 12, y, x, aug)
+            assert torch.equal(lr[b].cpu(), rl) and torch.equal(hr[b].cpu(), rh), (b, i, y, x, aug)

@@ -54,6 +54,8 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic samples per epoch instead of a dataset folder")
     p.add_argument("--vgg_weights", type=str, default="", help="state_dict file of torchvision vgg19 (offline pretrained weights)")
     p.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (smoke runs)")
+    p.add_argument("--gpu_pipeline", type=str2bool, default=False,
+                   help="keep the uint8 training images in HBM and crop/augment on the GPU (pesr_amd.input_pipeline)")
     return p
 
 
@@ -70,6 +72,31 @@ def make_loaders(args, rank, world):
                               num_workers=4, pin_memory=True, drop_last=True)
     val_loader = DataLoader(val_set, batch_size=1, shuffle=False, num_workers=1, pin_memory=True)
     return train_loader, val_loader, sampler
+
+
+class GpuLoader:
+    """Iterable with the DataLoader's contract (yields (lr, hr) batches) on top of GpuPatchSampler."""
+
+    def __init__(self, sampler, batch, patch, iters, seed):
+        import random
+        self.sampler, self.batch, self.patch, self.iters = sampler, batch, patch, iters
+        self.rng = random.Random(seed)
+
+    def __iter__(self):
+        for _ in range(self.iters):
+            yield self.sampler.sample(self.batch, self.patch, self.rng, augment=True, nhwc=True)
+
+
+def make_gpu_loader(args, rank, world, device):
+    import glob
+    from PIL import Image
+    from pesr_amd.input_pipeline import GpuPatchSampler
+    root = os.path.join("data/origin/train", args.train_dataset)
+    lr_paths = sorted(glob.glob(os.path.join(root, "LR", "*.png")))
+    lrs = [np.asarray(Image.open(p).convert("RGB")) for p in lr_paths]
+    hrs = [np.asarray(Image.open(os.path.join(root, "HR", os.path.basename(p))).convert("RGB")) for p in lr_paths]
+    iters = len(lrs) * args.num_repeats // args.batch_size
+    return GpuLoader(GpuPatchSampler(lrs, hrs, device), args.batch_size // world, args.patch_size, iters, seed=1 + rank)
 
 
 def main(argv=None):
@@ -94,6 +121,8 @@ def main(argv=None):
     from utils import compute_PSNR
 
     train_loader, val_loader, sampler = make_loaders(args, rank, world)
+    if args.gpu_pipeline and not args.synthetic:
+        train_loader, sampler = make_gpu_loader(args, rank, world, device), None
     opt = {"patch_size": args.patch_size, "num_channels": args.num_channels, "depth": args.num_blocks,
            "res_scale": args.res_scale, "spectral_norm": args.spectral_norm}
     G = Generator(opt)
