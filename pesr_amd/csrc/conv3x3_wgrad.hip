@@ -28,6 +28,7 @@ struct WgradArgs {
     int segs_per_split;
     int co_tiles, ci_tiles;
     int ps_in;
+    float* bias_part;  // [split][ci_tiles][Cout] partial column sums of dy (bias gradient), or null
 };
 
 // R: output rows per segment (narrow images: a 48-pixel segment is 2 x 24 or 4 x 12 instead of a mostly-empty 1 x 48)
@@ -71,6 +72,16 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
         for (int i = 0; i < COW; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 xreg[XL], dreg[DL];
+
+    // bias-gradient bookkeeping: thread -> (channel bcol of the co tile, row lane brl of BRL); this workgroup's pixel share
+    constexpr int BRL = NT / CO_T;
+    const int bcol = tid % CO_T, brl = tid / CO_T;
+    int brow0 = 0, brow1 = 0;
+    if (a.bias_part) {
+        if (TWO % a.ci_tiles == 0) { brow0 = cit * (TWO / a.ci_tiles); brow1 = brow0 + TWO / a.ci_tiles; }
+        else if (cit == 0) brow1 = TWO;
+    }
+    float bsum = 0.f;
 
     // dy channel base for this workgroup's co tile (ps_in: packed channel p = sub*C + cc)
     const int d_C = a.ps_in ? (a.Cout >> 2) : a.Cout;
@@ -172,10 +183,28 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
         }
 #undef PESR_WG_READ
 #undef PESR_WG_MFMA
+        if (a.bias_part) {
+            // bias gradient for free: the dy rows of this segment are in LDS; the ci-tile workgroups that share them
+            // split its pixels among themselves (balanced), each thread sums one channel over its rows
+            const float* dcol = buf + X_FLOATS + bcol;
+#pragma unroll 4
+            for (int px = brow0 + brl; px < brow1; px += BRL) bsum += dcol[px * DS];
+        }
         if (more) store_seg(nbuf);
         __syncthreads();
     }
 
+    if (a.bias_part) {   // combine the BRL row lanes through LDS (the staging buffers are free now), fixed order
+        float* red = lds;
+        red[brl * CO_T + bcol] = bsum;
+        __syncthreads();
+        if (brl == 0 && co0 + bcol < a.Cout) {
+            float t_ = red[bcol];
+#pragma unroll
+            for (int k = 1; k < BRL; ++k) t_ += red[k * CO_T + bcol];
+            a.bias_part[((size_t)sp * a.ci_tiles + cit) * a.Cout + co0 + bcol] = t_;
+        }
+    }
     // slab[sp][t][co][ci]: D tile row = co (= (lane>>4)*4 + reg), col = ci (= lane&15)
     float* out = a.slab + (size_t)sp * 9 * a.Cout * a.Cin;
 #pragma unroll
@@ -263,6 +292,15 @@ __global__ void colsum_final_kernel(const double* __restrict__ dsum, float* __re
     db[o] = alpha * (float)dsum[e];
 }
 
+// db[o] = alpha * dsum[p]; p = packed channel of o when the conv output was pixel-shuffled
+__global__ void bias_from_wgrad_kernel(const double* __restrict__ dsum, float* __restrict__ db, int Cout, float alpha, int ps) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Cout) return;
+    int o = p;
+    if (ps) { const int C = Cout >> 2; const int sub = p / C, cc = p - sub * C; o = 4 * cc + sub; }
+    db[o] = alpha * (float)dsum[p];
+}
+
 int pesr_bias_grad_launch(const float* dy, float* db, long pixels, int Cout, int OW, float alpha, int ps_in, float* part,
                           size_t part_bytes, hipStream_t stream) {
     // pixels = N*OH*OW of the (un-shuffled) conv output; Cout its channel count
@@ -312,7 +350,8 @@ static bool wgrad_plan(int N, int H, int W, int Cin, int Cout, int stride, Wgrad
     p->slab_bytes = ((size_t)p->split * 9 * Cout * Cin * sizeof(float) + 255) / 256 * 256;
     p->colsum_blocks = 2048;
     const size_t part_bytes = (size_t)p->colsum_blocks * 2 * Cout * sizeof(float) + 2 * (size_t)Cout * sizeof(double) + 256;
-    p->total_bytes = p->slab_bytes + part_bytes;
+    const size_t fused_bytes = (size_t)Cout * sizeof(double) + (size_t)p->split * p->ci_tiles * Cout * sizeof(float) + 1024;
+    p->total_bytes = p->slab_bytes + (part_bytes > fused_bytes ? part_bytes : fused_bytes);
     return true;
 }
 
@@ -354,6 +393,12 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
     a.segs_x = p.segs_x; a.row_groups = p.row_groups; a.total_segs = p.total_segs; a.segs_per_split = p.segs_per_split;
     a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.ps_in = ps_in;
+    // bias gradient fused into the wgrad kernel: partials [split*ci_tiles][Cout] (+ Cout doubles) behind the slab
+    const size_t bias_rows = (size_t)p.split * p.ci_tiles;
+    const size_t bias_need = (size_t)Cout * sizeof(double) + bias_rows * Cout * sizeof(float) + 256;
+    const bool fuse_bias = db != nullptr && ws_bytes - p.slab_bytes >= bias_need;
+    double* bias_dsum = (double*)((char*)ws + p.slab_bytes);
+    a.bias_part = fuse_bias ? (float*)((char*)ws + p.slab_bytes + (((size_t)Cout * sizeof(double) + 255) / 256) * 256) : nullptr;
     int rc;
 #define PESR_WG(S_, TWO_, R_) (p.cow == 4 ? launch_wgrad<4, S_, TWO_, R_>(a, p.split, stream) : launch_wgrad<2, S_, TWO_, R_>(a, p.split, stream))
     if (stride == 1) rc = p.rows == 4 ? PESR_WG(1, 48, 4) : (p.rows == 2 ? PESR_WG(1, 48, 2) : PESR_WG(1, 48, 1));
@@ -365,6 +410,12 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in);
     rc = pesr_launch_status();
     if (rc || !db) return rc;
+    if (fuse_bias) {
+        rc = pesr_reduce_rows_launch(a.bias_part, bias_dsum, (int)bias_rows, Cout, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bias_from_wgrad_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, (const double*)bias_dsum, db, Cout, alpha, ps_in);
+        return pesr_launch_status();
+    }
     float* part = (float*)((char*)ws + p.slab_bytes);
     return pesr_bias_grad_launch(dy, db, (long)N * a.OH * a.OW, Cout, a.OW, alpha, ps_in, part, ws_bytes - p.slab_bytes, stream);
 }
