@@ -20,6 +20,38 @@ def bump_weight_epoch() -> None:
     _WEIGHT_EPOCH[0] += 1
 
 
+# Flat-gradient fast path.  pesr_amd.optim.FlatParams registers, per parameter, a factory of fresh views into its flat
+# gradient buffer.  When a backward produces a parameter's FIRST gradient of the step (param.grad is None) the kernel
+# writes straight into such a view and returns it; autograd then adopts it as .grad without a copy or an add kernel
+# (AccumulateGrad steals a uniquely-referenced, contiguous gradient).  The slice is handed out ONCE per step: a
+# parameter used twice in one graph (the Discriminator sees hr and sr in the same backward) gets a temporary for its
+# second contribution, which autograd's input buffer adds to the first.
+_GRAD_VIEWS = {}   # id(param) -> [factory, claimed]
+
+
+def register_grad_view(param: torch.Tensor, factory) -> None:
+    _GRAD_VIEWS[id(param)] = [factory, False]
+
+
+def release_grad_views(params) -> None:
+    """New step (zero_grad): every registered slice may be claimed again."""
+    for p in params:
+        e = _GRAD_VIEWS.get(id(p))
+        if e is not None:
+            e[1] = False
+
+
+def grad_out(param):
+    """A fresh view of the parameter's flat-gradient slice if its first gradient may be written there, else None."""
+    if param is None or param.grad is not None:
+        return None
+    e = _GRAD_VIEWS.get(id(param))
+    if e is None or e[1]:
+        return None
+    e[1] = True
+    return e[0]()
+
+
 class PackedConvWeights:
     """Per-parameter cache of the kernel-side weight layouts (forward / dgrad packing, PS-permuted bias)."""
 
@@ -81,6 +113,7 @@ class Conv3x3Fn(Function):
         ctx.cache, ctx.stride, ctx.act, ctx.relu_in = cache, stride, act, relu_in
         ctx.mask_here = act == ops.ACT_RELU and not relu_grad_by_consumer
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.save_for_backward(x, weight, y if ctx.mask_here else None)
         return y
 
@@ -97,12 +130,13 @@ class Conv3x3Fn(Function):
                                    mask=x if ctx.relu_in else None, ps_in=ps)
         if ctx.needs_input_grad[1]:
             want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            outs = dict(dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref) if want_b else None)
             if cin == 3:
-                dw, db = ops.conv3x3_wgrad_rgb(gy, x, 0, want_bias=want_b)
+                dw, db = ops.conv3x3_wgrad_rgb(gy, x, 0, want_bias=want_b, **outs)
             elif weight.shape[0] == 3:
-                dw, db = ops.conv3x3_wgrad_rgb(x, gy, 1, want_bias=want_b)
+                dw, db = ops.conv3x3_wgrad_rgb(x, gy, 1, want_bias=want_b, **outs)
             else:
-                dw, db = ops.conv3x3_wgrad(x, gy, ctx.stride, want_bias=want_b, ps_in=ps)
+                dw, db = ops.conv3x3_wgrad(x, gy, ctx.stride, want_bias=want_b, ps_in=ps, **outs)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -120,7 +154,7 @@ class ConvAddFn(Function):
     def forward(ctx, x, skip, weight, bias, cache):
         x, skip = _c(x), _c(skip)
         y = ops.conv3x3_fwd(x, cache.fwd(weight), cache.bias(bias), weight.shape[0], 1, skip=skip)
-        ctx.cache = cache
+        ctx.cache, ctx.bias_ref = cache, bias
         ctx.save_for_backward(x, weight)
         return y
 
@@ -131,7 +165,7 @@ class ConvAddFn(Function):
         dx = ops.conv3x3_dgrad(gy, ctx.cache.dgrad(weight), tuple(x.shape), 1) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[2]:
-            dw, db = ops.conv3x3_wgrad(x, gy, 1, want_bias=True)
+            dw, db = ops.conv3x3_wgrad(x, gy, 1, want_bias=True, dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref))
         return dx, gy, dw, db, None
 
 
@@ -151,6 +185,7 @@ class ResBlockFn(Function):
         r = ops.conv3x3_fwd(x, c1.fwd(w1), b1.detach(), C, 1, act=ops.ACT_RELU)
         y = ops.conv3x3_fwd(r, c2.fwd(w2), b2.detach(), C, 1, alpha=res_scale, skip=x)
         ctx.c1, ctx.c2, ctx.res_scale = c1, c2, res_scale
+        ctx.b1_ref, ctx.b2_ref = b1, b2
         ctx.save_for_backward(x, r, w1, w2)
         return y
 
@@ -163,8 +198,8 @@ class ResBlockFn(Function):
         dr = ops.conv3x3_dgrad(gy, ctx.c2.dgrad(w2), tuple(r.shape), 1, alpha=s, mask=r)
         dw1 = db1 = dw2 = db2 = None
         if need_w:
-            dw2, db2 = ops.conv3x3_wgrad(r, gy, 1, alpha=s)
-            dw1, db1 = ops.conv3x3_wgrad(x, dr, 1)
+            dw2, db2 = ops.conv3x3_wgrad(r, gy, 1, alpha=s, dw_out=grad_out(w2), db_out=grad_out(ctx.b2_ref))
+            dw1, db1 = ops.conv3x3_wgrad(x, dr, 1, dw_out=grad_out(w1), db_out=grad_out(ctx.b1_ref))
         dx = ops.conv3x3_dgrad(dr, ctx.c1.dgrad(w1), tuple(x.shape), 1, skip=gy) if ctx.needs_input_grad[0] else None
         return dx, dw1, db1, dw2, db2, None, None, None
 
@@ -177,7 +212,7 @@ class MeanShiftFn(Function):
     def forward(ctx, x, weight, bias, x_nchw, y_nchw):
         x = _c(x)
         y = ops.meanshift_fwd(x, weight.detach(), bias.detach(), x_nchw, y_nchw)
-        ctx.x_nchw, ctx.y_nchw = x_nchw, y_nchw
+        ctx.x_nchw, ctx.y_nchw, ctx.bias_ref = x_nchw, y_nchw, bias
         ctx.save_for_backward(x, weight)
         return y
 
@@ -188,7 +223,7 @@ class MeanShiftFn(Function):
             gy = gy.permute(0, 2, 3, 1)
         gy = _c(gy)
         need_dx = ctx.needs_input_grad[0]
-        dx, dw, db = ops.meanshift_bwd(gy, x, weight, ctx.x_nchw, need_dx)
+        dx, dw, db = ops.meanshift_bwd(gy, x, weight, ctx.x_nchw, need_dx, dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref))
         if need_dx and ctx.x_nchw:
             dx = dx.permute(0, 3, 1, 2)
         return dx, dw, db, None, None
@@ -214,15 +249,16 @@ class ConvBnLReluFn(Function):
         x, z, weight, gamma, beta, stats = ctx.saved_tensors
         gy = _c(gy)
         need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
-        dz, dgamma, dbeta = ops.bn_lrelu_bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p)
+        dz, dgamma, dbeta = ops.bn_lrelu_bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p,
+                                             dgamma_out=grad_out(gamma) if need_p else None, dbeta_out=grad_out(beta) if need_p else None)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3x3_dgrad(dz, ctx.cache.dgrad(weight), tuple(x.shape), ctx.stride)
         if ctx.needs_input_grad[1]:
             if x.shape[3] == 3:
-                dw, _ = ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=False)
+                dw, _ = ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=False, dw_out=grad_out(weight))
             else:
-                dw, _ = ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=False)
+                dw, _ = ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=False, dw_out=grad_out(weight))
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
@@ -234,7 +270,7 @@ class LinearFn(Function):
     def forward(ctx, x, weight, bias, act, slope):
         x = _c(x)
         y = ops.linear_fwd(x, weight.detach(), bias.detach(), act, slope)
-        ctx.act, ctx.slope = act, slope
+        ctx.act, ctx.slope, ctx.bias_ref = act, slope, bias
         ctx.save_for_backward(x, weight, y if act != ops.ACT_NONE else None)
         return y
 
@@ -250,7 +286,7 @@ class LinearFn(Function):
         dx = ops.linear_dgrad(gy, weight.detach()) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1]:
-            dw, db = ops.linear_wgrad(gy, x, want_bias=True)
+            dw, db = ops.linear_wgrad(gy, x, want_bias=True, dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref))
         return dx, dw, db, None, None
 
 

@@ -155,8 +155,16 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
     return dx
 
 
+def _out(t, shape, device):
+    """Use the caller's output tensor (a view into a flat gradient buffer) when given, else allocate."""
+    if t is not None:
+        assert tuple(t.shape) == tuple(shape) and t.is_contiguous() and t.dtype == torch.float32
+        return t
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: float = 1.0, want_bias: bool = True,
-                  ps_in: bool = False):
+                  ps_in: bool = False, dw_out=None, db_out=None):
     """(dw [O, I, 3, 3], db [O] | None)."""
     _chk(x, "conv3x3_wgrad.x")
     _chk(dy, "conv3x3_wgrad.dy")
@@ -167,15 +175,16 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
     if nbytes == 0:
         raise _lib.PesrHipError(f"pesr_conv3x3_wgrad: unsupported shape Cin={Cin} Cout={cout} stride={stride}")
     ws = workspace(nbytes, x.device)
-    dw = torch.empty((cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
-    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    dw = _out(dw_out, (cout, Cin, 3, 3), x.device)
+    db = _out(db_out, (cout,), x.device) if want_bias else None
     rc = L.pesr_conv3x3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, H, W, Cin, cout, stride, alpha, int(ps_in), _p(ws),
                               ws.numel(), _stream())
     _lib.check(rc, f"pesr_conv3x3_wgrad[{N}x{H}x{W}x{Cin}->{cout},s{stride}]")
     return dw, db
 
 
-def conv3x3_wgrad_rgb(a: torch.Tensor, b3: torch.Tensor, mode: int, alpha: float = 1.0, want_bias: bool = True):
+def conv3x3_wgrad_rgb(a: torch.Tensor, b3: torch.Tensor, mode: int, alpha: float = 1.0, want_bias: bool = True,
+                      dw_out=None, db_out=None):
     """Weight grad of a conv with a 3-channel side. mode 0: a=dy [N,H,W,C], b3=x -> dw [C,3,3,3]; mode 1: a=x, b3=dy -> dw [3,C,3,3]."""
     _chk(a, "conv3x3_wgrad_rgb.a")
     _chk(b3, "conv3x3_wgrad_rgb.b3")
@@ -186,8 +195,8 @@ def conv3x3_wgrad_rgb(a: torch.Tensor, b3: torch.Tensor, mode: int, alpha: float
     if nbytes == 0:
         raise _lib.PesrHipError(f"pesr_conv3x3_wgrad_rgb: unsupported channel count {C}")
     ws = workspace(nbytes, a.device)
-    dw = torch.empty((C, 3, 3, 3) if mode == 0 else (3, C, 3, 3), dtype=torch.float32, device=a.device)
-    db = torch.empty((C if mode == 0 else 3,), dtype=torch.float32, device=a.device) if want_bias else None
+    dw = _out(dw_out, (C, 3, 3, 3) if mode == 0 else (3, C, 3, 3), a.device)
+    db = _out(db_out, (C if mode == 0 else 3,), a.device) if want_bias else None
     rc = L.pesr_conv3x3_wgrad_rgb(_p(a), _p(b3), _p(dw), _p(db), N, H, W, C, mode, alpha, _p(ws), ws.numel(), _stream())
     _lib.check(rc, "pesr_conv3x3_wgrad_rgb")
     return dw, db
@@ -209,12 +218,13 @@ def meanshift_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, x_nchw: boo
     return y
 
 
-def meanshift_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, x_nchw: bool = False, need_dx: bool = True):
+def meanshift_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, x_nchw: bool = False, need_dx: bool = True,
+                  dw_out=None, db_out=None):
     _chk(dy, "meanshift_bwd.dy")
     N, H, W, _ = dy.shape
     dx = torch.empty_like(dy) if need_dx else None
-    dw = torch.empty((3, 3, 1, 1), dtype=torch.float32, device=dy.device)
-    db = torch.empty((3,), dtype=torch.float32, device=dy.device)
+    dw = _out(dw_out, (3, 3, 1, 1), dy.device)
+    db = _out(db_out, (3,), dy.device)
     ws = workspace(1024 * 12 * 4 + 128, dy.device)
     rc = _lib.lib().pesr_meanshift_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), N, H, W, int(x_nchw), _p(ws),
                                        ws.numel(), _stream())
@@ -279,14 +289,14 @@ def bn_lrelu_fwd(x, gamma, beta, running_mean, running_var, num_batches, eps=1e-
     return y, stats
 
 
-def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param_grads=True):
+def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param_grads=True, dgamma_out=None, dbeta_out=None):
     _chk(dy, "bn_lrelu_bwd.dy")
     N, H, W, C = x.shape
     L = _lib.lib()
     ws = workspace(L.pesr_bn_workspace_bytes(N * H * W, C), x.device)
     dx = torch.empty_like(x)
-    dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if need_param_grads else None
-    dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if need_param_grads else None
+    dgamma = _out(dgamma_out, (C,), x.device) if need_param_grads else None
+    dbeta = _out(dbeta_out, (C,), x.device) if need_param_grads else None
     rc = L.pesr_bn_lrelu_bwd(_p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), N, H, W, C, slope,
                              int(dy_nchw), _p(ws), ws.numel(), _stream())
     _lib.check(rc, "pesr_bn_lrelu_bwd")
@@ -318,12 +328,12 @@ def linear_dgrad(dy, w):
     return dx
 
 
-def linear_wgrad(dy, x, want_bias=True):
+def linear_wgrad(dy, x, want_bias=True, dw_out=None, db_out=None):
     _chk(dy, "linear_wgrad.dy")
     M, Nf = dy.shape
     K = x.shape[1]
-    dw = torch.empty((Nf, K), dtype=torch.float32, device=dy.device)
-    db = torch.empty((Nf,), dtype=torch.float32, device=dy.device) if want_bias else None
+    dw = _out(dw_out, (Nf, K), dy.device)
+    db = _out(db_out, (Nf,), dy.device) if want_bias else None
     _lib.check(_lib.lib().pesr_linear_wgrad(_p(dy), _p(x), _p(dw), _p(db), M, Nf, K, _stream()), "pesr_linear_wgrad")
     return dw, db
 

@@ -38,21 +38,28 @@ class FlatParams:
             n = p.numel()
             self.flat_p[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[o:o + n].view(p.shape)
-            p.grad = self.flat_g[o:o + n].view(p.shape)
+            p.grad = None
+            PF.register_grad_view(p, (lambda o=o, n=n, shape=p.shape: self.flat_g[o:o + n].view(shape)))
+
+    def attach_one(self, i: int) -> None:
+        p, o = self.params[i], self.offsets[i]
+        if p.grad is not None and p.grad.data_ptr() != self.flat_g.data_ptr() + o * self.flat_g.element_size():
+            view = self.flat_g[o:o + p.numel()].view(p.shape)
+            view.copy_(p.grad)
+            p.grad = view
 
     def attach_grads(self) -> None:
-        """(Re)point every .grad at its slice of the flat gradient buffer."""
-        for p, o in zip(self.params, self.offsets):
-            n = p.numel()
-            view = self.flat_g[o:o + n].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                if p.grad is not None:
-                    view.copy_(p.grad)
-                p.grad = view
+        """Make the flat gradient buffer hold every parameter's gradient: a .grad that already is a view of its slice
+        (the fast path of functional.grad_out, or autograd's in-place accumulation into it) needs nothing; a foreign
+        tensor is copied in; a missing gradient leaves the slice at zero."""
+        for i in range(len(self.params)):
+            self.attach_one(i)
 
     def zero_grad(self) -> None:
         self.flat_g.zero_()
-        self.attach_grads()
+        for p in self.params:
+            p.grad = None
+        PF.release_grad_views(self.params)
 
 
 class GradBuckets:
@@ -102,6 +109,7 @@ class GradBuckets:
 
     def _make_hook(self, i: int) -> Callable:
         def hook(_p):
+            self.flat.attach_one(i)          # a gradient that arrived as a foreign tensor is moved into the flat buffer first
             b = self.bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0 and not self._launched[b]:

@@ -84,9 +84,18 @@ def test_flat_params_views_and_zero_grad():
     flat = FlatParams(ps)
     assert flat.numel == 16 + 8 and all(o % 4 == 0 for o in flat.offsets)
     for p, v in zip(ps, vals):
-        assert torch.equal(p.detach(), v) and p.grad is not None and p.data_ptr() >= flat.flat_p.data_ptr()
-    (ps[0].sum() * 2 + ps[1].sum()).backward()
+        assert torch.equal(p.detach(), v) and p.grad is None and p.data_ptr() >= flat.flat_p.data_ptr()
+    (ps[0].sum() * 2 + ps[1].sum()).backward()     # plain autograd: gradients arrive as foreign tensors
+    flat.attach_grads()                            # ... and are moved into the flat buffer
     assert torch.equal(flat.flat_g[:15], torch.full((15,), 2.0)) and torch.equal(flat.flat_g[16:23], torch.ones(7))
-    ps[1].grad = None                        # someone dropped a grad: attach_grads restores the view
+    assert ps[0].grad.data_ptr() == flat.flat_g.data_ptr()
+    (ps[0].sum()).backward()                       # a second backward accumulates in place into the flat view
+    assert torch.equal(flat.flat_g[:15], torch.full((15,), 3.0))
     flat.zero_grad()
-    assert ps[1].grad is not None and float(flat.flat_g.abs().sum()) == 0.0
+    assert ps[1].grad is None and float(flat.flat_g.abs().sum()) == 0.0
+    # the fast path of functional.grad_out: one claim per step
+    from pesr_amd import functional as PF
+    v1 = PF.grad_out(ps[0]); v2 = PF.grad_out(ps[0])
+    assert v1 is not None and v1.data_ptr() == flat.flat_g.data_ptr() and v2 is None
+    flat.zero_grad()
+    assert PF.grad_out(ps[0]) is not None
