@@ -11,13 +11,15 @@ from torch.autograd import Function
 
 from . import ops
 
-# Bumped whenever weights may have been changed behind torch's back (our fused Adam writes through raw
-# pointers and cannot bump Tensor._version).  Part of every packed-weight cache key.
-_WEIGHT_EPOCH = [0]
+# Our fused Adam writes parameters through raw pointers and cannot bump Tensor._version, so every parameter it owns
+# carries an explicit epoch here (bumped by FlatAdam.step for ITS parameters only - the static VGG weights and the
+# other network's weights keep their packed copies).  Part of every packed-weight cache key.
+_PARAM_EPOCH = {}   # id(param) -> int
 
 
-def bump_weight_epoch() -> None:
-    _WEIGHT_EPOCH[0] += 1
+def bump_weight_epoch(params) -> None:
+    for p in params:
+        _PARAM_EPOCH[id(p)] = _PARAM_EPOCH.get(id(p), 0) + 1
 
 
 # Flat-gradient fast path.  pesr_amd.optim.FlatParams registers, per parameter, a factory of fresh views into its flat
@@ -62,7 +64,7 @@ class PackedConvWeights:
 
     @staticmethod
     def _key(t: torch.Tensor):
-        return (t.data_ptr(), t._version, _WEIGHT_EPOCH[0])
+        return (t.data_ptr(), t._version, _PARAM_EPOCH.get(id(t), 0))
 
     def fwd(self, w: torch.Tensor) -> torch.Tensor:
         k = self._key(w)

@@ -149,7 +149,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_p)
         self.buckets = GradBuckets(self.flat, process_group, bucket_bytes)
         self.steps = 0
-        PF.bump_weight_epoch()
+        PF.bump_weight_epoch(self.flat.params)
 
     def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: ARG002 (kept for API compatibility)
         self.flat.zero_grad()
@@ -165,4 +165,4 @@ class FlatAdam(torch.optim.Optimizer):
         self.steps += 1
         ops.adam_step(self.flat.flat_p, self.flat.flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],
                       g["betas"][1], g["eps"], self.steps, scale)
-        PF.bump_weight_epoch()   # packed conv weights are now stale
+        PF.bump_weight_epoch(self.flat.params)   # this optimizer's packed conv weights are now stale
