@@ -44,12 +44,17 @@ def adam_close(got, ref, lr, steps, what=""):
     """Post-Adam parameter comparison.  Adam's first steps move every element by ~lr in the direction of sign(g), so an
     element whose gradient is at the fp32 noise level can legitimately differ by up to 2*lr per step (the reference's
     own fp32-vs-fp64 runs differ by 2.0*lr after two steps on some elements).  What parity
-    can and does assert: the worst element stays within that sign-flip bound, and the MEAN error stays far below lr
-    (a tensor that is not trained, or trained with a wrong gradient, is off by >= lr on average)."""
+    can and does assert: the worst element stays within that sign-flip bound, at most a few elements (3 % / 3) are
+    "flipped" (off by > 0.5 lr), and the MEAN error of all others stays far below lr (a tensor that is not trained, or
+    trained with a wrong gradient, is off by >= lr on average)."""
     a = np.asarray(got.detach().cpu() if torch.is_tensor(got) else got, dtype=np.float64).reshape(-1)
     b = np.asarray(ref.detach().cpu() if torch.is_tensor(ref) else ref, dtype=np.float64).reshape(-1)
     assert a.shape == b.shape, (what, a.shape, b.shape)
     err = np.abs(a - b)
     scale = np.abs(b).max() + 1e-30
     assert err.max() <= 2.2 * lr * steps + 2e-5 * scale, f"{what}: max err {err.max():.3e} = {err.max() / lr:.2f} lr"
-    assert err.mean() <= 0.08 * lr + 2e-6 * scale, f"{what}: mean err {err.mean():.3e} = {err.mean() / lr:.3f} lr"
+    flipped = err > 0.5 * lr                       # elements whose near-zero gradient changed sign somewhere
+    assert flipped.sum() <= max(3, 0.03 * err.size), f"{what}: {int(flipped.sum())} of {err.size} elements off by > 0.5 lr"
+    rest = err[~flipped]
+    if rest.size:
+        assert rest.mean() <= 0.06 * lr + 2e-6 * scale, f"{what}: mean err of the rest {rest.mean():.3e} = {rest.mean() / lr:.3f} lr"

@@ -77,3 +77,22 @@ def test_train_flags_match_reference_defaults():
     for k, v in expect.items():
         assert getattr(a, k) == v, k
     assert Tm.build_parser().parse_args(["--focal_loss", "false"]).focal_loss is False
+
+
+def test_product_focal_loss_matches_reference_values_and_q4_gradient():
+    """pesr_amd.model.FocalLoss (scalar-sized torch ops, runs anywhere): forward vs the values the REFERENCE module gave
+    (golden GV5), backward vs the torch-0.4-semantics closed form."""
+    import pytest
+    from oracle import step as OS
+    from pesr_amd.model.focal_loss import FocalLoss
+    g = load_golden("gv5_focal")
+    x = torch.from_numpy(g["x"])
+    for gamma in (0, 1, 2):
+        for t in (0, 1):
+            tt = torch.full_like(x, float(t))
+            xr = x.clone().requires_grad_(True)
+            loss = FocalLoss(gamma)(xr, tt)
+            assert float(loss) == pytest.approx(float(g[f"mean_g{gamma}_t{t}"]), rel=1e-6)
+            loss.backward()
+            ref = OS.focal_loss_grad_closed_form(x, tt, gamma)
+            assert torch.allclose(xr.grad, ref, rtol=1e-5, atol=1e-9)

@@ -222,3 +222,26 @@ def test_config5_large_tiles_64bit_indexing():
         # and the first image's corner (zero padding included) against a corner crop
         yc0 = G(x[0:1, :, :s, :s].contiguous())
         assert torch.equal(y[0, :, :4 * (s - m), :4 * (s - m)], yc0[0, :, :4 * (s - m), :4 * (s - m)])
+
+
+@pytest.mark.parametrize("gan_type,focal", [("SGAN", False), ("SGAN", True), ("RSGAN", False)])
+def test_gan_step_other_branches_vs_oracle(gan_type, focal):
+    """The non-default branches of reference train.py:210-213,244-253 (SGAN, plain BCE generator loss), one step."""
+    from model import Discriminator, Generator, VGG
+    from pesr_amd.optim import FlatAdam
+    from pesr_amd.step import Trainer
+    g_sd, d_sd, v_sd = gen_sd(64, 1), dis_sd(8), vgg_sd()
+    G = Generator({"num_channels": 64, "depth": 1, "res_scale": 0.1}); G.load_state_dict(g_sd); G.cuda()
+    D = Discriminator({"patch_size": 8, "spectral_norm": False}); D.load_state_dict(d_sd); D.cuda()
+    V = VGG(); V.load_state_dict(v_sd); V.cuda()
+    tr = Trainer(G, D, V, FlatAdam(G.parameters(), lr=5e-5), FlatAdam(D.parameters(), lr=5e-5), gan_type=gan_type,
+                 focal_loss=focal, alpha_l1=0.5)
+    st = OS.TrainState(g_sd, d_sd, v_sd, {"depth": 1, "res_scale": 0.1, "learning_rate": 5e-5, "gan_type": gan_type,
+                                           "focal_loss": focal, "alpha_l1": 0.5})
+    lr = detrand.image_batch((4, 3, 8, 8), 500); hr = detrand.image_batch((4, 3, 32, 32), 501)
+    ref = OS.gan_step(st, lr, hr)
+    log = tr.gan_step(lr.cuda(), hr.cuda())
+    for k in ("l1", "vgg", "g", "tv", "d"):
+        assert float(log[k]) == pytest.approx(ref[k], rel=5e-5, abs=1e-7), k
+    for k, v in G.state_dict().items():
+        adam_close(v, st.g[k], 5e-5, 1, "G." + k)
