@@ -110,12 +110,39 @@ def cpu_baseline(args, G, D, vgg):
                       f"(1/{16 // B} of a GPU step's batch), full model size, {dt:.1f} s"}
 
 
+def bench_infer512(args, device):
+    """BASELINE config 5 (side measurement, 1 GPU): G forward, no_grad, 4 x 512x512 LR -> 2048x2048; 105.39 TFLOP per batch."""
+    from model import Generator
+    torch.manual_seed(0)
+    G = Generator({"num_channels": 256, "depth": 32, "res_scale": 0.1}).to(device)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 256, (4, 3, 512, 512), generator=g).float().to(device)
+    with torch.no_grad():
+        for _ in range(max(1, args.warmup)):
+            G(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = G(x)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    tf = 105.3875 / dt
+    print(json.dumps({"metric": "LR tiles/sec (x4 SR generator forward, 512x512 LR tiles, batch 4)", "value": round(4 / dt, 3),
+                      "unit": "tiles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2),
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "BASELINE config 5: G forward no_grad, 4x3x512x512 -> 4x3x2048x2048, 256 ch x 32 blocks"},
+                      "step_tflops_per_gpu": round(tf, 2), "step_frac_of_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                      "out_checksum": float(y.double().sum())}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["gan", "pretrain"], default="gan")
+    ap.add_argument("--workload", choices=["gan", "pretrain", "infer512"], default="gan",
+                    help="gan = BASELINE config 3/4 (the headline metric); pretrain = config 2; infer512 = config 5 "
+                         "(G forward on 4 x 512x512 LR tiles, no_grad) - the latter two are side measurements")
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--patch_size", type=int, default=48)
     ap.add_argument("--num_channels", type=int, default=256)
@@ -139,6 +166,8 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from pesr_amd import ops
+    if args.workload == "infer512":
+        return bench_infer512(args, device)
     trainer, G, D, vgg = build(args, device, world)
     lr, hr = synth_batch(args.batch, args.patch_size, 1234 + rank, device)
     step = trainer.gan_step if args.workload == "gan" else trainer.pretrain_step
