@@ -90,6 +90,72 @@ class PackedConvWeights:
         return self._bias
 
 
+# Weight-gradient kernels run on a side stream: in a backward chain the dgrad kernels depend on each other but the wgrad
+# kernels only consume their outputs, so with two streams the workgroups of a wgrad fill the CUs that the previous
+# dgrad frees during its tail (each 256-workgroup launch otherwise idles the matrix pipes for ~25 us of ramp + epilogue).
+_SIDE = {}
+USE_SIDE_STREAM = __import__("os").environ.get("PESR_SIDE_STREAM", "1") != "0"   # PESR_SIDE_STREAM=0: everything on one stream
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    s = _SIDE.get(device.index)
+    if s is None:
+        s = _SIDE[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_side_stream(device=None) -> None:
+    """Make the current stream wait for everything queued on the side stream (optimizer step, gradient all-reduce)."""
+    for idx, s in _SIDE.items():
+        if device is None or device.index == idx:
+            torch.cuda.current_stream(s.device).wait_stream(s)
+
+
+_JOIN_QUEUED = [False]
+
+
+def _join_after_backward():
+    _JOIN_QUEUED[0] = False
+    join_side_stream()
+
+
+class _OnSide:
+    """with _OnSide(dev, tensors...): the side stream first waits for the work queued so far on the current stream;
+    the listed tensors (inputs read on the side stream) are protected from the caching allocator's early reuse.
+
+    Stream safety of the RESULTS: a gradient written into a flat-gradient view (`fast`) is consumed only by code that
+    joins the side stream first (FlatAdam.step, the all-reduce buckets, and a callback queued at the end of every
+    backward pass).  Anything else - a temporary that autograd itself will add to another contribution on the main
+    stream - makes the main stream wait for the side stream on exit (`fast=False`)."""
+
+    def __init__(self, device, *tensors, fast=False):
+        self.enabled = USE_SIDE_STREAM
+        self.fast, self.device = fast, device
+        if self.enabled:
+            if not _JOIN_QUEUED[0]:
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
+                    _JOIN_QUEUED[0] = True
+                except RuntimeError:      # not inside a backward pass (direct call of a backward in a test)
+                    self.fast = False
+            self.side = side_stream(device)
+            self.side.wait_stream(torch.cuda.current_stream(device))
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.side)
+            self.ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        if self.enabled:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.enabled:
+            self.ctx.__exit__(*a)
+            if not self.fast:
+                torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -127,18 +193,19 @@ class Conv3x3Fn(Function):
             gy = ops.relu_mask(gy, y)
         cin, ps = x.shape[3], ctx.cache.ps
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.conv3x3_dgrad(gy, ctx.cache.dgrad(weight), tuple(x.shape), ctx.stride,
-                                   mask=x if ctx.relu_in else None, ps_in=ps)
+        wpd = ctx.cache.dgrad(weight) if ctx.needs_input_grad[0] else None
         if ctx.needs_input_grad[1]:
             want_b = ctx.has_bias and ctx.needs_input_grad[2]
             outs = dict(dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref) if want_b else None)
-            if cin == 3:
-                dw, db = ops.conv3x3_wgrad_rgb(gy, x, 0, want_bias=want_b, **outs)
-            elif weight.shape[0] == 3:
-                dw, db = ops.conv3x3_wgrad_rgb(x, gy, 1, want_bias=want_b, **outs)
-            else:
-                dw, db = ops.conv3x3_wgrad(x, gy, ctx.stride, want_bias=want_b, ps_in=ps, **outs)
+            with _OnSide(gy.device, x, gy, fast=outs["dw_out"] is not None and (outs["db_out"] is not None or not want_b)):
+                if cin == 3:
+                    dw, db = ops.conv3x3_wgrad_rgb(gy, x, 0, want_bias=want_b, **outs)
+                elif weight.shape[0] == 3:
+                    dw, db = ops.conv3x3_wgrad_rgb(x, gy, 1, want_bias=want_b, **outs)
+                else:
+                    dw, db = ops.conv3x3_wgrad(x, gy, ctx.stride, want_bias=want_b, ps_in=ps, **outs)
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3x3_dgrad(gy, wpd, tuple(x.shape), ctx.stride, mask=x if ctx.relu_in else None, ps_in=ps)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -164,10 +231,13 @@ class ConvAddFn(Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = _c(gy)
-        dx = ops.conv3x3_dgrad(gy, ctx.cache.dgrad(weight), tuple(x.shape), 1) if ctx.needs_input_grad[0] else None
+        wpd = ctx.cache.dgrad(weight) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[2]:
-            dw, db = ops.conv3x3_wgrad(x, gy, 1, want_bias=True, dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref))
+            o_w, o_b = grad_out(weight), grad_out(ctx.bias_ref)
+            with _OnSide(gy.device, x, gy, fast=o_w is not None and o_b is not None):
+                dw, db = ops.conv3x3_wgrad(x, gy, 1, want_bias=True, dw_out=o_w, db_out=o_b)
+        dx = ops.conv3x3_dgrad(gy, wpd, tuple(x.shape), 1) if ctx.needs_input_grad[0] else None
         return dx, gy, dw, db, None
 
 
@@ -197,12 +267,18 @@ class ResBlockFn(Function):
         gy = _c(gy)
         s = ctx.res_scale
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
-        dr = ops.conv3x3_dgrad(gy, ctx.c2.dgrad(w2), tuple(r.shape), 1, alpha=s, mask=r)
         dw1 = db1 = dw2 = db2 = None
+        wpd2, wpd1 = ctx.c2.dgrad(w2), ctx.c1.dgrad(w1)      # (packing happens on the main stream)
         if need_w:
-            dw2, db2 = ops.conv3x3_wgrad(r, gy, 1, alpha=s, dw_out=grad_out(w2), db_out=grad_out(ctx.b2_ref))
-            dw1, db1 = ops.conv3x3_wgrad(x, dr, 1, dw_out=grad_out(w1), db_out=grad_out(ctx.b1_ref))
-        dx = ops.conv3x3_dgrad(dr, ctx.c1.dgrad(w1), tuple(x.shape), 1, skip=gy) if ctx.needs_input_grad[0] else None
+            o_w, o_b = grad_out(w2), grad_out(ctx.b2_ref)
+            with _OnSide(gy.device, r, gy, fast=o_w is not None and o_b is not None):
+                dw2, db2 = ops.conv3x3_wgrad(r, gy, 1, alpha=s, dw_out=o_w, db_out=o_b)
+        dr = ops.conv3x3_dgrad(gy, wpd2, tuple(r.shape), 1, alpha=s, mask=r)
+        if need_w:
+            o_w, o_b = grad_out(w1), grad_out(ctx.b1_ref)
+            with _OnSide(gy.device, x, dr, fast=o_w is not None and o_b is not None):
+                dw1, db1 = ops.conv3x3_wgrad(x, dr, 1, dw_out=o_w, db_out=o_b)
+        dx = ops.conv3x3_dgrad(dr, wpd1, tuple(x.shape), 1, skip=gy) if ctx.needs_input_grad[0] else None
         return dx, dw1, db1, dw2, db2, None, None, None
 
 
@@ -254,13 +330,16 @@ class ConvBnLReluFn(Function):
         dz, dgamma, dbeta = ops.bn_lrelu_bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p,
                                              dgamma_out=grad_out(gamma) if need_p else None, dbeta_out=grad_out(beta) if need_p else None)
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.conv3x3_dgrad(dz, ctx.cache.dgrad(weight), tuple(x.shape), ctx.stride)
+        wpd = ctx.cache.dgrad(weight) if ctx.needs_input_grad[0] else None
         if ctx.needs_input_grad[1]:
-            if x.shape[3] == 3:
-                dw, _ = ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=False, dw_out=grad_out(weight))
-            else:
-                dw, _ = ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=False, dw_out=grad_out(weight))
+            o_w = grad_out(weight)
+            with _OnSide(dz.device, x, dz, fast=o_w is not None):
+                if x.shape[3] == 3:
+                    dw, _ = ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=False, dw_out=o_w)
+                else:
+                    dw, _ = ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=False, dw_out=o_w)
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3x3_dgrad(dz, wpd, tuple(x.shape), ctx.stride)
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 

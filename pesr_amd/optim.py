@@ -119,6 +119,8 @@ class GradBuckets:
     def _launch(self, b: int) -> None:
         lo, hi = self.bounds[b]
         self._launched[b] = True
+        if self.flat.flat_g.is_cuda:
+            PF.join_side_stream(self.flat.flat_g.device)    # weight gradients are produced on the side stream
         self._works.append(dist.all_reduce(self.flat.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self) -> float:
@@ -159,6 +161,8 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure: Optional[Callable] = None):
         from . import ops
         assert closure is None
+        if self.flat.flat_g.is_cuda:
+            PF.join_side_stream(self.flat.flat_g.device)
         self.flat.attach_grads()
         scale = self.buckets.finish()
         g = self.param_groups[0]
