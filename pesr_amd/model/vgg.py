@@ -58,7 +58,8 @@ class VGG(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
 
-    def _features(self, x):
+    def features(self, x):
+        """sub_mean -> vgg19.features[:35] of one image batch (reference model/vgg.py:19-22 `_forward`)."""
         h = self.sub_mean(x)
         mods = list(self.vgg)
         prev_relu = False
@@ -78,7 +79,7 @@ class VGG(nn.Module):
         return h
 
     def forward(self, sr, hr):
-        vgg_sr = self._features(sr)
+        vgg_sr = self.features(sr)
         with torch.no_grad():
-            vgg_hr = self._features(hr.detach())
+            vgg_hr = self.features(hr.detach())
         return vgg_sr, vgg_hr
