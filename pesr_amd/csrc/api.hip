@@ -5,7 +5,8 @@
 #include "../../include/pesr_hip.h"
 
 static inline int pad16(int c) { return (c + 15) / 16 * 16; }
-static inline int pad64(int c) { return (c + 63) / 64 * 64; }
+// "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
+static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
 PESR_API int pesr_abi_version(void) { return 1; }
 

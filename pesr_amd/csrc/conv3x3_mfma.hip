@@ -537,6 +537,9 @@ static int dispatch(ConvArgs& a, int hext, int wext, hipStream_t stream) {
         if (tiles >= 192) return launch_cfg<1, 8, 9, 1, S, (S == 1 ? 2 : 6)>(a, hext, wext, stream);
     }
     if (a.Cout % 64 == 0) return launch_cfg<1, 4, 9, 1, S, (S == 1 ? 4 : 11)>(a, hext, wext, stream);
+    // <= 16 output channels (the C -> 3 layers, zero-padded to 16): 256 pixels x 16 channels per workgroup, the four
+    // waves split the pixels - 4x less padding work than the 64-channel tile
+    if (a.Cout == 16 && S == 1) return launch_cfg<4, 1, 4, 1, 1, 6>(a, hext, wext, stream);
     return PESR_EINVAL;
 }
 

@@ -11,7 +11,7 @@
 #include "common.h"
 #include "launchers.h"
 
-// R (reduction channels) is zero-padded to a multiple of 16 and Nn ("n" channels) to a multiple of 64, so
+// R (reduction channels) is zero-padded to a multiple of 16 and Nn ("n" channels) to 16 (if <= 16) or a multiple of 64, so
 // the 3-channel RGB layers run on the same MFMA kernels.
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode, int ps,
                                     int R, int Nn) {
@@ -42,7 +42,8 @@ __global__ void pack_bias_ps_kernel(const float* __restrict__ b, float* __restri
 
 int pesr_pack_conv3x3_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream) {
     const int R = (((mode == 0 ? I : O) + 15) / 16) * 16;
-    const int Nn = (((mode == 0 ? O : I) + 63) / 64) * 64;
+    const int Nr = mode == 0 ? O : I;
+    const int Nn = Nr <= 16 ? 16 : ((Nr + 63) / 64) * 64;
     if (ps && (O % 64 || I % 16)) return PESR_EINVAL;
     const long total = 9L * R * Nn;
     const int block = 256;

@@ -79,7 +79,8 @@ def pack_conv3x3(w: torch.Tensor, mode: int, ps: bool = False) -> torch.Tensor:
     O, I = w.shape[0], w.shape[1]
     assert w.shape[2:] == (3, 3)
     R, Nn = (I, O) if mode == 0 else (O, I)
-    out = torch.empty(9 * ((R + 15) // 16 * 16) * ((Nn + 63) // 64 * 64), dtype=torch.float32, device=w.device)
+    nn_pad = 16 if Nn <= 16 else (Nn + 63) // 64 * 64
+    out = torch.empty(9 * ((R + 15) // 16 * 16) * nn_pad, dtype=torch.float32, device=w.device)
     _lib.check(_lib.lib().pesr_pack_conv3x3(_p(w), _p(out), O, I, mode, int(ps), _stream()), "pesr_pack_conv3x3")
     return out
 

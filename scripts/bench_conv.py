@@ -21,6 +21,8 @@ shapes = [  # name, N, H, W, Cin, Cout, stride, ps
     ("VGG 128->128 @96", 16, 96, 96, 128, 128, 1, False),
     ("VGG 512->512 @24", 16, 24, 24, 512, 512, 1, False),
     ("VGG 512->512 @12", 16, 12, 12, 512, 512, 1, False),
+    ("RGB-out 256->3 @192", 16, 192, 192, 256, 3, 1, False),
+    ("RGB-out 64->3 @192", 16, 192, 192, 64, 3, 1, False),
     ("D 64->64 s2 @192", 16, 192, 192, 64, 64, 2, False),
     ("D 256->256 s2 @48", 16, 48, 48, 256, 256, 2, False),
     ("D 512->512 s2 @24", 16, 24, 24, 512, 512, 2, False),
@@ -38,6 +40,8 @@ for name, N, H, W, Cin, Cout, s, ps in shapes:
     flop = 2.0 * N * OH * OW * Cout * Cin * 9
     t = timeit(lambda: ops.conv3x3_fwd(x, wp, bp, Cout, s, ps_out=ps))
     line = f"{name:28s} fwd {t*1e3:8.1f} us {flop/t/1e9:7.1f} TF/s"
+    if Cout == 3:
+        print(line, flush=True); continue
     t = timeit(lambda: ops.conv3x3_dgrad(dy, wpd, (N, H, W, Cin), s, ps_in=ps))
     line += f" | dgrad {t*1e3:8.1f} us {flop/t/1e9:7.1f} TF/s"
     t = timeit(lambda: ops.conv3x3_wgrad(x, dy, s, ps_in=ps))
