@@ -84,9 +84,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ dsum, int C, long 
 }
 
 // second-stage reduce for backward: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat
-__global__ void bn_bwd_sums_kernel(const double* __restrict__ dsum, int C, float* __restrict__ sums) {
+__global__ void bn_bwd_sums_kernel(const double* __restrict__ dsum, int C, float* __restrict__ sums, float* __restrict__ dbeta,
+                                   float* __restrict__ dgamma) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 2 * C) sums[e] = (float)dsum[e];
+    if (e >= 2 * C) return;
+    const float v = (float)dsum[e];
+    sums[e] = v;
+    if (e < C) { if (dbeta) dbeta[e] = v; } else if (dgamma) dgamma[e - C] = v;   // dbeta = sum dz, dgamma = sum dz*xhat
 }
 
 __global__ void bn_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
@@ -195,15 +199,10 @@ int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma
                        sn, sc, sp, HW);
     int rc0 = pesr_reduce_rows_launch(part, dsum, (int)nb, 2 * C, stream);
     if (rc0) return rc0;
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const double*)dsum, C, sums);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const double*)dsum, C, sums, dbeta, dgamma);
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, dy, mean_invstd, gamma, beta, (const float*)sums,
                        (f32x4*)dx, M, C, slope, HW, sn, sc, sp);
-    int rc = pesr_launch_status();
-    if (rc) return rc;
-    // dbeta = sum dz, dgamma = sum dz*xhat : copy out of `sums` (device-to-device, async)
-    if (dbeta) (void)hipMemcpyAsync(dbeta, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, stream);
-    if (dgamma) (void)hipMemcpyAsync(dgamma, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, stream);
     return pesr_launch_status();
 }

@@ -219,11 +219,24 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
             }
 }
 
-// dw[o][i][t] = alpha * sum_s slab[s][t][p][i]   (p = packed channel of o when ps)
+// dw[o][i][t] = alpha * sum_s slab[s][t][p][i]   (p = packed channel of o when ps).
+// The fused bias gradient rides along: db[o] = alpha * sum_rows bias_part[row][p] (fixed order, double) for the first
+// Cout threads of the grid.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int split, int Cout, int Cin,
-                                    float alpha, int ps) {
+                                    float alpha, int ps, const float* __restrict__ bias_part, int bias_rows,
+                                    float* __restrict__ db) {
     const long total = 9L * Cout * Cin;
     const int C = Cout >> 2;
+    if (bias_part) {
+        const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (p < Cout) {
+            double s = 0.0;
+            for (int k = 0; k < bias_rows; ++k) s += (double)bias_part[(size_t)k * Cout + p];
+            int o = (int)p;
+            if (ps) { const int sub = (int)p / C, cc = (int)p - sub * C; o = 4 * cc + sub; }
+            db[o] = alpha * (float)s;
+        }
+    }
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < split; ++k) s += slab[(size_t)k * total + e];
@@ -290,15 +303,6 @@ __global__ void colsum_final_kernel(const double* __restrict__ dsum, float* __re
     int o = col;
     if (ps) { const int Cq = C >> 1; const int sj = col / Cq, cc = col - sj * Cq; o = 4 * cc + 2 * si + sj; }
     db[o] = alpha * (float)dsum[e];
-}
-
-// db[o] = alpha * dsum[p]; p = packed channel of o when the conv output was pixel-shuffled
-__global__ void bias_from_wgrad_kernel(const double* __restrict__ dsum, float* __restrict__ db, int Cout, float alpha, int ps) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= Cout) return;
-    int o = p;
-    if (ps) { const int C = Cout >> 2; const int sub = p / C, cc = p - sub * C; o = 4 * cc + sub; }
-    db[o] = alpha * (float)dsum[p];
 }
 
 int pesr_bias_grad_launch(const float* dy, float* db, long pixels, int Cout, int OW, float alpha, int ps_in, float* part,
@@ -397,7 +401,6 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     const size_t bias_rows = (size_t)p.split * p.ci_tiles;
     const size_t bias_need = (size_t)Cout * sizeof(double) + bias_rows * Cout * sizeof(float) + 256;
     const bool fuse_bias = db != nullptr && ws_bytes - p.slab_bytes >= bias_need;
-    double* bias_dsum = (double*)((char*)ws + p.slab_bytes);
     a.bias_part = fuse_bias ? (float*)((char*)ws + p.slab_bytes + (((size_t)Cout * sizeof(double) + 255) / 256) * 256) : nullptr;
     int rc;
 #define PESR_WG(S_, TWO_, R_) (p.cow == 4 ? launch_wgrad<4, S_, TWO_, R_>(a, p.split, stream) : launch_wgrad<2, S_, TWO_, R_>(a, p.split, stream))
@@ -407,15 +410,10 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     if (rc) return rc;
     const long total = 9L * Cout * Cin;
     const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in,
+                       fuse_bias ? (const float*)a.bias_part : (const float*)nullptr, (int)bias_rows, db);
     rc = pesr_launch_status();
-    if (rc || !db) return rc;
-    if (fuse_bias) {
-        rc = pesr_reduce_rows_launch(a.bias_part, bias_dsum, (int)bias_rows, Cout, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(bias_from_wgrad_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, (const double*)bias_dsum, db, Cout, alpha, ps_in);
-        return pesr_launch_status();
-    }
+    if (rc || !db || fuse_bias) return rc;
     float* part = (float*)((char*)ws + p.slab_bytes);
     return pesr_bias_grad_launch(dy, db, (long)N * a.OH * a.OW, Cout, a.OW, alpha, ps_in, part, ws_bytes - p.slab_bytes, stream);
 }
