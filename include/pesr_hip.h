@@ -38,6 +38,9 @@ int pesr_abi_version(void);
  * ps=1: output channels ordered sub-pixel-major for a conv feeding nn.PixelShuffle(2)
  * (reference model/basic.py:56-59). w is OIHW [O][I][3][3]. */
 int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream);
+/* many packs in one launch: desc is a DEVICE array of `count` rows of 8 int64 {w ptr, out ptr, O, I, mode, ps, R, Nn}
+ * with R = ceil16(reduction channels), Nn = 16 if n-channels <= 16 else ceil64 (the sizes pesr_pack_conv3x3 derives itself) */
+int pesr_pack_conv3x3_batched(const long long* desc, int count, void* stream);
 int pesr_pack_bias_ps(const float* b, float* out, int O, void* stream);
 
 /* ---- 3x3 conv, pad 1 (reference model/basic.py:4-7 `Conv`; ATen conv2d / convolution_backward) */

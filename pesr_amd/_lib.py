@@ -18,6 +18,7 @@ _P = c_void_p  # every device pointer / stream crosses the ABI as void*
 SIGNATURES = {
     "pesr_abi_version": (c_int, []),
     "pesr_pack_conv3x3": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pesr_pack_conv3x3_batched": (c_int, [_P, c_int, _P]),
     "pesr_pack_bias_ps": (c_int, [_P, _P, c_int, _P]),
     "pesr_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pesr_conv3x3_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,

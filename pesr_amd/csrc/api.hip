@@ -13,6 +13,9 @@ PESR_API int pesr_abi_version(void) { return 1; }
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
 }
+PESR_API int pesr_pack_conv3x3_batched(const long long* desc, int count, void* stream) {
+    return pesr_pack_conv3x3_batched_launch(desc, count, (hipStream_t)stream);
+}
 PESR_API int pesr_pack_bias_ps(const float* b, float* out, int O, void* stream) {
     return pesr_pack_bias_ps_launch(b, out, O, (hipStream_t)stream);
 }

@@ -4,6 +4,7 @@
 #include <stddef.h>
 
 int pesr_pack_conv3x3_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream);
+int pesr_pack_conv3x3_batched_launch(const long long* desc, int count, hipStream_t stream);
 int pesr_pack_bias_ps_launch(const float* b, float* out, int O, hipStream_t stream);
 
 int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,

@@ -31,6 +31,35 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// Batched form: one launch packs many convs (all of a network's, right after its optimizer step).  desc[d] (8 int64):
+// {src ptr, dst ptr, O, I, mode, ps, R, Nn}; blockIdx.y = d.
+__global__ void pack_conv3x3_batched_kernel(const long long* __restrict__ desc) {
+    const long long* d = desc + (size_t)blockIdx.y * 8;
+    const float* __restrict__ w = (const float*)d[0];
+    float* __restrict__ out = (float*)d[1];
+    const int O = (int)d[2], I = (int)d[3], mode = (int)d[4], ps = (int)d[5], R = (int)d[6], Nn = (int)d[7];
+    const long total = 9L * R * Nn;
+    const int C = O >> 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(e & 15);
+        long rest = e >> 4;
+        const int n = (int)(rest % Nn); rest /= Nn;
+        const int c = (int)(rest % (R >> 4));
+        const int t = (int)(rest / (R >> 4));
+        const int red = c * 16 + k;
+        int o = mode == 0 ? n : red;
+        const int i = mode == 0 ? red : n;
+        if (ps) { const int sub = o / C, cc = o - sub * C; o = 4 * cc + sub; }
+        out[e] = (o < O && i < I) ? w[((long)o * I + i) * 9 + t] : 0.f;
+    }
+}
+
+int pesr_pack_conv3x3_batched_launch(const long long* desc, int count, hipStream_t stream) {
+    if (count < 1) return PESR_OK;
+    hipLaunchKernelGGL(pack_conv3x3_batched_kernel, dim3(128, (unsigned)count), dim3(256), 0, stream, desc);
+    return pesr_launch_status();
+}
+
 // permute a bias vector into the packed (pixel-shuffle) channel order
 __global__ void pack_bias_ps_kernel(const float* __restrict__ b, float* __restrict__ out, int O) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -54,19 +54,31 @@ def grad_out(param):
     return e[0]()
 
 
+_ALL_PACKS = []   # weak registry of every PackedConvWeights (for the batched repack after an optimizer step)
+
+
 class PackedConvWeights:
     """Per-parameter cache of the kernel-side weight layouts (forward / dgrad packing, PS-permuted bias)."""
 
     def __init__(self, ps: bool = False):
+        import weakref
         self.ps = ps
         self._fwd = self._dgrad = self._bias = None
         self._kf = self._kd = self._kb = None
+        self._wref = None            # weakref to the weight parameter once it has been seen
+        _ALL_PACKS.append(weakref.ref(self))
 
     @staticmethod
     def _key(t: torch.Tensor):
         return (t.data_ptr(), t._version, _PARAM_EPOCH.get(id(t), 0))
 
+    def _note(self, w):
+        if self._wref is None or self._wref() is not w:
+            import weakref
+            self._wref = weakref.ref(w)
+
     def fwd(self, w: torch.Tensor) -> torch.Tensor:
+        self._note(w)
         k = self._key(w)
         if self._kf != k:
             self._fwd = ops.pack_conv3x3(w.detach(), 0, self.ps)
@@ -74,6 +86,7 @@ class PackedConvWeights:
         return self._fwd
 
     def dgrad(self, w: torch.Tensor) -> torch.Tensor:
+        self._note(w)
         k = self._key(w)
         if self._kd != k:
             self._dgrad = ops.pack_conv3x3(w.detach(), 1, self.ps)
@@ -154,6 +167,48 @@ class _OnSide:
             self.ctx.__exit__(*a)
             if not self.fast:
                 torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
+_REPACK_TABLES = {}
+
+
+def repack_all(params) -> None:
+    """Refresh, in ONE kernel launch, every packed layout that already exists for the given parameters (called by
+    FlatAdam.step right after its Adam kernel, instead of ~2 small pack launches per conv on the next forward/backward)."""
+    import numpy as np
+    ids = {id(p) for p in params}
+    jobs = []
+    for ref in list(_ALL_PACKS):
+        c = ref()
+        if c is None:
+            _ALL_PACKS.remove(ref)
+            continue
+        w = c._wref() if c._wref is not None else None
+        if w is None or id(w) not in ids or not w.is_cuda:
+            continue
+        O, I = w.shape[0], w.shape[1]
+        for mode, buf in ((0, c._fwd), (1, c._dgrad)):
+            if buf is None:
+                continue
+            R, Nn = (I, O) if mode == 0 else (O, I)
+            jobs.append((c, mode, (w.data_ptr(), buf.data_ptr(), O, I, mode, int(c.ps), (R + 15) // 16 * 16, 16 if Nn <= 16 else (Nn + 63) // 64 * 64)))
+    if not jobs:
+        return
+    dev = jobs[0][0]._wref().device
+    key = (tuple(sorted(ids)), tuple(j[2] for j in jobs))
+    table = _REPACK_TABLES.get(key)
+    if table is None:
+        _REPACK_TABLES.clear()
+        table = _REPACK_TABLES[key] = torch.from_numpy(np.array([j[2] for j in jobs], dtype=np.int64)).to(dev)
+    from . import _lib
+    _lib.check(_lib.lib().pesr_pack_conv3x3_batched(table.data_ptr(), len(jobs), torch.cuda.current_stream(dev).cuda_stream),
+               "pesr_pack_conv3x3_batched")
+    for c, mode, _ in jobs:
+        k = PackedConvWeights._key(c._wref())
+        if mode == 0:
+            c._kf = k
+        else:
+            c._kd = k
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:

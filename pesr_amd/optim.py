@@ -169,4 +169,5 @@ class FlatAdam(torch.optim.Optimizer):
         self.steps += 1
         ops.adam_step(self.flat.flat_p, self.flat.flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],
                       g["betas"][1], g["eps"], self.steps, scale)
-        PF.bump_weight_epoch(self.flat.params)   # this optimizer's packed conv weights are now stale
+        PF.bump_weight_epoch(self.flat.params)   # this optimizer's packed conv weights are now stale ...
+        PF.repack_all(self.flat.params)          # ... and are refreshed here in one batched launch
