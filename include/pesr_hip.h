@@ -141,6 +141,12 @@ int pesr_mse_fwd_bwd(const float* a, const float* b, float* grad, float* out1, l
  * transpose, applied transpose -> vflip -> hflip as the reference).  out: [B][3][P][P] fp32 (nhwc = 0) or [B][P][P][3]. */
 int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, void* stream);
 
+/* ---- validation PSNR on the Y channel (reference utils.py:32-41 compute_PSNR), one image pair [1][3][H][W] ------- */
+/* a_nhwc / b_nhwc: the tensor is stored [H][W][3] instead of [3][H][W].  out2 (device doubles): {mse, psnr dB}; all
+ * arithmetic in double on integer-valued terms -> bit-identical to the reference's numpy path.  workspace >= 2 KiB. */
+int pesr_psnr_y(const float* a, const float* b, double* out2, int H, int W, int a_nhwc, int b_nhwc, void* workspace,
+                size_t ws_bytes, void* stream);
+
 /* ---- fused Adam on one flat buffer (reference train.py:124-125; torch.optim.Adam) ---------------- */
 /* g is multiplied by grad_scale first (1/world_size after a sum all-reduce). step is 1-based. */
 int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

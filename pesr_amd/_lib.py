@@ -53,6 +53,7 @@ SIGNATURES.update({
     "pesr_loss_l1_tv_fwd_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "pesr_mse_fwd_bwd": (c_int, [_P, _P, _P, _P, c_long, c_float, _P, c_size_t, _P]),
     "pesr_crop_augment": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "pesr_psnr_y": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "pesr_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
 })
 

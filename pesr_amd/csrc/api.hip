@@ -140,3 +140,8 @@ PESR_API int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* b
 PESR_API int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, void* stream) {
     return pesr_crop_augment_launch(pool, desc, out, B, P, nhwc, (hipStream_t)stream);
 }
+
+PESR_API int pesr_psnr_y(const float* a, const float* b, double* out2, int H, int W, int a_nhwc, int b_nhwc, void* workspace,
+                         size_t ws_bytes, void* stream) {
+    return pesr_psnr_y_launch(a, b, out2, H, W, a_nhwc, b_nhwc, workspace, ws_bytes, (hipStream_t)stream);
+}

@@ -61,3 +61,6 @@ int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, f
                             float slope, hipStream_t stream);
 
 int pesr_crop_augment_launch(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, hipStream_t stream);
+
+int pesr_psnr_y_launch(const float* a, const float* b, double* out2, int H, int W, int a_nhwc, int b_nhwc, void* ws, size_t ws_bytes,
+                       hipStream_t stream);

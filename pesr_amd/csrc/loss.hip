@@ -85,3 +85,50 @@ int pesr_loss_mse_launch(const float* a, const float* b, float* grad, float* out
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)dsum, out1, 1.0 / (double)n);
     return pesr_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Validation PSNR on the device (reference utils.py:10-18,32-41): both images are clipped to 0..255 and rounded to
+// uint8 values, converted to the BT.601 luma y = (65.738 r + 129.057 g + 25.064 b)/256 + 16 in DOUBLE (as numpy does),
+// clipped and rounded again, and the squared differences are summed.  Every term is an integer-valued double, so the sum
+// is exact whatever its order: the result is bit-identical to the host computation.
+// Element (n = 0, c, y, x) of a logical NCHW tensor lives at c*sc + (y*W + x)*sp.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double luma_u8(const float* p, long sc) {
+    const double r = rint(fmin(fmax((double)p[0], 0.0), 255.0));
+    const double g = rint(fmin(fmax((double)p[sc], 0.0), 255.0));
+    const double b = rint(fmin(fmax((double)p[2 * sc], 0.0), 255.0));
+    const double y = ((r * (65.738 / 256) + g * (129.057 / 256)) + b * (25.064 / 256)) + 16.0;
+    return rint(fmin(fmax(y, 0.0), 255.0));
+}
+__global__ __launch_bounds__(256) void psnr_y_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ part,
+                                                     long P, long asc, long asp, long bsc, long bsp) {
+    double s = 0.0;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        const double d = luma_u8(a + p * asp, asc) - luma_u8(b + p * bsp, bsc);
+        s += d * d;
+    }
+    __shared__ double red[4];
+    const double w = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ void psnr_final_kernel(const double* __restrict__ part, double* __restrict__ out, int nb, double inv_n) {
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < nb; ++k) s += part[k];
+        const double mse = s * inv_n;
+        out[0] = mse;
+        out[1] = 20.0 * log10(255.0 / sqrt(mse));
+    }
+}
+int pesr_psnr_y_launch(const float* a, const float* b, double* out2, int H, int W, int a_nhwc, int b_nhwc, void* ws, size_t ws_bytes,
+                       hipStream_t stream) {
+    const int nb = 256;
+    if (!ws || ws_bytes < (size_t)nb * sizeof(double)) return PESR_EWORKSPACE;
+    const long P = (long)H * W;
+    hipLaunchKernelGGL(psnr_y_kernel, dim3(nb), dim3(256), 0, stream, a, b, (double*)ws, P, a_nhwc ? 1L : P, a_nhwc ? 3L : 1L,
+                       b_nhwc ? 1L : P, b_nhwc ? 3L : 1L);
+    hipLaunchKernelGGL(psnr_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)ws, out2, nb, 1.0 / (double)P);
+    return pesr_launch_status();
+}

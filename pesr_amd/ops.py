@@ -371,3 +371,25 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
         _chk(t, f"adam_step.{n}")
     rc = _lib.lib().pesr_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream())
     _lib.check(rc, "pesr_adam_step")
+
+
+def psnr_y(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Y-channel PSNR of two [1, 3, H, W] image tensors (NCHW-contiguous or channels_last) -> device double [mse, psnr]."""
+    outs = []
+    for t in (a, b):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4 or t.shape[0] != 1 or t.shape[1] != 3:
+            raise _lib.PesrHipError("psnr_y: expected [1, 3, H, W] float32 GPU tensors")
+        if t.is_contiguous():
+            outs.append((t, 0))
+        elif t.is_contiguous(memory_format=torch.channels_last):
+            outs.append((t, 1))
+        else:
+            outs.append((t.contiguous(), 0))
+    (ta, la), (tb, lb) = outs
+    assert ta.shape == tb.shape
+    H, W = ta.shape[2], ta.shape[3]
+    out = torch.empty(2, dtype=torch.float64, device=ta.device)
+    ws = workspace(4096, ta.device)
+    rc = _lib.lib().pesr_psnr_y(ta.data_ptr(), tb.data_ptr(), out.data_ptr(), H, W, la, lb, ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "pesr_psnr_y")
+    return out

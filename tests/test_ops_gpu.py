@@ -186,3 +186,17 @@ def test_gpu_input_pipeline_bit_exact():
         for b, (i, y, x, aug) in enumerate(picks):
             rl, rh = OI.crop_augment(lrs[i], hrs[i], 12, y, x, aug)
             assert torch.equal(lr[b].cpu(), rl) and torch.equal(hr[b].cpu(), rh), (b, i, y, x, aug)
+
+
+def test_psnr_on_device_bit_identical():
+    """utils.compute_PSNR on GPU tensors (device kernel) == the oracle's numpy restatement of reference utils.py:32-41."""
+    import importlib.util, os
+    from oracle import image as OI
+    spec = importlib.util.spec_from_file_location("entry_utils", os.path.join(os.path.dirname(os.path.dirname(__file__)), "utils.py"))
+    U = importlib.util.module_from_spec(spec); spec.loader.exec_module(U)
+    a = detrand.image_batch((1, 3, 37, 52), 41)
+    b = a + _rand(1, 3, 37, 52, seed=42, lo=-30, hi=30)            # includes values outside 0..255 (clipped)
+    ref = OI.psnr_y(a, b)
+    assert U.compute_PSNR(a.cuda(), b.cuda()) == ref                                                       # NCHW-contiguous
+    assert U.compute_PSNR(a.cuda().contiguous(memory_format=torch.channels_last), b.cuda()) == ref         # mixed layouts
+    assert abs(U.compute_PSNR(a, b) - ref) < 1e-12                                                         # host path

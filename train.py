@@ -194,7 +194,7 @@ def main(argv=None):
             with torch.no_grad():
                 for lr_img, hr_img in val_loader:
                     sr = G(lr_img.to(device))
-                    psnr.append(compute_PSNR(hr_img, sr))
+                    psnr.append(compute_PSNR(hr_img.to(device), sr))
             val_psnr = float(np.mean(psnr)) if psnr else 0.0
             print("Finish valid [%d/%d]. PSNR: %.4fdB" % (epoch, args.num_epochs, val_psnr))
             if tb is not None:

@@ -41,7 +41,12 @@ def normalize(tensors):
 
 
 def compute_PSNR(out, lbl):
-    """PSNR on the rounded Y channel of two [1,3,H,W] tensors (reference utils.py:32-41)."""
+    """PSNR on the rounded Y channel of two [1,3,H,W] tensors (reference utils.py:32-41).  GPU tensors are measured on the
+    device (pesr_amd.ops.psnr_y, bit-identical: integer-valued terms in double); only the scalar comes back."""
+    if torch.is_tensor(out) and torch.is_tensor(lbl) and out.is_cuda and lbl.is_cuda and out.dtype == torch.float32 \
+            and lbl.dtype == torch.float32 and out.dim() == 4 and out.shape[0] == 1 and out.shape == lbl.shape:
+        from pesr_amd import ops
+        return float(ops.psnr_y(out.detach(), lbl.detach())[1])
     o, l = tensors_to_imgs([out, lbl])
     yo = np.clip(rgb2y(o), 0, 255).round()
     yl = np.clip(rgb2y(l), 0, 255).round()
