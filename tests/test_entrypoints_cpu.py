@@ -96,3 +96,36 @@ def test_product_focal_loss_matches_reference_values_and_q4_gradient():
             loss.backward()
             ref = OS.focal_loss_grad_closed_form(x, tt, gamma)
             assert torch.allclose(xr.grad, ref, rtol=1e-5, atol=1e-9)
+
+
+def test_seeded_construction_matches_the_reference_when_it_is_available():
+    """Build container only (skipped where /root/reference does not exist): torch.manual_seed(s) + construction gives
+    bit-identical parameters and the same state_dict key order as the reference's modules."""
+    import subprocess, sys
+    import pytest
+    if not os.path.isdir("/root/reference/model"):
+        pytest.skip("reference not present (GPU box)")
+    code = r'''
+import sys, types, torch
+sys.path.insert(0, %r)
+from model import Generator, Discriminator
+torch.manual_seed(3)
+G = Generator({'depth': 2, 'num_channels': 16, 'res_scale': 0.1}); D = Discriminator({'patch_size': 8, 'spectral_norm': False})
+mine = [(k, v.clone()) for k, v in list(G.state_dict().items()) + list(D.state_dict().items())]
+for k in [k for k in list(sys.modules) if k == 'model' or k.startswith('model.')]:
+    del sys.modules[k]
+sys.path.remove(%r)
+tv, tvm = types.ModuleType('torchvision'), types.ModuleType('torchvision.models')
+tvm.vgg19 = lambda pretrained=False, **k: None; tv.models = tvm
+sys.modules['torchvision'] = tv; sys.modules['torchvision.models'] = tvm
+sys.path.insert(0, '/root/reference')
+import model as R
+torch.manual_seed(3)
+Gr = R.Generator({'depth': 2, 'num_channels': 16, 'res_scale': 0.1}); Dr = R.Discriminator({'patch_size': 8, 'spectral_norm': False})
+ref = list(Gr.state_dict().items()) + list(Dr.state_dict().items())
+assert [k for k, _ in mine] == [k for k, _ in ref]
+assert all(torch.equal(a, b) for (_, a), (_, b) in zip(mine, ref))
+print("identical")
+''' % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "identical" in out.stdout, out.stderr[-2000:]
