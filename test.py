@@ -13,17 +13,24 @@ import torch
 from utils import default_device, imgs_to_tensors, tensors_to_imgs
 
 
+# (flag, type, default, help) - the reference's flags and defaults (reference test.py:15-33)
+_FLAGS = [
+    ("dataset", str, "Set5", "folder under data/origin/test/ with an LR/ sub-folder of PNGs"),
+    ("perceptual_model", str, "check_point/PESR/train/PERC_model.pt", "GAN-phase generator checkpoint"),
+    ("psnr_model", str, "check_point/PESR/pretrain/PSNR_model.pt", "L1-pretrained generator checkpoint (used when alpha != 1)"),
+    ("num_channels", int, 256, "generator width"),
+    ("num_blocks", int, 32, "generator depth (residual blocks)"),
+    ("res_scale", float, 0.1, "residual scaling"),
+    ("alpha", float, 1, "image-space blend: alpha * perceptual + (1 - alpha) * x8-ensembled PSNR output"),
+    ("save_path", str, "results", "output folder"),
+]
+
+
 def build_parser():
-    p = argparse.ArgumentParser(description="SR benchmark")
-    p.add_argument("--dataset", type=str, default="Set5", help="test dataset")
-    p.add_argument("--perceptual_model", type=str, default="check_point/PESR/train/PERC_model.pt")
-    p.add_argument("--psnr_model", type=str, default="check_point/PESR/pretrain/PSNR_model.pt")
-    p.add_argument("--num_channels", type=int, default=256)
-    p.add_argument("--num_blocks", type=int, default=32)
-    p.add_argument("--res_scale", type=float, default=0.1)
-    p.add_argument("--alpha", type=float, default=1, help="PSNR-perceptual tradeoff")
-    p.add_argument("--save_path", type=str, default="results")
-    return p
+    parser = argparse.ArgumentParser(description="x4 super-resolution of a folder of LR images")
+    for name, typ, default, text in _FLAGS:
+        parser.add_argument("--" + name, type=typ, default=default, help=text)
+    return parser
 
 
 # the three generators of the 8-element dihedral group, in the reference's order (test.py:58-60), as tensor ops
