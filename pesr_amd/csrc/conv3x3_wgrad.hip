@@ -9,11 +9,12 @@
 //
 // One workgroup owns a (CO_T = 32*COW) x (CI_T = 64) x 9-tap block of dw in registers (8 waves x 36 or
 // 18 accumulator tiles) and sweeps a contiguous range of output-row segments (TWO pixels each); per
-// segment the 3-row input halo and the dy row segment are staged through registers into LDS (double
-// buffered, one barrier per segment).  Split-K partial blocks go to a workspace slab and a second
-// kernel reduces them in a fixed order (bitwise reproducible, no atomics) into the OIHW parameter
-// layout, applying alpha and the pixel-shuffle channel un-permutation.  Channel counts need only be
-// multiples of 4: tiles that overhang Cin / Cout load zeros and skip their stores.
+// segment the 3-row input halo and the dy row segment travel global -> LDS by LDS-DMA (double buffered,
+// one barrier per segment, no VGPR round trip) into a bank-interleaved image (see below).  Split-K
+// partial blocks go to a workspace slab and a second kernel reduces them in a fixed order (bitwise
+// reproducible, no atomics) into the OIHW parameter layout, applying alpha and the pixel-shuffle channel
+// un-permutation.  The bias gradient (column sums of dy) is accumulated on the VALU from the A fragments.
+// Channel counts need only be multiples of 4: tiles that overhang Cin / Cout load zeros and skip their stores.
 #include "common.h"
 #include "launchers.h"
 
@@ -28,30 +29,46 @@ struct WgradArgs {
     int segs_per_split;
     int co_tiles, ci_tiles;
     int ps_in;
-    float* bias_part;  // [split][ci_tiles][Cout] partial column sums of dy (bias gradient), or null
+    float* bias_part;  // [split][Cout] partial column sums of dy (bias gradient), or null
 };
 
+__device__ __attribute__((aligned(16))) const float g_wg_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // zero padding source for LDS-DMA
+
+__device__ __forceinline__ void wg_dma16(const float* gsrc, float* lds_piece) {
+    // one 1-KiB piece: lane l copies 16 B from its own gsrc to lds_piece + 16*l bytes (the LDS base is wave-uniform)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+
+// Staging is LDS-DMA in 1-KiB pieces (one global_load_lds_dwordx4 per wave per piece), so the LDS image cannot be padded
+// per pixel; instead every piece interleaves its PP pixels at 16-float granularity,
+//     float offset in piece = (group * PP + slot(pixel)) * 16 + channel % 16        (group = channel / 16)
+// which puts the 4 consecutive pixels that the 4 k-slots of a ds_read_b32 fragment touch on 4 different bank groups.
+//   x  : piece = 4 consecutive halo pixels x 64 ci, pieces of a halo row contiguous (row padded to a multiple of 4 pixels)
+//   dy : piece = 256 / CO_T pixels x CO_T co
 // R: output rows per segment (narrow images: a 48-pixel segment is 2 x 24 or 4 x 12 instead of a mostly-empty 1 x 48)
 template <int COW, int S, int TWO, int R>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
-    constexpr int NT = 512;
+    constexpr int NT = 512, NW = 8;
     constexpr int CO_T = 32 * COW;
     constexpr int CI_T = 64;
     constexpr int CW = TWO / R;                     // segment columns
     constexpr int TWX = (CW - 1) * S + 3;           // halo columns
     constexpr int HR = (R - 1) * S + 3;             // halo rows
-    constexpr int XPAD = (S == 1) ? 16 : 8;         // keeps the two pixel rows of a b32 read on different bank halves
-    constexpr int XS = CI_T + XPAD;                 // floats per halo pixel in LDS
-    constexpr int DS = CO_T + 16;                   // floats per dy pixel in LDS
-    constexpr int X_F4 = HR * TWX * (CI_T / 4);     // float4 units of one halo segment
-    constexpr int D_F4 = TWO * (CO_T / 4);
-    constexpr int XL = (X_F4 + NT - 1) / NT;
-    constexpr int DL = (D_F4 + NT - 1) / NT;
-    constexpr int X_FLOATS = HR * TWX * XS;
-    constexpr int BUF_FLOATS = X_FLOATS + TWO * DS;
+    constexpr int XPR = (TWX + 3) / 4;              // x pieces per halo row
+    constexpr int X_PIECES = HR * XPR;
+    constexpr int XSTR = 256 + (S == 2 ? 32 : 0);   // floats between x pieces (stride 2: lanes 2,3 read the next piece -> other bank half)
+    constexpr int PPI = 256 / CO_T;                 // dy pixels per piece: 2 (CO_T 128) or 4 (CO_T 64)
+    constexpr int D_PIECES = TWO / PPI;
+    constexpr int DSTR = 256 + (PPI == 2 ? 32 : 0);
+    constexpr int X_FLOATS = X_PIECES * XSTR;
+    constexpr int BUF_FLOATS = X_FLOATS + D_PIECES * DSTR;
+    constexpr int XK = (X_PIECES + NW - 1) / NW;
+    constexpr int DK = (D_PIECES + NW - 1) / NW;
+    static_assert(CW % 4 == 0 && CW % PPI == 0, "a piece / a k4 step never straddles segment rows");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int ci_tile = wave & 3, co_half = wave >> 2;
 
@@ -71,81 +88,82 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < COW; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xreg[XL], dreg[DL];
-
-    // bias-gradient bookkeeping: thread -> (channel bcol of the co tile, row lane brl of BRL); this workgroup's pixel share
-    constexpr int BRL = NT / CO_T;
-    const int bcol = tid % CO_T, brl = tid / CO_T;
-    int brow0 = 0, brow1 = 0;
-    if (a.bias_part) {
-        if (TWO % a.ci_tiles == 0) { brow0 = cit * (TWO / a.ci_tiles); brow1 = brow0 + TWO / a.ci_tiles; }
-        else if (cit == 0) brow1 = TWO;
-    }
-    float bsum = 0.f;
-
-    // dy channel base for this workgroup's co tile (ps_in: packed channel p = sub*C + cc)
+    // ---- DMA sources: (scalar part per piece and segment) + (one per-lane offset for all pieces) --------------------------
+    // pixel slot inside a piece: identity, or (stride 2, where k-slots step by 2 pixels) the bit swap 0,2,1,3
+    auto slot_of = [](int h) { return S == 1 ? h : ((h >> 1) | ((h & 1) << 1)); };
+    const int x_h = slot_of((lane >> 2) & 3);       // halo pixel of this lane inside an x piece (slot_of is an involution)
+    const int x_ch = ci0 + (lane >> 4) * 16 + (lane & 3) * 4;
+    const int x_lane = x_ch < a.Cin ? x_h * a.Cin + x_ch : -1;                    // < 0: channel tail, always padding
     const int d_C = a.ps_in ? (a.Cout >> 2) : a.Cout;
+    const int d_h = (lane >> 2) % PPI;              // dy pixel of this lane inside a piece
+    const int d_ch = co0 + ((lane >> 2) / PPI) * 16 + (lane & 3) * 4;
+    int d_lane = -1;
+    if (d_ch < a.Cout) {
+        if (a.ps_in) {   // packed channel p = sub*Cq + cc lives at shuffled pixel (2oy + sub/2, 2ox + sub%2), channel cc
+            const int sub = d_ch / d_C, cc = d_ch - sub * d_C;
+            d_lane = ((sub >> 1) * (2 * a.OW) + 2 * d_h + (sub & 1)) * d_C + cc;
+        } else
+            d_lane = d_h * a.Cout + d_ch;
+    }
+    const int d_rowstep = a.ps_in ? 4 * a.OW * d_C : a.OW * a.Cout;               // one output row / one output pixel of dy,
+    const int d_pixstep = a.ps_in ? 2 * d_C : a.Cout;                             // in floats
 
-    auto load_seg = [&](int seg) {
+    // One segment's DMA is XK + DK pieces per wave, issued as one burst at the top of the previous segment.  (Spreading
+    // the pieces over the k4 steps, or staggering the two waves of a SIMD, measured the same or slower: the ~25 us the
+    // staging costs per launch is memory-pipe time, not issue stalls.)  Branch-free inside a piece: an index past the
+    // end re-issues the last piece (same bytes to the same place).
+    struct SegCtx { const float* xseg; const float* dseg; int iy0, ix0, oy0, ox0; };
+    auto seg_ctx = [&](int seg) {
         const int xs = seg % a.segs_x;
         const int rowid = seg / a.segs_x;
         const int oy0 = (rowid % a.row_groups) * R, img = rowid / a.row_groups;
         const int ox0 = xs * CW;
-        const float* xi = a.x + (size_t)img * a.H * a.W * a.Cin;
-#pragma unroll
-        for (int k = 0; k < XL; ++k) {
-            const int e = tid + k * NT;
-            const int q = e % (CI_T / 4);
-            const int pix = e / (CI_T / 4);
-            const int hx = pix % TWX, hy = pix / TWX;
-            const int iy = oy0 * S - 1 + hy, ix = ox0 * S - 1 + hx;
-            const bool ok = (e < X_F4) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci0 + q * 4 < a.Cin;
-            const size_t off = ok ? ((size_t)iy * a.W + ix) * a.Cin + ci0 + q * 4 : 0;
-            f32x4 v = *(const f32x4*)(xi + off);
-            xreg[k] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < DL; ++k) {
-            const int e = tid + k * NT;
-            const int q = e % (CO_T / 4);
-            const int px = e / (CO_T / 4);
-            const int oy = oy0 + px / CW, ox = ox0 + px % CW;
-            const bool ok = (e < D_F4) && oy < a.OH && ox < a.OW && co0 + q * 4 < a.Cout;
-            size_t off = 0;
-            if (ok) {
-                if (a.ps_in) {  // packed channel p = sub*Cq + cc lives at shuffled pixel (2oy + sub/2, 2ox + sub%2), channel cc
-                    const int pch = co0 + q * 4;
-                    const int sub = pch / d_C, cc = pch - sub * d_C;
-                    off = (((size_t)img * (2 * a.OH) + 2 * oy + (sub >> 1)) * (2 * a.OW) + 2 * ox + (sub & 1)) * d_C + cc;
-                } else
-                    off = (((size_t)img * a.OH + oy) * a.OW + ox) * a.Cout + co0 + q * 4;
-            }
-            f32x4 v = *(const f32x4*)(a.dy + off);
-            dreg[k] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        SegCtx c;
+        c.oy0 = oy0; c.ox0 = ox0; c.iy0 = oy0 * S - 1; c.ix0 = ox0 * S - 1;
+        c.xseg = a.x + (((long)img * a.H + c.iy0) * a.W + c.ix0) * a.Cin;    // dereferenced only where valid
+        c.dseg = a.dy + (long)img * a.OH * d_rowstep + (long)oy0 * d_rowstep + (long)ox0 * d_pixstep;
+        return c;
+    };
+    auto dma_piece = [&](const SegCtx& c, int q, float* buf) {
+        if (q < XK) {
+            int j = wave + q * NW;
+            if (X_PIECES % NW != 0 && j > X_PIECES - 1) j = X_PIECES - 1;
+            const int rowj = j / XPR, col0 = (j % XPR) * 4;
+            const int iy = c.iy0 + rowj, ix = c.ix0 + col0 + x_h;
+            const bool ok = x_lane >= 0 && col0 + x_h < TWX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const float* src = c.xseg + (rowj * a.W + col0) * a.Cin + x_lane;
+            wg_dma16(ok ? src : g_wg_zero16, buf + j * XSTR);
+        } else {
+            int j = wave + (q - XK) * NW;
+            if (D_PIECES % NW != 0 && j > D_PIECES - 1) j = D_PIECES - 1;
+            const int py = (j * PPI) / CW, px0 = (j * PPI) % CW;
+            const bool ok = d_lane >= 0 && c.oy0 + py < a.OH && c.ox0 + px0 + d_h < a.OW;
+            const float* src = c.dseg + py * d_rowstep + px0 * d_pixstep + d_lane;
+            wg_dma16(ok ? src : g_wg_zero16, buf + X_FLOATS + j * DSTR);
         }
     };
-    auto store_seg = [&](float* buf) {
+    constexpr int NPIECE = XK + DK;
+
+    // ---- fragment addresses ------------------------------------------------------------------------------------------
+    // A (dy): pixel 4*k4 + g, channels (co_half*COW + i)*16 + r;   B (x): halo pixel (row, hx = pxx*S + tx), channels ci_tile*16 + r
+    const int a_lane = X_FLOATS + (PPI == 2 ? (g >> 1) * DSTR + (g & 1) * 16 : g * 16) + co_half * COW * PPI * 16 + r;
+    int b_lane[3];
 #pragma unroll
-        for (int k = 0; k < XL; ++k) {
-            const int e = tid + k * NT;
-            if (X_F4 % NT == 0 || e < X_F4) {
-                const int q = e % (CI_T / 4), pix = e / (CI_T / 4);
-                *(f32x4*)(buf + pix * XS + q * 4) = xreg[k];
-            }
-        }
+    for (int tx = 0; tx < 3; ++tx) {
+        const int hx = g * S + tx;
+        b_lane[tx] = (hx >> 2) * XSTR + (ci_tile * 4 + slot_of(hx & 3)) * 16 + r;
+    }
+
+    // bias gradient for free: the A fragments ARE dy, so every wave adds them up on the VALU under its MFMAs (lane (r, g)
+    // covers the pixels 4*k4 + g of every segment for channel (co_half*COW + i)*16 + r); one wave per co half publishes
+    float bsum[COW];
 #pragma unroll
-        for (int k = 0; k < DL; ++k) {
-            const int e = tid + k * NT;
-            if (D_F4 % NT == 0 || e < D_F4) {
-                const int q = e % (CO_T / 4), px = e / (CO_T / 4);
-                *(f32x4*)(buf + X_FLOATS + px * DS + q * 4) = dreg[k];
-            }
-        }
-    };
+    for (int i = 0; i < COW; ++i) bsum[i] = 0.f;
 
     if (seg_begin < seg_end) {
-        load_seg(seg_begin);
-        store_seg(lds);
+        const SegCtx c0 = seg_ctx(seg_begin);
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) dma_piece(c0, q, lds);
     }
     __syncthreads();
 
@@ -153,26 +171,29 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
     for (int seg = seg_begin; seg < seg_end; ++seg) {
         const int par = (seg - seg_begin) & 1;
         const float* buf = lds + par * BUF_FLOATS;
-        float* nbuf = lds + (par ^ 1) * BUF_FLOATS;
-        const bool more = seg + 1 < seg_end;
-        if (more) load_seg(seg + 1);
+        float* const nbuf = lds + (par ^ 1) * BUF_FLOATS;
+        if (seg + 1 < seg_end) {   // lands under this segment's MFMAs
+            const SegCtx cn = seg_ctx(seg + 1);
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q) dma_piece(cn, q, nbuf);
+        }
 
-        const float* xb = buf + ci_tile * 16 + r;
-        const float* db = buf + X_FLOATS + (co_half * COW) * 16 + r;
-        // fragments double-buffered across the k4 steps: the 4 + 9 ds_read_b32 of step k+1 are issued before the 36
+        // fragments double-buffered across the k4 steps: the COW + 9 ds_read_b32 of step k+1 are issued before the 36
         // MFMAs of step k, so their latency hides under the matrix pipe instead of stalling in front of every MFMA group
         float av0[COW], bv0[9], av1[COW], bv1[9];
 #define PESR_WG_READ(AV, BV, K4)                                                                        \
         {                                                                                              \
-            const int px_ = (K4) * 4 + g;                                                              \
-            _Pragma("unroll") for (int i = 0; i < COW; ++i) AV[i] = db[px_ * DS + i * 16];             \
+            const int p0_ = (K4) * 4, py_ = p0_ / CW, c0_ = (p0_ % CW) * S;                            \
+            _Pragma("unroll") for (int i = 0; i < COW; ++i)                                            \
+                AV[i] = buf[a_lane + (p0_ / PPI) * DSTR + i * PPI * 16];                               \
             _Pragma("unroll") for (int t = 0; t < 9; ++t)                                              \
-                BV[t] = xb[(((px_ / CW) * S + t / 3) * TWX + (px_ % CW) * S + (t % 3)) * XS];          \
+                BV[t] = buf[b_lane[t % 3] + ((py_ * S + t / 3) * XPR + c0_ / 4) * XSTR];               \
         }
 #define PESR_WG_MFMA(AV, BV)                                                                            \
         _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                  \
             _Pragma("unroll") for (int i = 0; i < COW; ++i)                                            \
-                acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[i], BV[t], acc[t][i], 0, 0, 0);
+                acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[i], BV[t], acc[t][i], 0, 0, 0);         \
+        _Pragma("unroll") for (int i = 0; i < COW; ++i) bsum[i] += AV[i];
         PESR_WG_READ(av0, bv0, 0)
 #pragma unroll
         for (int k4 = 0; k4 < TWO / 4; k4 += 2) {
@@ -183,27 +204,18 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
         }
 #undef PESR_WG_READ
 #undef PESR_WG_MFMA
-        if (a.bias_part) {
-            // bias gradient for free: the dy rows of this segment are in LDS; the ci-tile workgroups that share them
-            // split its pixels among themselves (balanced), each thread sums one channel over its rows
-            const float* dcol = buf + X_FLOATS + bcol;
-#pragma unroll 4
-            for (int px = brow0 + brl; px < brow1; px += BRL) bsum += dcol[px * DS];
-        }
-        if (more) store_seg(nbuf);
-        __syncthreads();
+        __syncthreads();   // retires the DMA of segment seg+1 (vmcnt) and this segment's LDS reads
     }
 
-    if (a.bias_part) {   // combine the BRL row lanes through LDS (the staging buffers are free now), fixed order
+    if (a.bias_part && cit == 0) {   // combine the 4 k-slot lane groups through LDS (the staging buffers are free now), fixed order
         float* red = lds;
-        red[brl * CO_T + bcol] = bsum;
-        __syncthreads();
-        if (brl == 0 && co0 + bcol < a.Cout) {
-            float t_ = red[bcol];
+        if (ci_tile == 0) {
 #pragma unroll
-            for (int k = 1; k < BRL; ++k) t_ += red[k * CO_T + bcol];
-            a.bias_part[((size_t)sp * a.ci_tiles + cit) * a.Cout + co0 + bcol] = t_;
+            for (int i = 0; i < COW; ++i) red[g * CO_T + (co_half * COW + i) * 16 + r] = bsum[i];
         }
+        __syncthreads();
+        if (tid < CO_T && co0 + tid < a.Cout)
+            a.bias_part[(size_t)sp * a.Cout + co0 + tid] = ((red[tid] + red[CO_T + tid]) + red[2 * CO_T + tid]) + red[3 * CO_T + tid];
     }
     // slab[sp][t][co][ci]: D tile row = co (= (lane>>4)*4 + reg), col = ci (= lane&15)
     float* out = a.slab + (size_t)sp * 9 * a.Cout * a.Cin;
@@ -218,6 +230,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
                 if (co < a.Cout && ci < a.Cin) out[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[t][i][jj];
             }
 }
+
 
 // dw[o][i][t] = alpha * sum_s slab[s][t][p][i]   (p = packed channel of o when ps).
 // The fused bias gradient rides along: db[o] = alpha * sum_rows bias_part[row][p] (fixed order, double) for the first
@@ -237,16 +250,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
             db[o] = alpha * (float)s;
         }
     }
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < split; ++k) s += slab[(size_t)k * total + e];
-        const int ci = (int)(e % Cin);
-        long rest = e / Cin;
+    // one thread = 4 consecutive ci of one (tap, co): `split` independent 16-B loads, 8 in flight, summed in slab order
+    const long total4 = total >> 2;
+    const f32x4* slab4 = (const f32x4*)slab;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= split; k += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab4[(size_t)(k + u) * total4 + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < split; ++k) s += slab4[(size_t)k * total4 + e];
+        const int ci = (int)((e * 4) % Cin);
+        long rest = (e * 4) / Cin;
         const int p = (int)(rest % Cout);
         const int t = (int)(rest / Cout);
         int o = p;
         if (ps) { const int sub = p / C, cc = p - sub * C; o = 4 * cc + sub; }
-        dw[((size_t)o * Cin + ci) * 9 + t] = alpha * s;
+        float* d = dw + ((size_t)o * Cin + ci) * 9 + t;
+        d[0] = alpha * s.x; d[9] = alpha * s.y; d[18] = alpha * s.z; d[27] = alpha * s.w;
     }
 }
 
@@ -363,9 +388,10 @@ template <int COW, int S, int TWO, int R>
 static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
     constexpr int TWX = (TWO / R - 1) * S + 3;
     constexpr int HR = (R - 1) * S + 3;
-    constexpr int XS = 64 + (S == 1 ? 16 : 8);
-    constexpr int DS = 32 * COW + 16;
-    constexpr size_t lds = 2 * (size_t)(HR * TWX * XS + TWO * DS) * sizeof(float);
+    constexpr int X_FLOATS = HR * ((TWX + 3) / 4) * (256 + (S == 2 ? 32 : 0));
+    constexpr int PPI = 256 / (32 * COW);
+    constexpr int D_FLOATS = (TWO / PPI) * (256 + (PPI == 2 ? 32 : 0));
+    constexpr size_t lds = 2 * (size_t)(X_FLOATS + D_FLOATS) * sizeof(float);
     static_assert(lds <= 160 * 1024, "wgrad LDS budget");
     auto kern = conv3x3_wgrad_kernel<COW, S, TWO, R>;
     static bool attr_set = false;
@@ -397,8 +423,8 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
     a.segs_x = p.segs_x; a.row_groups = p.row_groups; a.total_segs = p.total_segs; a.segs_per_split = p.segs_per_split;
     a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.ps_in = ps_in;
-    // bias gradient fused into the wgrad kernel: partials [split*ci_tiles][Cout] (+ Cout doubles) behind the slab
-    const size_t bias_rows = (size_t)p.split * p.ci_tiles;
+    // bias gradient fused into the wgrad kernel: partials [split][Cout] (+ Cout doubles) behind the slab
+    const size_t bias_rows = (size_t)p.split;
     const size_t bias_need = (size_t)Cout * sizeof(double) + bias_rows * Cout * sizeof(float) + 256;
     const bool fuse_bias = db != nullptr && ws_bytes - p.slab_bytes >= bias_need;
     a.bias_part = fuse_bias ? (float*)((char*)ws + p.slab_bytes + (((size_t)Cout * sizeof(double) + 255) / 256) * 256) : nullptr;
@@ -409,7 +435,7 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
 #undef PESR_WG
     if (rc) return rc;
     const long total = 9L * Cout * Cin;
-    const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    const int rgrid = (int)((total / 4 + 255) / 256 < 2048 ? (total / 4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in,
                        fuse_bias ? (const float*)a.bias_part : (const float*)nullptr, (int)bias_rows, db);
     rc = pesr_launch_status();

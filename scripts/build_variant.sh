@@ -1,0 +1,11 @@
+#!/bin/bash
+# build_variant.sh <name> <file.hip> [-DFLAG ...]: recompile ONE kernel file with extra flags and link it with the
+# objects of the regular build into exp/lib<name>.so (for scripts/ab_variants.py same-session A/B runs).
+set -e
+cd "$(dirname "$0")/.."
+name=$1; src=$2; shift 2
+mkdir -p exp
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fvisibility=hidden -Wno-unused-result "$@" -c pesr_amd/csrc/$src -o exp/$name.$src.o
+objs=$(ls pesr_amd/build/*.o | grep -v "/$src.o")
+hipcc -shared --offload-arch=gfx950 -fPIC -o exp/lib$name.so $objs exp/$name.$src.o
+echo exp/lib$name.so
