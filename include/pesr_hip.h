@@ -75,6 +75,10 @@ int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, in
 int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
                          float slope, void* stream);
 
+/* Input gradient of a C -> 3 conv (stride 1): reference Upsampler's last conv (model/basic.py:60), i.e. ATen
+ * convolution_backward(input) for it.  dy [N][H][W][3], w OIHW [3][C][3][3] (NOT packed), dx [N][H][W][C]. */
+int pesr_conv3x3_rgb_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, void* stream);
+
 /* Weight gradient of the RGB-boundary convs (one operand has 3 channels): reference `embed`
  * (model/pesr.py:23), Discriminator features.0 (model/pesr.py:53), Upsampler's last conv (model/basic.py:60).
  * a: the C-channel tensor [N][H][W][C], b3: the 3-channel tensor [N][H][W][3].

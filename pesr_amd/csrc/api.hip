@@ -137,6 +137,10 @@ PESR_API int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* b
     return pesr_conv_rgb_in_launch(x, w, bias, y, N, H, W, Cout, act, slope, (hipStream_t)stream);
 }
 
+PESR_API int pesr_conv3x3_rgb_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, void* stream) {
+    return pesr_conv_rgb_out_dgrad_launch(dy, w, dx, N, H, W, C, (hipStream_t)stream);
+}
+
 PESR_API int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, void* stream) {
     return pesr_crop_augment_launch(pool, desc, out, B, P, nhwc, (hipStream_t)stream);
 }

@@ -1,78 +1,108 @@
-// Forward 3x3 conv (pad 1, stride 1) from a 3-channel input: reference `embed` (model/pesr.py:23),
-// Discriminator features.0.0 (model/pesr.py:53) and vgg19 features.0 (model/vgg.py:8).  K = 27 only, so this
-// is HBM-bound on writing the C-channel output (151 MB for C = 64 at 16 x 192 x 192); the zero-padded MFMA
-// path spends 5x the time on padding.  One thread owns 4 consecutive output channels (108 weights in VGPRs,
-// loaded once) and walks pixels; the 16 (C/4) threads of a pixel share its 27 input values through L1.
+// 3x3 conv (pad 1, stride 1) FROM a 3-channel tensor: reference `embed` (model/pesr.py:23), Discriminator
+// features.0.0 (model/pesr.py:53), vgg19 features.0 (model/vgg.py:8) - and, with the weights read transposed and
+// flipped, the input gradient of the C -> 3 conv `upsample.4` (model/basic.py:60), which is the same operation on dy.
+// K = 27 only, so this is HBM-bound on writing the C-channel result (151 MB for C = 64 at 16 x 192 x 192, 604 MB for
+// C = 256); the zero-padded MFMA path spends 5x the time on padding.
+//
+// A workgroup owns an 8 x 32 pixel tile: the 10 x 34 halo goes to LDS once as [pixel][R, G, B, 0]; one thread owns 4
+// consecutive output channels (108 weights in VGPRs, loaded once per kernel) and walks the tile's pixels, taking each
+// tap's RGB with ONE broadcast ds_read_b128 (all channel groups of a pixel read the same address).  A wave stores
+// 64 consecutive float4 = whole pixels, fully coalesced.
 // Accumulation order per output: bias + taps in (ky, kx, ci) order - a plain fmaf chain.
 #include "common.h"
 #include "launchers.h"
 
-template <int ACT>
+#define RGB_TH 8
+#define RGB_TW 32
+
+// WMODE 0: w is OIHW [C][3][3][3] of this conv.   WMODE 1: w is OIHW [3][C][3][3] of the conv whose input gradient this is.
+template <int ACT, int WMODE>
 __global__ __launch_bounds__(256) void conv_rgb_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int N, int H,
-                                                          int W, int C, float slope) {
-    // w: OIHW [C][3][3][3]
+                                                          int W, int C, float slope, int tiles_x, int tiles_y) {
+    constexpr int HW_ = RGB_TW + 2, HH_ = RGB_TH + 2;
+    __shared__ f32x4 halo[HH_ * HW_];
     const int C4 = C >> 2;
     const int cg = threadIdx.x % C4;                 // channel group (4 channels)
     const int pl = threadIdx.x / C4;                 // pixel lane within the block
-    const int ppb = 256 / C4;                        // pixels per block iteration
+    const int ppb = 256 / C4;                        // pixel lanes
     float wr[4][27];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
-            // k = (ky*3+kx)*3 + ci  <-  OIHW index ((co*3 + ci)*3 + ky)*3 + kx
-            const int ci = k % 3, t = k / 3;
-            wr[q][k] = w[((cg * 4 + q) * 3 + ci) * 9 + t];
+            const int ci = k % 3, t = k / 3, oc = cg * 4 + q;       // k = (ky*3+kx)*3 + ci
+            wr[q][k] = WMODE == 0 ? w[(oc * 3 + ci) * 9 + t] : w[((size_t)ci * C + oc) * 9 + (8 - t)];
         }
     float br[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) br[q] = bias[cg * 4 + q];
     }
-    const long total = (long)N * H * W;
-    for (long p = (long)blockIdx.x * ppb + pl; p < total; p += (long)gridDim.x * ppb) {
-        if (pl >= ppb) break;
-        const int xx = (int)(p % W);
-        const int yy = (int)((p / W) % H);
-        const long n = p / ((long)W * H);
-        const float* xi = x + n * (long)H * W * 3;
-        float in[27];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = yy + ky - 1, ix = xx + kx - 1;
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const float* q = xi + ((long)(ok ? iy : 0) * W + (ok ? ix : 0)) * 3;
-                const float v0 = q[0], v1 = q[1], v2 = q[2];
-                in[(ky * 3 + kx) * 3 + 0] = ok ? v0 : 0.f;
-                in[(ky * 3 + kx) * 3 + 1] = ok ? v1 : 0.f;
-                in[(ky * 3 + kx) * 3 + 2] = ok ? v2 : 0.f;
+    const int ntiles = N * tiles_y * tiles_x;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx * RGB_TW, y0 = ty * RGB_TH;
+        const float* xi = x + (size_t)n * H * W * 3;
+        __syncthreads();                             // the previous tile's readers are done
+        for (int e = threadIdx.x; e < HH_ * HW_; e += 256) {
+            const int hy = e / HW_, hx = e - hy * HW_;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const float* q = xi + ((size_t)iy * W + ix) * 3;
+                v.x = q[0]; v.y = q[1]; v.z = q[2];
             }
-        f32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float s = br[q];
-#pragma unroll
-            for (int k = 0; k < 27; ++k) s = fmaf(in[k], wr[q][k], s);
-            if (ACT == PESR_ACT_RELU) s = s > 0.f ? s : 0.f;
-            else if (ACT == PESR_ACT_LRELU) s = s > 0.f ? s : s * slope;
-            o[q] = s;
+            halo[e] = v;
         }
-        *(f32x4*)(y + p * C + cg * 4) = o;
+        __syncthreads();
+        if (pl < ppb) {
+            for (int p = pl; p < RGB_TH * RGB_TW; p += ppb) {
+                const int py = p / RGB_TW, px = p - py * RGB_TW;
+                const int oy = y0 + py, ox = x0 + px;
+                if (oy >= H || ox >= W) continue;
+                float in[27];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const f32x4 v = halo[(py + t / 3) * HW_ + px + t % 3];
+                    in[t * 3 + 0] = v.x; in[t * 3 + 1] = v.y; in[t * 3 + 2] = v.z;
+                }
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float s = br[q];
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) s = fmaf(in[k], wr[q][k], s);
+                    if (ACT == PESR_ACT_RELU) s = s > 0.f ? s : 0.f;
+                    else if (ACT == PESR_ACT_LRELU) s = s > 0.f ? s : s * slope;
+                    o[q] = s;
+                }
+                *(f32x4*)(y + (((size_t)n * H + oy) * W + ox) * C + cg * 4) = o;
+            }
+        }
     }
+}
+
+template <int WMODE>
+static int rgb_in_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act, float slope,
+                         hipStream_t stream) {
+    if (C % 4 || C > 1024 || 256 % (C / 4)) return PESR_EINVAL;
+    const int tiles_x = (W + RGB_TW - 1) / RGB_TW, tiles_y = (H + RGB_TH - 1) / RGB_TH;
+    long grid = (long)N * tiles_x * tiles_y;
+    if (grid > 256 * 8) grid = 256 * 8;
+    const dim3 g((unsigned)grid), b(256);
+    if (act == PESR_ACT_RELU) hipLaunchKernelGGL((conv_rgb_in_kernel<PESR_ACT_RELU, WMODE>), g, b, 0, stream, x, w, bias, y, N, H, W, C, slope, tiles_x, tiles_y);
+    else if (act == PESR_ACT_LRELU) hipLaunchKernelGGL((conv_rgb_in_kernel<PESR_ACT_LRELU, WMODE>), g, b, 0, stream, x, w, bias, y, N, H, W, C, slope, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv_rgb_in_kernel<PESR_ACT_NONE, WMODE>), g, b, 0, stream, x, w, bias, y, N, H, W, C, slope, tiles_x, tiles_y);
+    return pesr_launch_status();
 }
 
 int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
                             float slope, hipStream_t stream) {
-    if (C % 4 || C > 1024 || 256 % (C / 4)) return PESR_EINVAL;
-    const int ppb = 256 / (C / 4);
-    const long total = (long)N * H * W;
-    long grid = (total + ppb - 1) / ppb;
-    if (grid > 256 * 8) grid = 256 * 8;
-    if (act == PESR_ACT_RELU) hipLaunchKernelGGL(conv_rgb_in_kernel<PESR_ACT_RELU>, dim3((unsigned)grid), dim3(256), 0, stream, x, w, bias, y, N, H, W, C, slope);
-    else if (act == PESR_ACT_LRELU) hipLaunchKernelGGL(conv_rgb_in_kernel<PESR_ACT_LRELU>, dim3((unsigned)grid), dim3(256), 0, stream, x, w, bias, y, N, H, W, C, slope);
-    else hipLaunchKernelGGL(conv_rgb_in_kernel<PESR_ACT_NONE>, dim3((unsigned)grid), dim3(256), 0, stream, x, w, bias, y, N, H, W, C, slope);
-    return pesr_launch_status();
+    return rgb_in_launch<0>(x, w, bias, y, N, H, W, C, act, slope, stream);
+}
+
+// dx[N][H][W][C] of y = conv3x3(x, w[3][C][3][3]) given dy[N][H][W][3]
+int pesr_conv_rgb_out_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream) {
+    return rgb_in_launch<1>(dy, w, nullptr, dx, N, H, W, C, PESR_ACT_NONE, 0.f, stream);
 }

@@ -248,7 +248,9 @@ class Conv3x3Fn(Function):
             gy = ops.relu_mask(gy, y)
         cin, ps = x.shape[3], ctx.cache.ps
         dx = dw = db = None
-        wpd = ctx.cache.dgrad(weight) if ctx.needs_input_grad[0] else None
+        # dx of a C -> 3 conv is a 3 -> C conv of dy: the HBM-bound direct kernel, no packed weights
+        rgb_dgrad = weight.shape[0] == 3 and ctx.stride == 1 and not ctx.relu_in and not ps and cin % 4 == 0 and 256 % (cin // 4) == 0
+        wpd = ctx.cache.dgrad(weight) if ctx.needs_input_grad[0] and not rgb_dgrad else None
         if ctx.needs_input_grad[1]:
             want_b = ctx.has_bias and ctx.needs_input_grad[2]
             outs = dict(dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref) if want_b else None)
@@ -260,7 +262,10 @@ class Conv3x3Fn(Function):
                 else:
                     dw, db = ops.conv3x3_wgrad(x, gy, ctx.stride, want_bias=want_b, ps_in=ps, **outs)
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3x3_dgrad(gy, wpd, tuple(x.shape), ctx.stride, mask=x if ctx.relu_in else None, ps_in=ps)
+            if rgb_dgrad:
+                dx = ops.conv3x3_rgb_dgrad(gy, weight.detach(), tuple(x.shape))
+            else:
+                dx = ops.conv3x3_dgrad(gy, wpd, tuple(x.shape), ctx.stride, mask=x if ctx.relu_in else None, ps_in=ps)
         return dx, dw, db, None, None, None, None, None
 
 

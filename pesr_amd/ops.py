@@ -156,6 +156,17 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
     return dx
 
 
+def conv3x3_rgb_dgrad(dy: torch.Tensor, w_oihw: torch.Tensor, in_shape) -> torch.Tensor:
+    """dx of a C -> 3 conv (stride 1, no fused mask): dy [N,H,W,3], w OIHW [3,C,3,3] -> dx [N,H,W,C]."""
+    _chk(dy, "conv3x3_rgb_dgrad.dy"); _chk(w_oihw, "conv3x3_rgb_dgrad.w")
+    N, H, W, C = in_shape
+    assert dy.shape == (N, H, W, 3) and w_oihw.shape == (3, C, 3, 3)
+    dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+    rc = _lib.lib().pesr_conv3x3_rgb_dgrad(_p(dy), _p(w_oihw), _p(dx), N, H, W, C, _stream())
+    _lib.check(rc, f"pesr_conv3x3_rgb_dgrad[{N}x{H}x{W}x{C}<-3]")
+    return dx
+
+
 def _out(t, shape, device):
     """Use the caller's output tensor (a view into a flat gradient buffer) when given, else allocate."""
     if t is not None:

@@ -27,7 +27,7 @@ def _close(a, b, rel, what=""):
     assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e} > {rel})"
 
 
-@pytest.mark.parametrize("N,H,W,C", [(2, 12, 12, 64), (1, 9, 7, 256)])
+@pytest.mark.parametrize("N,H,W,C", [(2, 12, 12, 64), (1, 9, 7, 256), (2, 37, 70, 64)])
 def test_rgb_convs(N, H, W, C):
     """3 -> C and C -> 3 convs (zero-padded onto the MFMA kernel) and their grads."""
     from pesr_amd import ops
@@ -62,6 +62,8 @@ def test_rgb_convs(N, H, W, C):
     dx_ref, dw_ref, db_ref = O.conv3x3_grads(xc, w2, dy3)
     dx2 = ops.conv3x3_dgrad(_nhwc(dy3), ops.pack_conv3x3(w2.cuda(), 1), (N, H, W, C))
     _close(_nchw(dx2), dx_ref, 1e-5, "dgrad 3->C")
+    dx2d = ops.conv3x3_rgb_dgrad(_nhwc(dy3), w2.cuda(), (N, H, W, C))                             # direct kernel (3 -> C conv of dy)
+    _close(_nchw(dx2d), dx_ref, 1e-5, "dgrad 3->C direct")
     dw2, db2 = ops.conv3x3_wgrad_rgb(_nhwc(xc), _nhwc(dy3), 1)
     _close(dw2.cpu(), dw_ref, 1e-5, "wgrad C->3")
     _close(db2.cpu(), db_ref, 1e-5, "bgrad C->3")
@@ -129,7 +131,7 @@ def test_bn_lrelu(N, C, H, W, nchw):
     _close(_nchw(dx), xr.grad, 5e-5, "bn dx"); _close(dg.cpu(), gr.grad, 5e-5, "dgamma"); _close(db.cpu(), br.grad, 5e-5, "dbeta")
 
 
-@pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (16, 1024, 73728)])
+@pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (3, 70, 1000), (16, 1024, 73728)])
 def test_linear(M, N, K):
     from pesr_amd import ops
     x = _rand(M, K, seed=1); w = _rand(N, K, seed=2, lo=-0.01, hi=0.01); b = _rand(N, seed=3)
