@@ -32,7 +32,7 @@ def k1_hbm_traffic_bytes():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot read PMCs
     live): 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB in the profile."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final_k1_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r01_final2_k1_pmc_summary.csv")
     try:
         fetch = write = None
         for r in csv.DictReader(open(path)):
@@ -220,7 +220,7 @@ def main():
                            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": k1_hbm_traffic_bytes(),
                            "traffic_note": "HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in "
-                                           "profiles/r01_final_k1_pmc_summary.csv (mean of fwd and dgrad launches); algorithmic: 78-116 MB",
+                                           "profiles/r01_final2_k1_pmc_summary.csv (mean of fwd and dgrad launches); algorithmic: 78-116 MB",
                            "launches_timed": kern_n, "avg_launch_us": round(kern_ms * 1e3, 2)}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, G, D, vgg)

@@ -1,0 +1,59 @@
+"""Condense rocprofv3 CSV output into the small tables kept under profiles/.
+
+  python scripts/summarize_profiles.py trace <kernel_trace.csv> <steps> <out.csv> [warmup]   per (kernel, grid): launches, avg us, ms/step
+  python scripts/summarize_profiles.py pmc <out.csv> <counter_collection.csv> [...]   per (kernel, counter): launches, mean per launch
+"""
+import collections, csv, sys
+
+
+def short(name):
+    return name if len(name) <= 180 else name[:180]
+
+
+def trace(path, steps, out, warmup=0):
+    """steps = timed steps in the run; the launches of the `warmup` untimed steps (first in time, per group) are dropped."""
+    groups = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+        key = (short(r["Kernel_Name"]), grid, wg)
+        groups.setdefault(key, []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    agg = {}
+    for key, lst in groups.items():
+        lst.sort()
+        drop = len(lst) * warmup // (warmup + steps) if len(lst) >= warmup + steps else 0
+        kept = lst[drop:]
+        agg[key] = (len(kept), sum(t for _, t in kept))
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid_threads", "workgroup", f"launches({steps} steps)", "avg_us", "total_ms_per_step"])
+        for (k, g, wg), (n, s) in rows:
+            w.writerow([k, g, wg, n, round(s / n, 1), round(s / 1e3 / steps, 3)])
+
+
+def pmc(out, paths):
+    agg = collections.OrderedDict()
+    for p in paths:
+        per_dispatch = collections.defaultdict(float)
+        names = {}
+        for r in csv.DictReader(open(p)):
+            key = (r["Dispatch_Id"], r["Counter_Name"])
+            per_dispatch[key] += float(r["Counter_Value"])          # summed over XCDs / instances
+            names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+        for (d, c), v in per_dispatch.items():
+            k = (names[d], c)
+            n, s = agg.get(k, (0, 0.0))
+            agg[k] = (n + 1, s + v)
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "launches", "mean_per_launch"])
+        for (k, c), (n, s) in sorted(agg.items()):
+            w.writerow([k, c, n, round(s / n, 1)])
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2], int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 0)
+    else:
+        pmc(sys.argv[2], sys.argv[3:])
