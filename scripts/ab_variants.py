@@ -6,7 +6,7 @@ sys.path.insert(0, R)
 from pesr_amd import _lib
 what = "fwd"
 args = sys.argv[1:]
-if args and args[0] in ("fwd", "wgrad"):
+if args and args[0] in ("fwd", "fwdskip", "wgrad"):
     what = args.pop(0)
 libs = args
 N, H, W, C = 16, 48, 48, 256
@@ -42,7 +42,10 @@ def run_fwd(l, iters=20):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        l.pesr_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1, 1.0, 1, 0.0, 0, None, 0, s)
+        if what == "fwdskip":   # the dgrad-of-conv1 epilogue: ReLU mask + residual add
+            l.pesr_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), None, dy.data_ptr(), x.data_ptr(), y.data_ptr(), N, H, W, C, C, 1, 0.1, 0, 0.0, 0, None, 0, s)
+        else:
+            l.pesr_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1, 1.0, 1, 0.0, 0, None, 0, s)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 for l in handles: run(l, 5)

@@ -35,6 +35,8 @@ CASES = [
     (2, 24, 24, 64, 64, 2),
     (1, 13, 11, 32, 128, 2),   # odd sizes with stride 2
     (1, 24, 24, 128, 256, 2),
+    (1, 20, 100, 64, 128, 1),  # wider than one 48-pixel wgrad segment: 3 segments per row, the last one ragged
+    (1, 30, 70, 64, 64, 2),    # stride 2 with 2 segments per output row (OW = 35)
 ]
 
 
