@@ -70,6 +70,16 @@ size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout
 int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                        int stride, float alpha, int ps_in, void* workspace, size_t ws_bytes, void* stream);
 
+/* Stride-1 3x3 conv (pad 1) with a 1-D Winograd F(2,3) transform along x: 2/3 of the multiplies of pesr_conv3x3_fwd, same
+ * tensors and fused epilogue (y = act(alpha * (conv + bias) [masked] + skip)), for even W, Cin % 16 == 0, Cout % 128 == 0
+ * (pesr_conv3x3_wino_supported).  Stands in for the same ATen conv2d / convolution_backward(input) calls of the reference
+ * `Conv` (model/basic.py:4-7).  w_packed: 12 * Cin * Cout floats from pesr_pack_conv3x3_wino (mode 0: forward weights from
+ * OIHW [Cout][Cin][3][3]; mode 1: the input-gradient weights - then call with Cin/Cout of the gradient problem swapped). */
+int pesr_conv3x3_wino_supported(int N, int H, int W, int Cin, int Cout);
+int pesr_pack_conv3x3_wino(const float* w, float* w_packed, int Cout, int Cin, int mode, void* stream);
+int pesr_conv3x3_wino(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask, float* y,
+                      int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, void* stream);
+
 /* Forward 3x3 conv from a 3-channel input, stride 1 (reference `embed` model/pesr.py:23, Discriminator features.0
  * model/pesr.py:53, vgg19 features.0): x [N][H][W][3], w OIHW [Cout][3][3][3] (NOT packed), y [N][H][W][Cout]. */
 int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,

@@ -1,0 +1,293 @@
+// 3x3 stride-1 convolution with a 1-D Winograd F(2,3) transform along x, on the fp32-input MFMA, gfx950.
+//
+// Same contract as conv3x3_mfma.hip (reference nn.Conv2d(k=3, padding=1), model/basic.py:4-7, forward and - with
+// dgrad-transformed weights - input gradient) for even widths and Cout % 128 == 0, with 2/3 of the multiplies:
+// for an output pixel pair (2t, 2t+1) of a row and the input columns d0..d3 = x[2t-1 .. 2t+2],
+//     V  = [d0 - d2, d1 + d2, d2 - d1, d1 - d3]                        (input transform, per row and channel)
+//     U  = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2]                        (weight transform along kx, done by pack.hip)
+//     M_xi = sum_{ky, ci} V_xi[row + ky - 1][ci] * U_xi[ky][ci]         (4 accumulators instead of 2 outputs x 3 taps)
+//     y[2t] = M0 + M1 + M2,   y[2t+1] = M1 - M2 - M3.
+// So a 16-channel chunk has 3 (ky) x 4 (xi) = 12 weight slabs of [Cout][16] instead of 9 taps, and the GEMM rows are
+// x-tiles (pixel pairs): 12 slab-MFMAs per 2 pixels instead of 18.
+//
+// One workgroup = 144 x-tiles (TR rows x TXT tiles, 288 output pixels) x 128 output channels, 8 waves, each wave owning
+// 16 channels x 4 xi x 9 m-tiles of accumulators (144 VGPRs).  Per chunk the raw input halo arrives by LDS-DMA (one chunk
+// ahead), a cooperative pass turns it into V ([row][xi][x-tile][16ch], 64 B per entry like the direct kernel's halo) and
+// the 12 slabs stream through an 8-slot LDS-DMA ring, one barrier per ky (4 slabs, 4608 MFMA cycles); fragments are
+// read one slab ahead into a second register set.  The output transform happens in registers before the tile leaves
+// through LDS as coalesced 16-byte stores with the usual fused epilogue (bias, scale, ReLU mask, skip, activation).
+#include "common.h"
+#include "launchers.h"
+#include "wino_pack.h"
+
+__device__ __attribute__((aligned(16))) const float g_wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void wino_dma16(const float* gsrc, char* lds_piece) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+
+struct WinoArgs {
+    const float* x;     // [N][H][W][Cin]
+    const float* wp;    // packed, transformed weights [3*4][Cin/16][Cout][16]
+    const float* bias;  // [Cout] or null
+    const float* skip;  // [N][H][W][Cout] or null
+    const float* mask;  // [N][H][W][Cout] or null : result zeroed where mask <= 0
+    float* y;           // [N][H][W][Cout]
+    int N, H, W, Cin, Cout;
+    int TR, TXT;        // tile: TR output rows x TXT x-tiles (TR * TXT == 144)
+    int tiles_x, tiles_y, n_tiles;
+    int HT, WT;         // raw halo: TR + 2 rows x 2*TXT + 2 columns
+    float alpha, slope;
+    int act;
+};
+
+constexpr int WINO_NT = 512, WINO_BN = 128, WINO_MG = 9, WINO_RING = 8;
+constexpr int WINO_SLAB = WINO_BN * 64;   // bytes of one weight slab [128][16]
+constexpr int WINO_HL = 4;                // raw-halo DMA pieces per wave (<= 32 pieces = 512 pixels)
+
+__global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo_pix = a.HT * a.WT;
+    const int raw_bytes = ((halo_pix * 64 + 1023) / 1024) * 1024;
+    const int v_bytes = a.HT * 4 * a.TXT * 64;
+    char* const raw = smem;
+    char* const vbuf = smem + raw_bytes;
+    char* const ring = vbuf + v_bytes;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int nt = bid % a.n_tiles;  bid /= a.n_tiles;
+    const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int gy0 = ty * a.TR, gt0 = tx * a.TXT;          // first output row / first x-tile of the tile
+    const int n0 = nt * WINO_BN;
+    const int C16 = a.Cin >> 4;
+
+    // per-lane LDS offsets: A = V[row][xi][x-tile][16ch] (row and xi added per slab), B = slab[channel][16]
+    int a_off[WINO_MG];
+#pragma unroll
+    for (int i = 0; i < WINO_MG; ++i) {
+        const int m = i * 16 + r;
+        const int trow = m / a.TXT, txt = m - trow * a.TXT;
+        a_off[i] = (trow * 4 * a.TXT + txt) * 64 + g * 16;
+    }
+    const int b_off = (wave * 16 + r) * 64 + g * 16;
+    const int xi_stride = a.TXT * 64;                      // bytes between the xi planes of a V row
+
+    // raw halo: per-lane global offsets of this wave's DMA pieces (piece = 16 pixels x 64 B)
+    const float* const xi_img = a.x + (size_t)img * a.H * a.W * a.Cin;
+    int h_src[WINO_HL];
+#pragma unroll
+    for (int k = 0; k < WINO_HL; ++k) {
+        const int e = (wave + k * 8) * 64 + lane;          // float4 unit inside the halo image
+        const int hp = e >> 2, q = e & 3;
+        int off = -2;
+        if (hp < halo_pix) {
+            const int hy = hp / a.WT, hx = hp - hy * a.WT;
+            const int iy = gy0 - 1 + hy, ix = 2 * gt0 - 1 + hx;
+            off = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (iy * a.W + ix) * a.Cin + q * 4 : -1;
+        }
+        h_src[k] = off;
+    }
+    auto dma_raw = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < WINO_HL; ++k) {
+            if (h_src[k] != -2) {
+                const float* src = h_src[k] >= 0 ? xi_img + h_src[k] + c * 16 : g_wino_zero16;
+                wino_dma16(src, raw + (wave + k * 8) * 1024);
+            }
+        }
+    };
+    // weight slab s = (c*3 + ky)*4 + xi of the kernel's own order; packed as [ky*4 + xi][c][Cout][16]: one 1-KiB piece per wave
+    const float* const wn = a.wp + (size_t)n0 * 16 + wave * 256 + lane * 4;
+    const size_t slab_stride = (size_t)a.Cout * 16;
+    const int nslab = C16 * 12;
+    int sd = 0;                                            // DMA cursor (slab index); past the end it re-fetches the last slab
+    auto dma_next = [&]() {
+        const int s = sd < nslab ? sd : nslab - 1;
+        const int c = s / 12, t12 = s - c * 12;
+        wino_dma16(wn + ((size_t)t12 * C16 + c) * slab_stride, ring + (sd & (WINO_RING - 1)) * WINO_SLAB + wave * 1024);
+        ++sd;
+    };
+    // raw -> V: item = (halo row, x-tile, 4-channel group)
+    auto transform = [&]() {
+        const int items = a.HT * a.TXT * 4;
+        for (int it = tid; it < items; it += WINO_NT) {
+            const int q = it & 3;
+            const int rest = it >> 2;
+            const int hrow = rest / a.TXT, txt = rest - hrow * a.TXT;
+            const char* src = raw + ((hrow * a.WT + 2 * txt) * 64 + q * 16);
+            const f32x4 d0 = *(const f32x4*)(src), d1 = *(const f32x4*)(src + 64), d2 = *(const f32x4*)(src + 128),
+                        d3 = *(const f32x4*)(src + 192);
+            char* dst = vbuf + ((hrow * 4 * a.TXT + txt) * 64 + q * 16);
+            *(f32x4*)(dst) = d0 - d2;
+            *(f32x4*)(dst + xi_stride) = d1 + d2;
+            *(f32x4*)(dst + 2 * xi_stride) = d2 - d1;
+            *(f32x4*)(dst + 3 * xi_stride) = d1 - d3;
+        }
+    };
+
+    f32x4 acc[4][WINO_MG];
+#pragma unroll
+    for (int x4 = 0; x4 < 4; ++x4)
+#pragma unroll
+        for (int i = 0; i < WINO_MG; ++i) acc[x4][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 fa0[WINO_MG], fa1[WINO_MG], fb0, fb1;            // two fragment sets, statically indexed
+#define WINO_READ_A(FA, KY, XI)                                                                          \
+    {                                                                                                    \
+        const char* const vb_ = vbuf + ((KY) * 4 + (XI)) * xi_stride;                                    \
+        _Pragma("unroll") for (int i = 0; i < WINO_MG; ++i) FA[i] = *(const f32x4*)(vb_ + a_off[i]);      \
+    }
+#define WINO_READ_B(FB, S_) FB = *(const f32x4*)(ring + ((S_) & (WINO_RING - 1)) * WINO_SLAB + b_off);
+#define WINO_MFMA(FA, FB, XI)                                                                            \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
+        _Pragma("unroll") for (int i = 0; i < WINO_MG; ++i)                                              \
+            acc[XI][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[i][kk], FB[kk], acc[XI][i], 0, 0, 0);
+
+    // ---- prologue: chunk 0's halo, slabs 0..4 ------------------------------------------------------------------------------
+    dma_raw(0);
+    dma_next(); dma_next(); dma_next(); dma_next(); dma_next();
+    __syncthreads();
+    transform();
+    __syncthreads();
+    if (C16 > 1) dma_raw(1);
+    WINO_READ_B(fb0, 0)
+    int s = 0;                                             // slab being multiplied
+#pragma unroll 1
+    for (int c = 0; c < C16; ++c) {
+        WINO_READ_A(fa0, 0, 0)                             // V of this chunk exists only now; the slab's B fragment is already in fb0
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            dma_next(); dma_next(); dma_next(); dma_next(); // slabs s+5 .. s+8 -> the slots of s-3 .. s (all read)
+            // xi = 0
+            WINO_READ_A(fa1, ky, 1) WINO_READ_B(fb1, s + 1)
+            WINO_MFMA(fa0, fb0, 0)
+            // xi = 1
+            WINO_READ_A(fa0, ky, 2) WINO_READ_B(fb0, s + 2)
+            WINO_MFMA(fa1, fb1, 1)
+            // xi = 2
+            WINO_READ_A(fa1, ky, 3) WINO_READ_B(fb1, s + 3)
+            WINO_MFMA(fa0, fb0, 2)
+            // xi = 3: prefetch the next ky's first slab; across a chunk boundary only its B half (V is rebuilt below)
+            if (ky < 2) WINO_READ_A(fa0, ky + 1, 0)
+            WINO_READ_B(fb0, s + 4)
+            WINO_MFMA(fa1, fb1, 3)
+            s += 4;
+            __syncthreads();                               // publishes the slabs DMA'd in this step; frees the ones read
+        }
+        if (c + 1 < C16) {
+            transform();                                   // raw holds chunk c+1 (DMA'd a chunk ago, retired by the barriers since)
+            __syncthreads();
+            if (c + 2 < C16) dma_raw(c + 2);
+        }
+    }
+#undef WINO_READ_A
+#undef WINO_READ_B
+#undef WINO_MFMA
+
+    // ---- epilogue: output transform in registers, tile through LDS, coalesced stores ------------------------------------
+    constexpr int RS = WINO_BN * 4 + 16;                   // padded row stride of the staged tile
+    constexpr int C4 = WINO_BN / 4;
+    char* const ob = smem;
+    const int prow = 2 * a.TXT;                            // output pixels per tile row
+#pragma unroll
+    for (int i = 0; i < WINO_MG; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = i * 16 + g * 4 + jj;
+            const int trow = m / a.TXT, txt = m - trow * a.TXT;
+            const float m0 = acc[0][i][jj], m1 = acc[1][i][jj], m2 = acc[2][i][jj], m3 = acc[3][i][jj];
+            char* o = ob + (trow * prow + 2 * txt) * RS + (wave * 16 + r) * 4;
+            *(float*)(o) = (m0 + m1) + m2;
+            *(float*)(o + RS) = (m1 - m2) - m3;
+        }
+    __syncthreads();
+    const size_t img_out = (size_t)img * a.H * a.W;
+    const int npix = 288;
+    for (int u = tid; u < npix * C4; u += WINO_NT) {
+        const int p = u / C4, c4 = u - p * C4;
+        const int co = n0 + c4 * 4;
+        const int py = p / prow, px = p - py * prow;
+        const int oy = gy0 + py, ox = 2 * gt0 + px;
+        if (oy >= a.H || ox >= a.W) continue;
+        f32x4 v = *(const f32x4*)(ob + p * RS + c4 * 16);
+        const size_t idx = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+        if (a.bias) v += *(const f32x4*)(a.bias + co);
+        v *= a.alpha;
+        if (a.mask) {
+            const f32x4 mk = *(const f32x4*)(a.mask + idx);
+            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
+        if (a.skip) v += *(const f32x4*)(a.skip + idx);
+        if (a.act == PESR_ACT_RELU) {
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        } else if (a.act == PESR_ACT_LRELU) {
+            v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+            v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+        }
+        *(f32x4*)(a.y + idx) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight transform + packing (wino_pack.h)
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode) {
+    const long total = 12L * O * I;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+        out[e] = pesr_wino_pack_elem(w, O, I, mode, e);
+}
+
+int pesr_pack_conv3x3_wino_launch(const float* w, float* out, int O, int I, int mode, hipStream_t stream) {
+    if (O % 16 || I % 16 || (mode != 0 && mode != 1)) return PESR_EINVAL;
+    const long total = 12L * O * I;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid), dim3(256), 0, stream, w, out, O, I, mode);
+    return pesr_launch_status();
+}
+
+int pesr_conv3x3_wino_supported_impl(int N, int H, int W, int Cin, int Cout) {
+    return N > 0 && H > 0 && W >= 2 && W % 2 == 0 && Cin % 16 == 0 && Cin >= 16 && Cout % WINO_BN == 0;
+}
+
+int pesr_conv3x3_wino_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
+                             int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, hipStream_t stream) {
+    if (!pesr_conv3x3_wino_supported_impl(N, H, W, Cin, Cout)) return PESR_EINVAL;
+    WinoArgs a{};
+    a.x = x; a.wp = wp; a.bias = bias; a.skip = skip; a.mask = mask; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.alpha = alpha; a.slope = slope; a.act = act;
+    // tile shape: TR x TXT == 144 x-tiles, least out-of-image area, within the LDS budget and the raw-halo DMA pieces
+    const int XT = W / 2;
+    long best = -1;
+    for (int TXT = 1; TXT <= 144; ++TXT) {
+        if (144 % TXT) continue;
+        const int TR = 144 / TXT;
+        const int HT = TR + 2, WT = 2 * TXT + 2;
+        const size_t raw_bytes = ((size_t)HT * WT * 64 + 1023) / 1024 * 1024;
+        const size_t lds = raw_bytes + (size_t)HT * 4 * TXT * 64 + (size_t)WINO_RING * WINO_SLAB;
+        if (lds > 160 * 1024 || HT * WT > WINO_HL * 8 * 16) continue;
+        const long cover = (long)pesr_cdiv(H, TR) * TR * pesr_cdiv(XT, TXT) * TXT;
+        const long score = cover * 4096 + (long)HT * WT;
+        if (best < 0 || score < best) { best = score; a.TR = TR; a.TXT = TXT; }
+    }
+    if (best < 0) return PESR_EINVAL;
+    a.HT = a.TR + 2; a.WT = 2 * a.TXT + 2;
+    a.tiles_y = pesr_cdiv(H, a.TR); a.tiles_x = pesr_cdiv(XT, a.TXT); a.n_tiles = Cout / WINO_BN;
+    const size_t raw_bytes = ((size_t)a.HT * a.WT * 64 + 1023) / 1024 * 1024;
+    size_t lds = raw_bytes + (size_t)a.HT * 4 * a.TXT * 64 + (size_t)WINO_RING * WINO_SLAB;
+    const size_t lds_out = (size_t)288 * (WINO_BN * 4 + 16);
+    if (lds_out > lds) lds = lds_out;
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long grid = (long)N * a.tiles_y * a.tiles_x * a.n_tiles;
+    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)grid), dim3(WINO_NT), lds, stream, a);
+    return pesr_launch_status();
+}

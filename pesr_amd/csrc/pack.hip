@@ -10,6 +10,7 @@
 // epilogue can write the shuffled tensor with contiguous channel runs (reference model/basic.py:56-59).
 #include "common.h"
 #include "launchers.h"
+#include "wino_pack.h"
 
 // R (reduction channels) is zero-padded to a multiple of 16 and Nn ("n" channels) to 16 (if <= 16) or a multiple of 64, so
 // the 3-channel RGB layers run on the same MFMA kernels.
@@ -32,12 +33,18 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
 }
 
 // Batched form: one launch packs many convs (all of a network's, right after its optimizer step).  desc[d] (8 int64):
-// {src ptr, dst ptr, O, I, mode, ps, R, Nn}; blockIdx.y = d.
+// {src ptr, dst ptr, O, I, mode, ps, R, Nn}; blockIdx.y = d.  mode 2 / 3: the Winograd packing of mode 0 / 1.
 __global__ void pack_conv3x3_batched_kernel(const long long* __restrict__ desc) {
     const long long* d = desc + (size_t)blockIdx.y * 8;
     const float* __restrict__ w = (const float*)d[0];
     float* __restrict__ out = (float*)d[1];
     const int O = (int)d[2], I = (int)d[3], mode = (int)d[4], ps = (int)d[5], R = (int)d[6], Nn = (int)d[7];
+    if (mode >= 2) {   // Winograd packing (conv3x3_wino.hip): mode 2 = forward, 3 = dgrad
+        const long total_w = 12L * O * I;
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total_w; e += (long)gridDim.x * blockDim.x)
+            out[e] = pesr_wino_pack_elem(w, O, I, mode - 2, e);
+        return;
+    }
     const long total = 9L * R * Nn;
     const int C = O >> 2;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {

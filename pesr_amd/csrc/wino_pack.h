@@ -1,0 +1,22 @@
+// Element e of the transformed, packed Winograd weights out[(ky*4 + xi)][c][n][k] (conv3x3_wino.hip):
+//   mode 0 (forward): g[kx] = w[o = n][i = 16c+k][ky][kx]
+//   mode 1 (dgrad)  : g[kx] = w[o = 16c+k][i = n][2-ky][2-kx]   (the input gradient is the conv with the flipped kernel)
+//   U = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2]
+#pragma once
+__device__ __forceinline__ float pesr_wino_pack_elem(const float* __restrict__ w, int O, int I, int mode, long e) {
+    const int R = mode == 0 ? I : O, Nn = mode == 0 ? O : I;
+    const int k = (int)(e & 15);
+    long rest = e >> 4;
+    const int n = (int)(rest % Nn); rest /= Nn;
+    const int c = (int)(rest % (R >> 4));
+    const int t12 = (int)(rest / (R >> 4));
+    const int ky = t12 >> 2, xi = t12 & 3;
+    const int red = c * 16 + k;
+    const int o = mode == 0 ? n : red, i = mode == 0 ? red : n;
+    const float* g = w + ((long)o * I + i) * 9 + (mode == 0 ? ky : 2 - ky) * 3;
+    const float g0 = mode == 0 ? g[0] : g[2], g1 = g[1], g2 = mode == 0 ? g[2] : g[0];
+    if (xi == 0) return g0;
+    if (xi == 1) return 0.5f * ((g0 + g1) + g2);
+    if (xi == 2) return 0.5f * ((g0 - g1) + g2);
+    return g2;
+}

@@ -63,8 +63,8 @@ class PackedConvWeights:
     def __init__(self, ps: bool = False):
         import weakref
         self.ps = ps
-        self._fwd = self._dgrad = self._bias = None
-        self._kf = self._kd = self._kb = None
+        self._fwd = self._dgrad = self._bias = self._wfwd = self._wdgrad = None
+        self._kf = self._kd = self._kb = self._kwf = self._kwd = None
         self._wref = None            # weakref to the weight parameter once it has been seen
         _ALL_PACKS.append(weakref.ref(self))
 
@@ -92,6 +92,36 @@ class PackedConvWeights:
             self._dgrad = ops.pack_conv3x3(w.detach(), 1, self.ps)
             self._kd = k
         return self._dgrad
+
+    def wino_fwd(self, w: torch.Tensor):
+        self._note(w)
+        k = self._key(w)
+        if self._kwf != k:
+            self._wfwd = ops.pack_conv3x3_wino(w.detach(), 0)
+            self._kwf = k
+        return self._wfwd
+
+    def wino_dgrad(self, w: torch.Tensor):
+        self._note(w)
+        k = self._key(w)
+        if self._kwd != k:
+            self._wdgrad = ops.pack_conv3x3_wino(w.detach(), 1)
+            self._kwd = k
+        return self._wdgrad
+
+    def for_fwd(self, w: torch.Tensor, x_shape, stride: int = 1):
+        """Packed weights for y = conv(x, w): the Winograd packing where that kernel applies, else the direct one."""
+        N, H, W, Cin = x_shape
+        if not self.ps and ops.wino_eligible(N, H, W, Cin, w.shape[0], stride):
+            return self.wino_fwd(w)
+        return self.fwd(w)
+
+    def for_dgrad(self, w: torch.Tensor, x_shape, stride: int = 1):
+        """Packed weights for dx of y = conv(x, w) with x of NHWC shape x_shape."""
+        N, H, W, Cin = x_shape
+        if not self.ps and ops.wino_eligible(N, H, W, w.shape[0], Cin, stride):
+            return self.wino_dgrad(w)
+        return self.dgrad(w)
 
     def bias(self, b):
         if b is None or not self.ps:
@@ -192,6 +222,9 @@ def repack_all(params) -> None:
                 continue
             R, Nn = (I, O) if mode == 0 else (O, I)
             jobs.append((c, mode, (w.data_ptr(), buf.data_ptr(), O, I, mode, int(c.ps), (R + 15) // 16 * 16, 16 if Nn <= 16 else (Nn + 63) // 64 * 64)))
+        for mode, wpk in ((2, c._wfwd), (3, c._wdgrad)):      # Winograd packings (batched kernel modes 2 / 3)
+            if wpk is not None:
+                jobs.append((c, mode, (w.data_ptr(), wpk.t.data_ptr(), O, I, mode, 0, I if mode == 2 else O, O if mode == 2 else I)))
     if not jobs:
         return
     dev = jobs[0][0]._wref().device
@@ -207,8 +240,12 @@ def repack_all(params) -> None:
         k = PackedConvWeights._key(c._wref())
         if mode == 0:
             c._kf = k
-        else:
+        elif mode == 1:
             c._kd = k
+        elif mode == 2:
+            c._kwf = k
+        else:
+            c._kwd = k
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -231,7 +268,7 @@ class Conv3x3Fn(Function):
     def forward(ctx, x, weight, bias, cache: PackedConvWeights, stride, act, relu_in, relu_grad_by_consumer):
         x = _c(x)
         cout = weight.shape[0]
-        y = ops.conv3x3_fwd(x, lambda: cache.fwd(weight), cache.bias(bias), cout, stride, act=act, ps_out=cache.ps,
+        y = ops.conv3x3_fwd(x, lambda: cache.for_fwd(weight, x.shape, stride), cache.bias(bias), cout, stride, act=act, ps_out=cache.ps,
                             w_oihw=weight.detach())
         ctx.cache, ctx.stride, ctx.act, ctx.relu_in = cache, stride, act, relu_in
         ctx.mask_here = act == ops.ACT_RELU and not relu_grad_by_consumer
@@ -250,7 +287,7 @@ class Conv3x3Fn(Function):
         dx = dw = db = None
         # dx of a C -> 3 conv is a 3 -> C conv of dy: the HBM-bound direct kernel, no packed weights
         rgb_dgrad = weight.shape[0] == 3 and ctx.stride == 1 and not ctx.relu_in and not ps and cin % 4 == 0 and 256 % (cin // 4) == 0
-        wpd = ctx.cache.dgrad(weight) if ctx.needs_input_grad[0] and not rgb_dgrad else None
+        wpd = ctx.cache.for_dgrad(weight, x.shape, ctx.stride) if ctx.needs_input_grad[0] and not rgb_dgrad else None
         if ctx.needs_input_grad[1]:
             want_b = ctx.has_bias and ctx.needs_input_grad[2]
             outs = dict(dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref) if want_b else None)
@@ -282,7 +319,7 @@ class ConvAddFn(Function):
     @staticmethod
     def forward(ctx, x, skip, weight, bias, cache):
         x, skip = _c(x), _c(skip)
-        y = ops.conv3x3_fwd(x, cache.fwd(weight), cache.bias(bias), weight.shape[0], 1, skip=skip)
+        y = ops.conv3x3_fwd(x, cache.for_fwd(weight, x.shape), cache.bias(bias), weight.shape[0], 1, skip=skip)
         ctx.cache, ctx.bias_ref = cache, bias
         ctx.save_for_backward(x, weight)
         return y
@@ -291,7 +328,7 @@ class ConvAddFn(Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = _c(gy)
-        wpd = ctx.cache.dgrad(weight) if ctx.needs_input_grad[0] else None
+        wpd = ctx.cache.for_dgrad(weight, x.shape) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[2]:
             o_w, o_b = grad_out(weight), grad_out(ctx.bias_ref)
@@ -314,8 +351,8 @@ class ResBlockFn(Function):
     def forward(ctx, x, w1, b1, w2, b2, c1: PackedConvWeights, c2: PackedConvWeights, res_scale):
         x = _c(x)
         C = w1.shape[0]
-        r = ops.conv3x3_fwd(x, c1.fwd(w1), b1.detach(), C, 1, act=ops.ACT_RELU)
-        y = ops.conv3x3_fwd(r, c2.fwd(w2), b2.detach(), C, 1, alpha=res_scale, skip=x)
+        r = ops.conv3x3_fwd(x, c1.for_fwd(w1, x.shape), b1.detach(), C, 1, act=ops.ACT_RELU)
+        y = ops.conv3x3_fwd(r, c2.for_fwd(w2, x.shape), b2.detach(), C, 1, alpha=res_scale, skip=x)
         ctx.c1, ctx.c2, ctx.res_scale = c1, c2, res_scale
         ctx.b1_ref, ctx.b2_ref = b1, b2
         ctx.save_for_backward(x, r, w1, w2)
@@ -328,7 +365,7 @@ class ResBlockFn(Function):
         s = ctx.res_scale
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
         dw1 = db1 = dw2 = db2 = None
-        wpd2, wpd1 = ctx.c2.dgrad(w2), ctx.c1.dgrad(w1)      # (packing happens on the main stream)
+        wpd2, wpd1 = ctx.c2.for_dgrad(w2, x.shape), ctx.c1.for_dgrad(w1, x.shape)      # (packing happens on the main stream)
         if need_w:
             o_w, o_b = grad_out(w2), grad_out(ctx.b2_ref)
             with _OnSide(gy.device, r, gy, fast=o_w is not None and o_b is not None):
@@ -375,7 +412,7 @@ class ConvBnLReluFn(Function):
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, num_batches, cache, stride, eps, momentum,
                 slope, y_nchw):
         x = _c(x)
-        z = ops.conv3x3_fwd(x, lambda: cache.fwd(weight), None, weight.shape[0], stride, w_oihw=weight.detach())
+        z = ops.conv3x3_fwd(x, lambda: cache.for_fwd(weight, x.shape, stride), None, weight.shape[0], stride, w_oihw=weight.detach())
         y, stats = ops.bn_lrelu_fwd(z, gamma.detach(), beta.detach(), running_mean, running_var, num_batches, eps,
                                     momentum, slope, y_nchw)
         ctx.cache, ctx.stride, ctx.slope, ctx.y_nchw = cache, stride, slope, y_nchw
@@ -390,7 +427,7 @@ class ConvBnLReluFn(Function):
         dz, dgamma, dbeta = ops.bn_lrelu_bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p,
                                              dgamma_out=grad_out(gamma) if need_p else None, dbeta_out=grad_out(beta) if need_p else None)
         dx = dw = None
-        wpd = ctx.cache.dgrad(weight) if ctx.needs_input_grad[0] else None
+        wpd = ctx.cache.for_dgrad(weight, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
         if ctx.needs_input_grad[1]:
             o_w = grad_out(weight)
             with _OnSide(dz.device, x, dz, fast=o_w is not None):

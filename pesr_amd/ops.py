@@ -95,6 +95,41 @@ def pack_bias_ps(b: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # 3x3 conv family
 # ------------------------------------------------------------------------------------------------
+class WinoPacked:
+    """Weights packed for the Winograd F(2,3)-along-x kernel (pesr_pack_conv3x3_wino); conv3x3_fwd / conv3x3_dgrad dispatch on it."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
+USE_WINO = __import__("os").environ.get("PESR_WINO", "1") != "0"     # PESR_WINO=0: direct kernel everywhere
+
+
+def wino_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps: bool = False) -> bool:
+    """The Winograd kernel applies (stride 1, even width, Cout % 128 == 0, no fused PixelShuffle) AND its 288-pixel x
+    128-channel tiles fill the chip; small layers stay on the direct kernel (smaller tiles, split-K)."""
+    if not USE_WINO or stride != 1 or ps or W % 2 or Cin % 16 or Cin < 16 or Cout % 128:
+        return False
+    return N * ((H * (W // 2) + 143) // 144) * (Cout // 128) >= 192
+
+
+def pack_conv3x3_wino(w: torch.Tensor, mode: int) -> WinoPacked:
+    """OIHW [O, I, 3, 3] -> transformed [12, R/16, Nn, 16] (mode 0: forward, mode 1: dgrad)."""
+    _chk(w, "pack_conv3x3_wino.w")
+    O, I = w.shape[0], w.shape[1]
+    out = torch.empty(12 * O * I, dtype=torch.float32, device=w.device)
+    rc = _lib.lib().pesr_pack_conv3x3_wino(_p(w), _p(out), O, I, mode, _stream())
+    _lib.check(rc, f"pesr_pack_conv3x3_wino[{O}x{I},mode{mode}]")
+    return WinoPacked(out)
+
+
+def _conv3x3_wino(x, wp: WinoPacked, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, what):
+    rc = _lib.lib().pesr_conv3x3_wino(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope,
+                                     _stream())
+    _lib.check(rc, f"pesr_conv3x3_wino[{what} {N}x{H}x{W}x{Cin}->{cout}]")
+
+
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout: int, stride: int = 1,
                 alpha: float = 1.0, act: int = ACT_NONE, slope: float = 0.0, skip: Optional[torch.Tensor] = None,
                 mask: Optional[torch.Tensor] = None, ps_out: bool = False,
@@ -124,10 +159,15 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     if callable(wp):
         wp = wp()
     L = _lib.lib()
-    nws = L.pesr_conv3x3_workspace_bytes(N, OH, OW, cout)
-    ws = workspace(nws, x.device) if nws else None
-    rc = L.pesr_conv3x3_fwd(_p(x), _p(wp), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, stride,
-                            alpha, act, slope, int(ps_out), _p(ws), nws, _stream())
+    if isinstance(wp, WinoPacked):
+        assert stride == 1 and not ps_out
+        _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, "fwd")
+        rc = 0
+    else:
+        nws = L.pesr_conv3x3_workspace_bytes(N, OH, OW, cout)
+        ws = workspace(nws, x.device) if nws else None
+        rc = L.pesr_conv3x3_fwd(_p(x), _p(wp), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, stride,
+                                alpha, act, slope, int(ps_out), _p(ws), nws, _stream())
     if timed:
         e1.record()
         KERNEL_EVENTS.pairs.append((e0, e1))
@@ -148,6 +188,10 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
             _chk(t, f"conv3x3_dgrad.{n}")
             assert t.shape == dx.shape
     L = _lib.lib()
+    if isinstance(wpd, WinoPacked):     # the input gradient is the conv of dy with the flipped, transposed kernel
+        assert stride == 1 and not ps_in
+        _conv3x3_wino(dy, wpd, None, skip, mask, dx, N, H, W, cout, Cin, alpha, ACT_NONE, 0.0, "dgrad")
+        return dx
     nws = L.pesr_conv3x3_workspace_bytes(N, H, W, Cin) if stride == 1 else 0
     ws = workspace(nws, dy.device) if nws else None
     rc = L.pesr_conv3x3_dgrad(_p(dy), _p(wpd), _p(mask), _p(skip), _p(dx), N, H, W, Cin, cout, stride, alpha,

@@ -158,3 +158,45 @@ def test_conv3x3_random_shape_sweep():
             _close(_nchw(dx), dx_ref, 1e-5)
             dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), s)
             _close(dw.cpu(), dw_ref, 2e-5); _close(db.cpu(), db_ref, 2e-5)
+
+
+WINO_CASES = [
+    # N, H, W, Cin, Cout     (W even, Cout % 128 == 0)
+    (1, 6, 48, 16, 128),
+    (2, 7, 10, 32, 128),      # ragged: partial tile rows and a partial x-tile row
+    (1, 48, 48, 256, 256),    # K1 shape, one image
+    (1, 13, 96, 64, 256),
+    (2, 5, 2, 16, 128),       # one pixel pair per row
+    (1, 9, 194, 16, 128),     # wider than one tile
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", WINO_CASES)
+def test_conv3x3_winograd_kernel(N, H, W, Cin, Cout):
+    """Winograd F(2,3)-along-x kernel (conv3x3_wino.hip) against the oracle: forward with every fused epilogue, input gradient."""
+    from pesr_amd import ops
+    x = _rand(N, Cin, H, W, seed=1); w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.1); b = _rand(Cout, seed=3)
+    skip = _rand(N, Cout, H, W, seed=4); mk = _rand(N, Cout, H, W, seed=5)
+    ref = O.conv3x3(x, w, b)
+    wf = ops.pack_conv3x3_wino(w.cuda(), 0)
+    y = ops.conv3x3_fwd(_nhwc(x), wf, b.cuda(), Cout, act=ops.ACT_RELU)
+    _close(_nchw(y), torch.relu(ref), 1e-5)
+    y = ops.conv3x3_fwd(_nhwc(x), wf, b.cuda(), Cout, alpha=0.1, skip=_nhwc(skip), mask=_nhwc(mk))
+    _close(_nchw(y), torch.where(mk > 0, ref * 0.1, torch.zeros_like(ref)) + skip, 1e-5)
+    if Cin % 128 == 0:
+        dy = _rand(N, Cout, H, W, seed=6)
+        dx_ref, _, _ = O.conv3x3_grads(x, w, dy)
+        dx = ops.conv3x3_dgrad(_nhwc(dy), ops.pack_conv3x3_wino(w.cuda(), 1), (N, H, W, Cin), mask=_nhwc(x), skip=_nhwc(x))
+        _close(_nchw(dx), torch.where(x > 0, dx_ref, torch.zeros_like(dx_ref)) + x, 2e-6 * (Cout * 9) ** 0.5)
+
+
+def test_winograd_dispatch_rule():
+    """functional picks the Winograd packing only where the kernel applies and fills the chip (the G body shape), and the
+    direct one elsewhere (odd widths, fused PixelShuffle, stride 2, small layers)."""
+    from pesr_amd import ops
+    assert ops.wino_eligible(16, 48, 48, 256, 256)
+    assert not ops.wino_eligible(16, 48, 47, 256, 256)          # odd width
+    assert not ops.wino_eligible(16, 48, 48, 256, 256, stride=2)
+    assert not ops.wino_eligible(16, 48, 48, 256, 1024, ps=True)
+    assert not ops.wino_eligible(16, 12, 12, 512, 512)          # too few tiles: the direct kernel splits K instead
+    assert not ops.wino_eligible(16, 48, 48, 256, 64)
