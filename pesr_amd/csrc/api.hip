@@ -144,12 +144,14 @@ PESR_API int pesr_conv3x3_rgb_dgrad(const float* dy, const float* w, float* dx, 
 PESR_API int pesr_conv3x3_wino_supported(int N, int H, int W, int Cin, int Cout) {
     return pesr_conv3x3_wino_supported_impl(N, H, W, Cin, Cout);
 }
-PESR_API int pesr_pack_conv3x3_wino(const float* w, float* w_packed, int Cout, int Cin, int mode, void* stream) {
-    return pesr_pack_conv3x3_wino_launch(w, w_packed, Cout, Cin, mode, (hipStream_t)stream);
+PESR_API int pesr_pack_conv3x3_wino(const float* w, float* w_packed, int Cout, int Cin, int mode, int ps, void* stream) {
+    return pesr_pack_conv3x3_wino_launch(w, w_packed, Cout, Cin, mode, ps, (hipStream_t)stream);
 }
 PESR_API int pesr_conv3x3_wino(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask,
-                               float* y, int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, void* stream) {
-    return pesr_conv3x3_wino_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, (hipStream_t)stream);
+                               float* y, int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out,
+                               int ps_in, void* stream) {
+    return pesr_conv3x3_wino_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, ps_out, ps_in,
+                                    (hipStream_t)stream);
 }
 
 PESR_API int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, void* stream) {

@@ -40,6 +40,8 @@ struct WinoArgs {
     int HT, WT;         // raw halo: TR + 2 rows x 2*TXT + 2 columns
     float alpha, slope;
     int act;
+    int ps;             // 1: output stored pixel-shuffled (r = 2): packed channel (2*si+sj)*C + c -> y[n][2oy+si][2ox+sj][c], C = Cout/4
+    int ps_in;          // 1: x is a pixel-shuffled tensor [N][2H][2W][Cin/4] read as its sub-pixel-major [N][H][W][Cin] view
 };
 
 constexpr int WINO_NT = 512, WINO_BN = 128, WINO_MG = 9, WINO_RING = 8;
@@ -89,15 +91,24 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
         if (hp < halo_pix) {
             const int hy = hp / a.WT, hx = hp - hy * a.WT;
             const int iy = gy0 - 1 + hy, ix = 2 * gt0 - 1 + hx;
-            off = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (iy * a.W + ix) * a.Cin + q * 4 : -1;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                off = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * (a.Cin >> 2) + q * 4 : (iy * a.W + ix) * a.Cin + q * 4;
+            else
+                off = -1;
         }
         h_src[k] = off;
     }
     auto dma_raw = [&](int c) {
+        int coff = c * 16;
+        if (a.ps_in) {   // chunk c = channels [16c, 16c+16) of sub-pixel `sub`: one pixel of the shuffled tensor
+            const int C = a.Cin >> 2;
+            const int sub = coff / C, cc0 = coff - sub * C;
+            coff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * C + cc0;
+        }
 #pragma unroll
         for (int k = 0; k < WINO_HL; ++k) {
             if (h_src[k] != -2) {
-                const float* src = h_src[k] >= 0 ? xi_img + h_src[k] + c * 16 : g_wino_zero16;
+                const float* src = h_src[k] >= 0 ? xi_img + h_src[k] + coff : g_wino_zero16;
                 wino_dma16(src, raw + (wave + k * 8) * 1024);
             }
         }
@@ -216,7 +227,14 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
         const int oy = gy0 + py, ox = 2 * gt0 + px;
         if (oy >= a.H || ox >= a.W) continue;
         f32x4 v = *(const f32x4*)(ob + p * RS + c4 * 16);
-        const size_t idx = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+        size_t idx;
+        if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
+            const int C = a.Cout >> 2;
+            const int sub = co / C, cc = co - sub * C;
+            idx = (((size_t)img * (2 * a.H) + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1)) * C + cc;
+        } else {
+            idx = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+        }
         if (a.bias) v += *(const f32x4*)(a.bias + co);
         v *= a.alpha;
         if (a.mask) {
@@ -236,17 +254,17 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // weight transform + packing (wino_pack.h)
-__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode) {
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode, int ps) {
     const long total = 12L * O * I;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
-        out[e] = pesr_wino_pack_elem(w, O, I, mode, e);
+        out[e] = pesr_wino_pack_elem(w, O, I, mode, ps, e);
 }
 
-int pesr_pack_conv3x3_wino_launch(const float* w, float* out, int O, int I, int mode, hipStream_t stream) {
-    if (O % 16 || I % 16 || (mode != 0 && mode != 1)) return PESR_EINVAL;
+int pesr_pack_conv3x3_wino_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream) {
+    if (O % 16 || I % 16 || (mode != 0 && mode != 1) || (ps && O % 64)) return PESR_EINVAL;
     const long total = 12L * O * I;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid), dim3(256), 0, stream, w, out, O, I, mode);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid), dim3(256), 0, stream, w, out, O, I, mode, ps);
     return pesr_launch_status();
 }
 
@@ -255,12 +273,15 @@ int pesr_conv3x3_wino_supported_impl(int N, int H, int W, int Cin, int Cout) {
 }
 
 int pesr_conv3x3_wino_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
-                             int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, hipStream_t stream) {
+                             int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
+                             hipStream_t stream) {
     if (!pesr_conv3x3_wino_supported_impl(N, H, W, Cin, Cout)) return PESR_EINVAL;
+    if (ps && (Cout % 16 || skip || mask)) return PESR_EINVAL;
+    if (ps_in && Cin % 64) return PESR_EINVAL;
     WinoArgs a{};
     a.x = x; a.wp = wp; a.bias = bias; a.skip = skip; a.mask = mask; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.alpha = alpha; a.slope = slope; a.act = act;
+    a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
     // tile shape: TR x TXT == 144 x-tiles, least out-of-image area, within the LDS budget and the raw-halo DMA pieces
     const int XT = W / 2;
     long best = -1;

@@ -59,9 +59,10 @@ int pesr_reduce_rows_launch(const float* part, double* dsum, int nb, int ncols, 
 
 // 1-D Winograd F(2,3) variant of the stride-1 conv (conv3x3_wino.hip)
 int pesr_conv3x3_wino_supported_impl(int N, int H, int W, int Cin, int Cout);
-int pesr_pack_conv3x3_wino_launch(const float* w, float* out, int O, int I, int mode, hipStream_t stream);
+int pesr_pack_conv3x3_wino_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream);
 int pesr_conv3x3_wino_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
-                             int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, hipStream_t stream);
+                             int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
+                             hipStream_t stream);
 int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
                             float slope, hipStream_t stream);
 int pesr_conv_rgb_out_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream);

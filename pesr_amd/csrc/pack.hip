@@ -42,7 +42,7 @@ __global__ void pack_conv3x3_batched_kernel(const long long* __restrict__ desc) 
     if (mode >= 2) {   // Winograd packing (conv3x3_wino.hip): mode 2 = forward, 3 = dgrad
         const long total_w = 12L * O * I;
         for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total_w; e += (long)gridDim.x * blockDim.x)
-            out[e] = pesr_wino_pack_elem(w, O, I, mode - 2, e);
+            out[e] = pesr_wino_pack_elem(w, O, I, mode - 2, ps, e);
         return;
     }
     const long total = 9L * R * Nn;

@@ -3,7 +3,9 @@
 //   mode 1 (dgrad)  : g[kx] = w[o = 16c+k][i = n][2-ky][2-kx]   (the input gradient is the conv with the flipped kernel)
 //   U = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2]
 #pragma once
-__device__ __forceinline__ float pesr_wino_pack_elem(const float* __restrict__ w, int O, int I, int mode, long e) {
+// ps = 1: the conv feeds nn.PixelShuffle(2); its output channels are ordered sub-pixel-major like pack.hip does
+//         (packed p = sub*C + cc  <->  original o = 4*cc + sub, C = O/4).
+__device__ __forceinline__ float pesr_wino_pack_elem(const float* __restrict__ w, int O, int I, int mode, int ps, long e) {
     const int R = mode == 0 ? I : O, Nn = mode == 0 ? O : I;
     const int k = (int)(e & 15);
     long rest = e >> 4;
@@ -12,7 +14,9 @@ __device__ __forceinline__ float pesr_wino_pack_elem(const float* __restrict__ w
     const int t12 = (int)(rest / (R >> 4));
     const int ky = t12 >> 2, xi = t12 & 3;
     const int red = c * 16 + k;
-    const int o = mode == 0 ? n : red, i = mode == 0 ? red : n;
+    int o = mode == 0 ? n : red;
+    const int i = mode == 0 ? red : n;
+    if (ps) { const int C = O >> 2; const int sub = o / C, cc = o - sub * C; o = 4 * cc + sub; }
     const float* g = w + ((long)o * I + i) * 9 + (mode == 0 ? ky : 2 - ky) * 3;
     const float g0 = mode == 0 ? g[0] : g[2], g1 = g[1], g2 = mode == 0 ? g[2] : g[0];
     if (xi == 0) return g0;

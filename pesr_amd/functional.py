@@ -97,7 +97,7 @@ class PackedConvWeights:
         self._note(w)
         k = self._key(w)
         if self._kwf != k:
-            self._wfwd = ops.pack_conv3x3_wino(w.detach(), 0)
+            self._wfwd = ops.pack_conv3x3_wino(w.detach(), 0, self.ps)
             self._kwf = k
         return self._wfwd
 
@@ -105,21 +105,21 @@ class PackedConvWeights:
         self._note(w)
         k = self._key(w)
         if self._kwd != k:
-            self._wdgrad = ops.pack_conv3x3_wino(w.detach(), 1)
+            self._wdgrad = ops.pack_conv3x3_wino(w.detach(), 1, self.ps)
             self._kwd = k
         return self._wdgrad
 
     def for_fwd(self, w: torch.Tensor, x_shape, stride: int = 1):
         """Packed weights for y = conv(x, w): the Winograd packing where that kernel applies, else the direct one."""
         N, H, W, Cin = x_shape
-        if not self.ps and ops.wino_eligible(N, H, W, Cin, w.shape[0], stride):
+        if ops.wino_eligible(N, H, W, Cin, w.shape[0], stride):
             return self.wino_fwd(w)
         return self.fwd(w)
 
     def for_dgrad(self, w: torch.Tensor, x_shape, stride: int = 1):
         """Packed weights for dx of y = conv(x, w) with x of NHWC shape x_shape."""
         N, H, W, Cin = x_shape
-        if not self.ps and ops.wino_eligible(N, H, W, w.shape[0], Cin, stride):
+        if ops.wino_eligible(N, H, W, w.shape[0], Cin, stride):
             return self.wino_dgrad(w)
         return self.dgrad(w)
 
@@ -224,7 +224,7 @@ def repack_all(params) -> None:
             jobs.append((c, mode, (w.data_ptr(), buf.data_ptr(), O, I, mode, int(c.ps), (R + 15) // 16 * 16, 16 if Nn <= 16 else (Nn + 63) // 64 * 64)))
         for mode, wpk in ((2, c._wfwd), (3, c._wdgrad)):      # Winograd packings (batched kernel modes 2 / 3)
             if wpk is not None:
-                jobs.append((c, mode, (w.data_ptr(), wpk.t.data_ptr(), O, I, mode, 0, I if mode == 2 else O, O if mode == 2 else I)))
+                jobs.append((c, mode, (w.data_ptr(), wpk.t.data_ptr(), O, I, mode, int(c.ps), I if mode == 2 else O, O if mode == 2 else I)))
     if not jobs:
         return
     dev = jobs[0][0]._wref().device

@@ -106,27 +106,28 @@ class WinoPacked:
 USE_WINO = __import__("os").environ.get("PESR_WINO", "1") != "0"     # PESR_WINO=0: direct kernel everywhere
 
 
-def wino_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps: bool = False) -> bool:
-    """The Winograd kernel applies (stride 1, even width, Cout % 128 == 0, no fused PixelShuffle) AND its 288-pixel x
-    128-channel tiles fill the chip; small layers stay on the direct kernel (smaller tiles, split-K)."""
-    if not USE_WINO or stride != 1 or ps or W % 2 or Cin % 16 or Cin < 16 or Cout % 128:
+def wino_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1) -> bool:
+    """The Winograd kernel applies (stride 1, even width, Cout % 128 == 0) AND its 288-pixel x 128-channel tiles fill the
+    chip; small layers stay on the direct kernel (smaller tiles, split-K).  Cin / Cout are those of the problem the kernel
+    runs (for an input gradient: Cin = the forward conv's Cout and vice versa)."""
+    if not USE_WINO or stride != 1 or W % 2 or Cin % 64 or Cout % 128:
         return False
     return N * ((H * (W // 2) + 143) // 144) * (Cout // 128) >= 192
 
 
-def pack_conv3x3_wino(w: torch.Tensor, mode: int) -> WinoPacked:
-    """OIHW [O, I, 3, 3] -> transformed [12, R/16, Nn, 16] (mode 0: forward, mode 1: dgrad)."""
+def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacked:
+    """OIHW [O, I, 3, 3] -> transformed [12, R/16, Nn, 16] (mode 0: forward, mode 1: dgrad; ps: sub-pixel-major O order)."""
     _chk(w, "pack_conv3x3_wino.w")
     O, I = w.shape[0], w.shape[1]
     out = torch.empty(12 * O * I, dtype=torch.float32, device=w.device)
-    rc = _lib.lib().pesr_pack_conv3x3_wino(_p(w), _p(out), O, I, mode, _stream())
+    rc = _lib.lib().pesr_pack_conv3x3_wino(_p(w), _p(out), O, I, mode, int(ps), _stream())
     _lib.check(rc, f"pesr_pack_conv3x3_wino[{O}x{I},mode{mode}]")
     return WinoPacked(out)
 
 
-def _conv3x3_wino(x, wp: WinoPacked, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, what):
+def _conv3x3_wino(x, wp: WinoPacked, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, what, ps_out=False, ps_in=False):
     rc = _lib.lib().pesr_conv3x3_wino(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope,
-                                     _stream())
+                                     int(ps_out), int(ps_in), _stream())
     _lib.check(rc, f"pesr_conv3x3_wino[{what} {N}x{H}x{W}x{Cin}->{cout}]")
 
 
@@ -160,8 +161,8 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         wp = wp()
     L = _lib.lib()
     if isinstance(wp, WinoPacked):
-        assert stride == 1 and not ps_out
-        _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, "fwd")
+        assert stride == 1
+        _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, "fwd", ps_out=ps_out)
         rc = 0
     else:
         nws = L.pesr_conv3x3_workspace_bytes(N, OH, OW, cout)
@@ -189,8 +190,8 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
             assert t.shape == dx.shape
     L = _lib.lib()
     if isinstance(wpd, WinoPacked):     # the input gradient is the conv of dy with the flipped, transposed kernel
-        assert stride == 1 and not ps_in
-        _conv3x3_wino(dy, wpd, None, skip, mask, dx, N, H, W, cout, Cin, alpha, ACT_NONE, 0.0, "dgrad")
+        assert stride == 1
+        _conv3x3_wino(dy, wpd, None, skip, mask, dx, N, H, W, cout, Cin, alpha, ACT_NONE, 0.0, "dgrad", ps_in=ps_in)
         return dx
     nws = L.pesr_conv3x3_workspace_bytes(N, H, W, Cin) if stride == 1 else 0
     ws = workspace(nws, dy.device) if nws else None

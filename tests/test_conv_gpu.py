@@ -110,6 +110,13 @@ def test_conv3x3_pixel_shuffle_fused():
     dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dys), ps_in=True)
     _close(dw.cpu(), dw_ref, 1e-5)
     _close(db.cpu(), db_ref, 1e-5)
+    # the Winograd kernel with the same fusions (Upsampler convs 256 -> 1024 and their input gradients)
+    yw = ops.conv3x3_fwd(_nhwc(x), ops.pack_conv3x3_wino(w.cuda(), 0, ps=True), bp, Cout, ps_out=True)
+    _close(_nchw(yw), ref, 1e-5)
+    w2 = _rand(Cout, 128, 3, 3, seed=8, scale=0.1); x2 = _rand(N, 128, H, W, seed=9)
+    dx2_ref, _, _ = O.conv3x3_grads(x2, w2, dy)
+    dxw = ops.conv3x3_dgrad(_nhwc(dys), ops.pack_conv3x3_wino(w2.cuda(), 1, ps=True), (N, H, W, 128), ps_in=True)
+    _close(_nchw(dxw), dx2_ref, 1e-5)
 
 
 def test_conv3x3_determinism_race_screen():
@@ -197,6 +204,5 @@ def test_winograd_dispatch_rule():
     assert ops.wino_eligible(16, 48, 48, 256, 256)
     assert not ops.wino_eligible(16, 48, 47, 256, 256)          # odd width
     assert not ops.wino_eligible(16, 48, 48, 256, 256, stride=2)
-    assert not ops.wino_eligible(16, 48, 48, 256, 1024, ps=True)
     assert not ops.wino_eligible(16, 12, 12, 512, 512)          # too few tiles: the direct kernel splits K instead
     assert not ops.wino_eligible(16, 48, 48, 256, 64)
