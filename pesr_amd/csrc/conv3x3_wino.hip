@@ -12,7 +12,8 @@
 //
 // One workgroup = 144 x-tiles (TR rows x TXT tiles, 288 output pixels) x 128 output channels, 8 waves, each wave owning
 // 16 channels x 4 xi x 9 m-tiles of accumulators (144 VGPRs).  Per chunk the raw input halo arrives by LDS-DMA (one chunk
-// ahead), a cooperative pass turns it into V ([row][xi][x-tile][16ch], 64 B per entry like the direct kernel's halo) and
+// ahead), a cooperative pass turns it into V ([row][xi][x-tile][16ch], 64 B per entry, 16-byte k-groups XOR-swizzled by
+// (x-tile >> 2) & 3 so that fragment reads are bank-conflict free - the weights carry the same swizzle from pack time) and
 // the 12 slabs stream through an 8-slot LDS-DMA ring, one barrier per ky (4 slabs, 4608 MFMA cycles); fragments are
 // read one slab ahead into a second register set.  The output transform happens in registers before the tile leaves
 // through LDS as coalesced 16-byte stores with the usual fused epilogue (bias, scale, ReLU mask, skip, activation).
@@ -75,9 +76,9 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
     for (int i = 0; i < WINO_MG; ++i) {
         const int m = i * 16 + r;
         const int trow = m / a.TXT, txt = m - trow * a.TXT;
-        a_off[i] = (trow * 4 * a.TXT + txt) * 64 + g * 16;
+        a_off[i] = (trow * 4 * a.TXT + txt) * 64 + (g ^ ((txt >> 2) & 3)) * 16;   // k-group g of x-tile txt sits at g ^ ((txt>>2)&3)
     }
-    const int b_off = (wave * 16 + r) * 64 + g * 16;
+    const int b_off = (wave * 16 + r) * 64 + (g ^ ((r >> 2) & 3)) * 16;                  // same swizzle, baked into the packed weights
     const int xi_stride = a.TXT * 64;                      // bytes between the xi planes of a V row
 
     // raw halo: per-lane global offsets of this wave's DMA pieces (piece = 16 pixels x 64 B)
@@ -117,12 +118,16 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
     const float* const wn = a.wp + (size_t)n0 * 16 + wave * 256 + lane * 4;
     const size_t slab_stride = (size_t)a.Cout * 16;
     const int nslab = C16 * 12;
-    int sd = 0;                                            // DMA cursor (slab index); past the end it re-fetches the last slab
+    // DMA cursor: slab sd = (chunk cd, tap td) lives at wn + woff; past the last slab it stays there (harmless re-fetches)
+    int sd = 0, cd = 0, td = 0;
+    size_t woff = 0;
     auto dma_next = [&]() {
-        const int s = sd < nslab ? sd : nslab - 1;
-        const int c = s / 12, t12 = s - c * 12;
-        wino_dma16(wn + ((size_t)t12 * C16 + c) * slab_stride, ring + (sd & (WINO_RING - 1)) * WINO_SLAB + wave * 1024);
+        wino_dma16(wn + woff, ring + (sd & (WINO_RING - 1)) * WINO_SLAB + wave * 1024);
         ++sd;
+        if (sd < nslab) {
+            if (++td == 12) { td = 0; ++cd; woff = (size_t)cd * slab_stride; }
+            else woff += (size_t)C16 * slab_stride;
+        }
     };
     // raw -> V: item = (halo row, x-tile, 4-channel group)
     auto transform = [&]() {
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
             const char* src = raw + ((hrow * a.WT + 2 * txt) * 64 + q * 16);
             const f32x4 d0 = *(const f32x4*)(src), d1 = *(const f32x4*)(src + 64), d2 = *(const f32x4*)(src + 128),
                         d3 = *(const f32x4*)(src + 192);
-            char* dst = vbuf + ((hrow * 4 * a.TXT + txt) * 64 + q * 16);
+            char* dst = vbuf + ((hrow * 4 * a.TXT + txt) * 64 + (q ^ ((txt >> 2) & 3)) * 16);
             *(f32x4*)(dst) = d0 - d2;
             *(f32x4*)(dst + xi_stride) = d1 + d2;
             *(f32x4*)(dst + 2 * xi_stride) = d2 - d1;
@@ -148,17 +153,22 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
 #pragma unroll
         for (int i = 0; i < WINO_MG; ++i) acc[x4][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 fa0[WINO_MG], fa1[WINO_MG], fb0, fb1;            // two fragment sets, statically indexed
-#define WINO_READ_A(FA, KY, XI)                                                                          \
+    // Fragments: the 9 m-tiles of a slab are walked in 3 groups of 3; while a group's 12 MFMAs run (k-step outer, m-tile
+    // inner: an accumulator is revisited every 3rd MFMA) the next group's 3 A fragments are read into the other half of
+    // fa[], and the next slab's B fragment into the other fb[] - 24 + 8 fragment VGPRs next to the 144 accumulators.
+    // The weight ring needs no barrier: a wave reads only the 16 channels (1 KiB of every slab) that it DMA'd itself, so
+    // s_waitcnt vmcnt(0) once per ky is enough; barriers only fence the shared raw / V buffers, twice per chunk.
+    f32x4 fa[2][3], fb[2];
+#define WINO_READ_A(FA, KY, XI, GRP)                                                                     \
     {                                                                                                    \
         const char* const vb_ = vbuf + ((KY) * 4 + (XI)) * xi_stride;                                    \
-        _Pragma("unroll") for (int i = 0; i < WINO_MG; ++i) FA[i] = *(const f32x4*)(vb_ + a_off[i]);      \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) FA[i] = *(const f32x4*)(vb_ + a_off[(GRP) * 3 + i]); \
     }
 #define WINO_READ_B(FB, S_) FB = *(const f32x4*)(ring + ((S_) & (WINO_RING - 1)) * WINO_SLAB + b_off);
-#define WINO_MFMA(FA, FB, XI)                                                                            \
+#define WINO_MFMA(FA, FB, XI, GRP)                                                                       \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
-        _Pragma("unroll") for (int i = 0; i < WINO_MG; ++i)                                              \
-            acc[XI][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[i][kk], FB[kk], acc[XI][i], 0, 0, 0);
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
+            acc[XI][(GRP) * 3 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[i][kk], FB[kk], acc[XI][(GRP) * 3 + i], 0, 0, 0);
 
     // ---- prologue: chunk 0's halo, slabs 0..4 ------------------------------------------------------------------------------
     dma_raw(0);
@@ -167,36 +177,35 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
     transform();
     __syncthreads();
     if (C16 > 1) dma_raw(1);
-    WINO_READ_B(fb0, 0)
-    int s = 0;                                             // slab being multiplied
+    WINO_READ_B(fb[0], 0)
+    int s = 0;                                             // first slab of the current ky step
 #pragma unroll 1
     for (int c = 0; c < C16; ++c) {
-        WINO_READ_A(fa0, 0, 0)                             // V of this chunk exists only now; the slab's B fragment is already in fb0
+        WINO_READ_A(fa[0], 0, 0, 0)                        // V of this chunk exists only now; the slab's B fragment is already in fb[0]
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            dma_next(); dma_next(); dma_next(); dma_next(); // slabs s+5 .. s+8 -> the slots of s-3 .. s (all read)
-            // xi = 0
-            WINO_READ_A(fa1, ky, 1) WINO_READ_B(fb1, s + 1)
-            WINO_MFMA(fa0, fb0, 0)
-            // xi = 1
-            WINO_READ_A(fa0, ky, 2) WINO_READ_B(fb0, s + 2)
-            WINO_MFMA(fa1, fb1, 1)
-            // xi = 2
-            WINO_READ_A(fa1, ky, 3) WINO_READ_B(fb1, s + 3)
-            WINO_MFMA(fa0, fb0, 2)
-            // xi = 3: prefetch the next ky's first slab; across a chunk boundary only its B half (V is rebuilt below)
-            if (ky < 2) WINO_READ_A(fa0, ky + 1, 0)
-            WINO_READ_B(fb0, s + 4)
-            WINO_MFMA(fa1, fb1, 3)
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's pieces of slabs s+1 .. s+4 (issued a step ago) are in LDS
+            dma_next(); dma_next(); dma_next(); dma_next(); // slabs s+5 .. s+8 -> the slots of s-3 .. s (read by this wave already)
+#pragma unroll
+            for (int st = 0; st < 12; ++st) {
+                const int xi = st / 3, grp = st % 3, cur = st & 1;
+                if (st < 11) WINO_READ_A(fa[cur ^ 1], ky, (st + 1) / 3, (st + 1) % 3)
+                else if (ky < 2) WINO_READ_A(fa[cur ^ 1], ky + 1, 0, 0)     // across a chunk boundary V is rebuilt first
+                if (grp == 0) WINO_READ_B(fb[(xi & 1) ^ 1], s + xi + 1)
+                __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of the MFMA group (hipcc sinks it next to its use)
+                WINO_MFMA(fa[cur], fb[xi & 1], xi, grp)
+                __builtin_amdgcn_sched_barrier(0);
+            }
             s += 4;
-            __syncthreads();                               // publishes the slabs DMA'd in this step; frees the ones read
         }
         if (c + 1 < C16) {
-            transform();                                   // raw holds chunk c+1 (DMA'd a chunk ago, retired by the barriers since)
+            __syncthreads();                               // every wave is done with V; raw holds chunk c+1 (DMA'd a chunk ago)
+            transform();
             __syncthreads();
             if (c + 2 < C16) dma_raw(c + 2);
         }
     }
+    __syncthreads();
 #undef WINO_READ_A
 #undef WINO_READ_B
 #undef WINO_MFMA
