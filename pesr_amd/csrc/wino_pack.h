@@ -7,11 +7,11 @@
 //         (packed p = sub*C + cc  <->  original o = 4*cc + sub, C = O/4).
 __device__ __forceinline__ float pesr_wino_pack_elem(const float* __restrict__ w, int O, int I, int mode, int ps, long e) {
     const int R = mode == 0 ? I : O, Nn = mode == 0 ? O : I;
-    // bank swizzle of the LDS image (the slab is DMA'd verbatim): the 16-byte k-group kg of row n sits at position kg ^ ((n>>2)&3),
-    // so the 16 rows a fragment read touches per k-slot fall on 16 different 4-bank groups
+    // bank swizzle of the LDS image (the slab is DMA'd verbatim): the 16-byte k-group kg of row n sits at position kg ^ ((n>>1)&3),
+    // so the 16 rows a fragment read touches per k-slot fall on 8 different 16-byte slots of the 128-byte LDS window
     const int n_ = (int)((e >> 4) % (mode == 0 ? O : I));
     const int kpos = (int)(e & 15);
-    const int k = ((((kpos >> 2) ^ ((n_ >> 2) & 3)) << 2) | (kpos & 3));
+    const int k = ((((kpos >> 2) ^ ((n_ >> 1) & 3)) << 2) | (kpos & 3));
     long rest = e >> 4;
     const int n = (int)(rest % Nn); rest /= Nn;
     const int c = (int)(rest % (R >> 4));

@@ -10,8 +10,11 @@ w = (torch.rand(C, C, 3, 3, device="cuda") - 0.5) * 0.1
 b = torch.rand(C, device="cuda")
 dy = torch.rand(N, H, W, C, device="cuda") - 0.5
 wp, wpd = ops.pack_conv3x3(w, 0), ops.pack_conv3x3(w, 1)
+ww, wwd = ops.pack_conv3x3_wino(w, 0), ops.pack_conv3x3_wino(w, 1)     # Winograd F(2,3) kernel, same shapes
 for _ in range(6):
     ops.conv3x3_fwd(x, wp, b, C, act=ops.ACT_RELU)
     ops.conv3x3_dgrad(dy, wpd, (N, H, W, C), mask=x)
     ops.conv3x3_wgrad(x, dy)
+    ops.conv3x3_fwd(x, ww, b, C, act=ops.ACT_RELU)
+    ops.conv3x3_dgrad(dy, wwd, (N, H, W, C), mask=x)
 torch.cuda.synchronize()

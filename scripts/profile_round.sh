@@ -1,4 +1,4 @@
-export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/f2; mkdir -p $O; cd /tmp
+export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/f3; mkdir -p $O; cd /tmp
 timeout 400 python3 $R/bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench.json
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
 PESR_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/single -o run -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/single.log 2>&1
@@ -6,4 +6,4 @@ timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o ru
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/scripts/profile_k1.py > $O/pmc2.log 2>&1
 timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq -o run -- python3 $R/scripts/profile_k1.py > $O/pmc3.log 2>&1
 timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm -o run -- python3 $R/scripts/profile_k1.py > $O/pmc4.log 2>&1
-cd $R; find gpurun_out/f2 -name "*.csv" | head -20; cat $O/bench.json | cut -c1-150
+cd $R; find gpurun_out/f3 -name "*.csv" | head -20; cat $O/bench.json | cut -c1-150
