@@ -76,12 +76,12 @@ int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, in
  * `Conv` (model/basic.py:4-7).  w_packed: 12 * Cin * Cout floats from pesr_pack_conv3x3_wino (mode 0: forward weights from
  * OIHW [Cout][Cin][3][3]; mode 1: the input-gradient weights - then call with Cin/Cout of the gradient problem swapped).
  * ps / ps_out / ps_in: as for pesr_pack_conv3x3 / pesr_conv3x3_fwd / pesr_conv3x3_dgrad (fused PixelShuffle store, fused
- * pixel-unshuffle load). */
+ * pixel-unshuffle load).  workspace (optional, pesr_conv3x3_workspace_bytes): lets layers with few tiles split K. */
 int pesr_conv3x3_wino_supported(int N, int H, int W, int Cin, int Cout);
 int pesr_pack_conv3x3_wino(const float* w, float* w_packed, int Cout, int Cin, int mode, int ps, void* stream);
 int pesr_conv3x3_wino(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask, float* y,
                       int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in,
-                      void* stream);
+                      void* workspace, size_t ws_bytes, void* stream);
 
 /* Forward 3x3 conv from a 3-channel input, stride 1 (reference `embed` model/pesr.py:23, Discriminator features.0
  * model/pesr.py:53, vgg19 features.0): x [N][H][W][3], w OIHW [Cout][3][3][3] (NOT packed), y [N][H][W][Cout]. */

@@ -36,7 +36,7 @@ SIGNATURES.update({
     "pesr_conv3x3_wino_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "pesr_pack_conv3x3_wino": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "pesr_conv3x3_wino": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
-                                  c_int, _P]),
+                                  c_int, _P, c_size_t, _P]),
     "pesr_conv3x3_rgb_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "pesr_conv3x3_rgb_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "pesr_meanshift_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

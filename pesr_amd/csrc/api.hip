@@ -149,9 +149,9 @@ PESR_API int pesr_pack_conv3x3_wino(const float* w, float* w_packed, int Cout, i
 }
 PESR_API int pesr_conv3x3_wino(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask,
                                float* y, int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out,
-                               int ps_in, void* stream) {
+                               int ps_in, void* workspace, size_t ws_bytes, void* stream) {
     return pesr_conv3x3_wino_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, ps_out, ps_in,
-                                    (hipStream_t)stream);
+                                    workspace, ws_bytes, (hipStream_t)stream);
 }
 
 PESR_API int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, void* stream) {

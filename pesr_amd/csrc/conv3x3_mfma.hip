@@ -435,6 +435,14 @@ __global__ void conv_splitk_finish_kernel(const float* __restrict__ slab, const 
     }
 }
 
+int pesr_conv_splitk_finish_launch(const float* slab, const float* bias, const float* skip, const float* mask, float* y, long total,
+                                   int C, int ksplit, float alpha, int act, float slope, hipStream_t stream) {
+    const int fgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(fgrid), dim3(256), 0, stream, slab, bias, skip, mask, y, total, C, ksplit, alpha,
+                       act, slope);
+    return pesr_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------

@@ -16,8 +16,9 @@
 // (x-tile >> 1) & 3: the LDS serves a ds_read_b128 eight lanes (128 B = 32 banks) per clock, and with this key eight
 // consecutive x-tiles hit eight different 16-byte slots - SQ_LDS_BANK_CONFLICT drops from 40.7 M to 15.5 M per launch; the
 // weights carry the same swizzle from pack time) and
-// the 12 slabs stream through an 8-slot LDS-DMA ring, one barrier per ky (4 slabs, 4608 MFMA cycles); fragments are
-// read one slab ahead into a second register set.  The output transform happens in registers before the tile leaves
+// the 12 slabs stream through an 8-slot LDS-DMA ring that each wave fences for itself (it reads only the 1 KiB of a slab it
+// DMA'd); fragments are read one 3-m-tile group ahead.  Layers with too few tiles split the Cin chunks over workgroups
+// (raw partial sums + the direct kernel's fixed-order finish kernel).  The output transform happens in registers before the tile leaves
 // through LDS as coalesced 16-byte stores with the usual fused epilogue (bias, scale, ReLU mask, skip, activation).
 #include "common.h"
 #include "launchers.h"
@@ -45,6 +46,9 @@ struct WinoArgs {
     int act;
     int ps;             // 1: output stored pixel-shuffled (r = 2): packed channel (2*si+sj)*C + c -> y[n][2oy+si][2ox+sj][c], C = Cout/4
     int ps_in;          // 1: x is a pixel-shuffled tensor [N][2H][2W][Cin/4] read as its sub-pixel-major [N][H][W][Cin] view
+    int ksplit;         // > 1: the Cin chunks are split over ksplit workgroups per tile; raw partial sums go to slab[ks][...]
+    int chunks_per_split;
+    float* slab;
 };
 
 constexpr int WINO_NT = 512, WINO_BN = 128, WINO_MG = 9, WINO_RING = 8;
@@ -63,14 +67,18 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
 
-    int bid = blockIdx.x;
+    const int tiles_total = a.n_tiles * a.tiles_x * a.tiles_y * a.N;
+    const int ks = blockIdx.x / tiles_total;              // split-K slice (0 when ksplit == 1)
+    int bid = blockIdx.x - ks * tiles_total;
     const int nt = bid % a.n_tiles;  bid /= a.n_tiles;
     const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
     const int gy0 = ty * a.TR, gt0 = tx * a.TXT;          // first output row / first x-tile of the tile
     const int n0 = nt * WINO_BN;
-    const int C16 = a.Cin >> 4;
+    const int C16T = a.Cin >> 4;                           // chunks in the packed weights
+    const int CB = ks * a.chunks_per_split;                // this workgroup's chunk range [CB, CB + C16)
+    const int C16 = (C16T - CB) < a.chunks_per_split ? (C16T - CB) : a.chunks_per_split;
 
     // per-lane LDS offsets: A = V[row][xi][x-tile][16ch] (row and xi added per slab), B = slab[channel][16]
     int a_off[WINO_MG];
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
         h_src[k] = off;
     }
     auto dma_raw = [&](int c) {
-        int coff = c * 16;
+        int coff = (CB + c) * 16;
         if (a.ps_in) {   // chunk c = channels [16c, 16c+16) of sub-pixel `sub`: one pixel of the shuffled tensor
             const int C = a.Cin >> 2;
             const int sub = coff / C, cc0 = coff - sub * C;
@@ -122,13 +130,13 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
     const int nslab = C16 * 12;
     // DMA cursor: slab sd = (chunk cd, tap td) lives at wn + woff; past the last slab it stays there (harmless re-fetches)
     int sd = 0, cd = 0, td = 0;
-    size_t woff = 0;
+    size_t woff = (size_t)CB * slab_stride;
     auto dma_next = [&]() {
         wino_dma16(wn + woff, ring + (sd & (WINO_RING - 1)) * WINO_SLAB + wave * 1024);
         ++sd;
         if (sd < nslab) {
-            if (++td == 12) { td = 0; ++cd; woff = (size_t)cd * slab_stride; }
-            else woff += (size_t)C16 * slab_stride;
+            if (++td == 12) { td = 0; ++cd; woff = (size_t)(CB + cd) * slab_stride; }
+            else woff += (size_t)C16T * slab_stride;
         }
     };
     // raw -> V: item = (halo row, x-tile, 4-channel group)
@@ -246,6 +254,10 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
         } else {
             idx = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
         }
+        if (a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
+            *(f32x4*)(a.slab + (size_t)ks * ((size_t)a.N * a.H * a.W * a.Cout) + idx) = v;
+            continue;
+        }
         if (a.bias) v += *(const f32x4*)(a.bias + co);
         v *= a.alpha;
         if (a.mask) {
@@ -285,7 +297,7 @@ int pesr_conv3x3_wino_supported_impl(int N, int H, int W, int Cin, int Cout) {
 
 int pesr_conv3x3_wino_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
                              int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
-                             hipStream_t stream) {
+                             void* ws, size_t ws_bytes, hipStream_t stream) {
     if (!pesr_conv3x3_wino_supported_impl(N, H, W, Cin, Cout)) return PESR_EINVAL;
     if (ps && (Cout % 16 || skip || mask)) return PESR_EINVAL;
     if (ps_in && Cin % 64) return PESR_EINVAL;
@@ -319,7 +331,24 @@ int pesr_conv3x3_wino_launch(const float* x, const float* wp, const float* bias,
         (void)hipFuncSetAttribute((const void*)conv3x3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const long grid = (long)N * a.tiles_y * a.tiles_x * a.n_tiles;
-    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)grid), dim3(WINO_NT), lds, stream, a);
+    const long tiles = (long)N * a.tiles_y * a.tiles_x * a.n_tiles;
+    // split-K over the Cin chunks when the tiles alone cannot fill the 256 CUs (the 24x24 512-channel layers)
+    const int C16T = Cin / 16;
+    a.ksplit = 1; a.chunks_per_split = C16T; a.slab = (float*)ws;
+    const size_t out_bytes = (size_t)N * H * W * Cout * sizeof(float);
+    if (ws && tiles < 160 && !ps && C16T >= 8) {
+        int want = (int)((256 + tiles - 1) / tiles);
+        if (want > 8) want = 8;
+        if (want > C16T / 4) want = C16T / 4;
+        while (want > 1 && (size_t)want * out_bytes > ws_bytes) --want;
+        if (want > 1) {
+            a.chunks_per_split = (C16T + want - 1) / want;
+            a.ksplit = (C16T + a.chunks_per_split - 1) / a.chunks_per_split;
+        }
+    }
+    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)(tiles * a.ksplit)), dim3(WINO_NT), lds, stream, a);
+    if (a.ksplit > 1)
+        return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)(out_bytes / sizeof(float)), Cout, a.ksplit,
+                                              alpha, act, slope, stream);
     return pesr_launch_status();
 }

@@ -62,7 +62,9 @@ int pesr_conv3x3_wino_supported_impl(int N, int H, int W, int Cin, int Cout);
 int pesr_pack_conv3x3_wino_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream);
 int pesr_conv3x3_wino_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
                              int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
-                             hipStream_t stream);
+                             void* ws, size_t ws_bytes, hipStream_t stream);
+int pesr_conv_splitk_finish_launch(const float* slab, const float* bias, const float* skip, const float* mask, float* y, long total,
+                                   int C, int ksplit, float alpha, int act, float slope, hipStream_t stream);
 int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
                             float slope, hipStream_t stream);
 int pesr_conv_rgb_out_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream);

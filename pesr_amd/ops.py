@@ -112,7 +112,13 @@ def wino_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1) 
     runs (for an input gradient: Cin = the forward conv's Cout and vice versa)."""
     if not USE_WINO or stride != 1 or W % 2 or Cin % 64 or Cout % 128:
         return False
-    return N * ((H * (W // 2) + 143) // 144) * (Cout // 128) >= 192
+    per_img = (H * (W // 2) + 143) // 144
+    wgs = N * per_img * (Cout // 128)
+    if wgs >= 192:
+        return True
+    # fewer tiles: the kernel splits the Cin chunks over up to Cin/64 workgroups per tile - worth it while the 144-x-tile
+    # tiles are (nearly) full, i.e. from 24x24 images up
+    return per_img * 144 <= 1.15 * H * (W // 2) and wgs * min(8, Cin // 64) >= 192
 
 
 def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacked:
@@ -126,8 +132,11 @@ def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacke
 
 
 def _conv3x3_wino(x, wp: WinoPacked, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, what, ps_out=False, ps_in=False):
-    rc = _lib.lib().pesr_conv3x3_wino(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope,
-                                     int(ps_out), int(ps_in), _stream())
+    L = _lib.lib()
+    nws = L.pesr_conv3x3_workspace_bytes(N, H, W, cout) if not ps_out else 0     # split-K scratch for layers with few tiles
+    ws = workspace(nws, x.device) if nws else None
+    rc = L.pesr_conv3x3_wino(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope,
+                             int(ps_out), int(ps_in), _p(ws), nws, _stream())
     _lib.check(rc, f"pesr_conv3x3_wino[{what} {N}x{H}x{W}x{Cin}->{cout}]")
 
 

@@ -13,7 +13,7 @@ def wino(x, w, b=None, skip=None, mask=None, alpha=1.0, act=0, mode=0):
     assert L.pesr_pack_conv3x3_wino(w.data_ptr(), wp.data_ptr(), O, I, mode, 0, S()) == 0
     y = torch.empty(N, H, W, Cout, device="cuda")
     p = lambda t: None if t is None else t.data_ptr()
-    rc = L.pesr_conv3x3_wino(x.data_ptr(), wp.data_ptr(), p(b), p(skip), p(mask), y.data_ptr(), N, H, W, Cin, Cout, alpha, act, 0.0, 0, 0, S())
+    rc = L.pesr_conv3x3_wino(x.data_ptr(), wp.data_ptr(), p(b), p(skip), p(mask), y.data_ptr(), N, H, W, Cin, Cout, alpha, act, 0.0, 0, 0, None, 0, S())
     assert rc == 0, rc
     return y
 def nhwc(t): return t.permute(0, 2, 3, 1).contiguous().cuda()
@@ -54,5 +54,5 @@ def t(fn, it=20):
         e1.record(); torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1) / it * 1e3)
     return best
 td = t(lambda: L.pesr_conv3x3_fwd(x.data_ptr(), wpd.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1, 1.0, 1, 0.0, 0, None, 0, S()))
-tw = t(lambda: L.pesr_conv3x3_wino(x.data_ptr(), wpw.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1.0, 1, 0.0, 0, 0, S()))
+tw = t(lambda: L.pesr_conv3x3_wino(x.data_ptr(), wpw.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1.0, 1, 0.0, 0, 0, None, 0, S()))
 print(f"K1 shape: direct {td:.1f} us, winograd {tw:.1f} us  ({43.487e9 / tw / 1e6:.1f} algorithmic TFLOP/s)")

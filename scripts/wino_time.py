@@ -20,7 +20,7 @@ def run(l, it=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(it):
-        l.pesr_conv3x3_wino(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1.0, 1, 0.0, 0, 0, s)
+        l.pesr_conv3x3_wino(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1.0, 1, 0.0, 0, 0, None, 0, s)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it * 1e3
 for l in hs: run(l, 5)

@@ -175,6 +175,7 @@ WINO_CASES = [
     (1, 13, 96, 64, 256),
     (2, 5, 2, 16, 128),       # one pixel pair per row
     (1, 9, 194, 16, 128),     # wider than one tile
+    (2, 24, 24, 256, 256),    # few tiles: split-K over the Cin chunks + finish kernel
 ]
 
 
@@ -204,5 +205,6 @@ def test_winograd_dispatch_rule():
     assert ops.wino_eligible(16, 48, 48, 256, 256)
     assert not ops.wino_eligible(16, 48, 47, 256, 256)          # odd width
     assert not ops.wino_eligible(16, 48, 48, 256, 256, stride=2)
-    assert not ops.wino_eligible(16, 12, 12, 512, 512)          # too few tiles: the direct kernel splits K instead
+    assert ops.wino_eligible(16, 24, 24, 512, 512)              # 128 tiles: split-K over the Cin chunks fills the chip
+    assert not ops.wino_eligible(16, 12, 12, 512, 512)          # half-empty tiles: the direct kernel (smaller tiles) instead
     assert not ops.wino_eligible(16, 48, 48, 256, 64)
