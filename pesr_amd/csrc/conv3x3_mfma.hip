@@ -535,6 +535,9 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
 template <int S>
 static int dispatch(ConvArgs& a, int hext, int wext, hipStream_t stream) {
     const long M = (long)a.N * a.GH * a.GW;
+    // stride-2 conv to 64 channels (D features.1): the 144-pixel tile's halo (2x2 input pixels per output) leaves room for one
+    // 4-wave workgroup per CU only; 64-pixel tiles fit three (141 vs 185 us on 16x192x192x64)
+    if (S == 2 && a.ntaps == 9 && a.Cout == 64 && M >= 64 * 512) return launch_cfg<1, 4, 4, 1, S, 5>(a, hext, wext, stream);
     if (a.Cout % 256 == 0) {
         // enough tiles to fill 256 CUs with the big tile?
         const long tiles_big = (M / 144) * (a.Cout / 256);

@@ -24,6 +24,7 @@ shapes = [  # name, N, H, W, Cin, Cout, stride, ps
     ("RGB-out 256->3 @192", 16, 192, 192, 256, 3, 1, False),
     ("RGB-out 64->3 @192", 16, 192, 192, 64, 3, 1, False),
     ("D 64->64 s2 @192", 16, 192, 192, 64, 64, 2, False),
+    ("D 128->128 s2 @96", 16, 96, 96, 128, 128, 2, False),
     ("D 256->256 s2 @48", 16, 48, 48, 256, 256, 2, False),
     ("D 512->512 s2 @24", 16, 24, 24, 512, 512, 2, False),
 ]

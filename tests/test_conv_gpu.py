@@ -37,6 +37,7 @@ CASES = [
     (1, 24, 24, 128, 256, 2),
     (1, 20, 100, 64, 128, 1),  # wider than one 48-pixel wgrad segment: 3 segments per row, the last one ragged
     (1, 30, 70, 64, 64, 2),    # stride 2 with 2 segments per output row (OW = 35)
+    (4, 192, 192, 64, 64, 2),  # D features.1 at full resolution: the 64-pixel-tile forward config
 ]
 
 
