@@ -15,6 +15,7 @@
 // reproducible, no atomics) into the OIHW parameter layout, applying alpha and the pixel-shuffle channel
 // un-permutation.  The bias gradient (column sums of dy) is accumulated on the VALU from the A fragments.
 // Channel counts need only be multiples of 4: tiles that overhang Cin / Cout load zeros and skip their stores.
+#include <cstdlib>
 #include "common.h"
 #include "launchers.h"
 
@@ -405,10 +406,17 @@ static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
 }
 }  // namespace
 
+// PESR_WGRAD_WINO=0 keeps every layer on the direct kernel (A/B runs)
+static bool wgrad_wino_enabled() {
+    static const bool on = [] { const char* e = getenv("PESR_WGRAD_WINO"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int stride) {
     WgradPlan p;
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return 0;
-    return p.total_bytes;
+    const size_t ww = (stride == 1 && wgrad_wino_enabled()) ? pesr_conv3x3_wgrad_wino_ws_bytes(N, H, W, Cin, Cout) : 0;
+    return p.total_bytes > ww ? p.total_bytes : ww;
 }
 
 int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
@@ -417,6 +425,10 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return PESR_EINVAL;
     if (ws_bytes < p.total_bytes || !ws) return PESR_EWORKSPACE;
     if (ps_in && (stride != 1 || Cout % 16)) return PESR_EINVAL;
+    if (stride == 1 && wgrad_wino_enabled()) {   // the Winograd form where it applies (even width >= 48, 64-multiple channels)
+        const int rc = pesr_conv3x3_wgrad_wino_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, ws, ws_bytes, stream);
+        if (rc != PESR_EINVAL && rc != PESR_EWORKSPACE) return rc;
+    }
     WgradArgs a{};
     a.x = x; a.dy = dy; a.slab = (float*)ws;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;

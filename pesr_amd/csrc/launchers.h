@@ -57,6 +57,10 @@ int pesr_adam_launch(float* p, const float* g, float* m, float* v, long n, float
 // dsum[col] = sum_k part[k*ncols + col] in double, fixed order (reduce.hip)
 int pesr_reduce_rows_launch(const float* part, double* dsum, int nb, int ncols, hipStream_t stream);
 
+// transposed Winograd weight gradient (conv3x3_wgrad_wino.hip); the launch returns PESR_EINVAL for shapes it does not cover
+size_t pesr_conv3x3_wgrad_wino_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int pesr_conv3x3_wgrad_wino_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                                   float alpha, int ps_in, void* ws, size_t ws_bytes, hipStream_t stream);
 // 1-D Winograd F(2,3) variant of the stride-1 conv (conv3x3_wino.hip)
 int pesr_conv3x3_wino_supported_impl(int N, int H, int W, int Cin, int Cout);
 int pesr_pack_conv3x3_wino_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream);
