@@ -77,49 +77,65 @@ __global__ __launch_bounds__(WW_NT) void conv3x3_wgrad_wino_kernel(const WgWinoA
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    // Loads put RAW values into registers (an out-of-range element reads a dummy in-range address); zeroing, transform and
+    // ds_write happen in store_*() behind the MFMA block.  (With the select next to the load, hipcc waits for the load
+    // right there - vmcnt(0) in front of the MFMAs - and every segment pays the full global-memory latency.)
     f32x4 vx[4], dd[2];
-    auto load_vrow = [&](int img, int xs, int iy) {   // the four input columns of this thread's x-tile, row iy
-        const bool row_ok = v_thr && v_ch_ok && iy >= 0 && iy < a.H;
-        const int ix0 = xs * 48 + 2 * vt - 1;
-        const float* rowp = a.x + (((size_t)img * a.H + (row_ok ? iy : 0)) * a.W) * a.Cin + ci0 + vc4 * 4;
+    unsigned vmask = 0, dmask = 0;
+    // per strip, a thread's column offsets (floats from the start of an image row) and their validity are fixed; a segment
+    // only moves the wave-uniform row pointers
+    int v_off[4], d_off[2];
+    unsigned v_cols = 0, d_cols = 0;
+    auto set_strip = [&](int xs) {
+        v_cols = 0; d_cols = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ix = ix0 + j;
-            const bool ok = row_ok && ix >= 0 && ix < a.W;
-            const f32x4 v = *(const f32x4*)(rowp + (size_t)(ok ? ix : 0) * a.Cin);
-            vx[j] = ok ? v : zero4;
+            const int ix = xs * 48 + 2 * vt - 1 + j;
+            const bool ok = v_thr && v_ch_ok && ix >= 0 && ix < a.W;
+            v_off[j] = ok ? ix * a.Cin + ci0 + vc4 * 4 : 0;
+            v_cols |= ok ? (1u << j) : 0u;
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ox = xs * 48 + 2 * dt + j;
+            const bool ok = d_thr && d_ch_ok && ox < a.W;
+            d_off[j] = ok ? (a.ps_in ? 2 * ox * d_C : ox * a.Cout) + d_choff : 0;
+            d_cols |= ok ? (1u << j) : 0u;
+        }
+    };
+    auto load_vrow = [&](int img, int xs, int iy) {   // the four input columns of this thread's x-tile, row iy
+        const bool row_ok = iy >= 0 && iy < a.H;       // wave-uniform
+        const float* const rowp = a.x + ((size_t)img * a.H + (row_ok ? iy : 0)) * a.W * a.Cin;
+        vmask = row_ok ? v_cols : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vx[j] = *(const f32x4*)(rowp + v_off[j]);
     };
     auto store_vrow = [&](int slot) {
         if (v_thr) {
+            const f32x4 d0 = (vmask & 1u) ? vx[0] : zero4, d1 = (vmask & 2u) ? vx[1] : zero4, d2 = (vmask & 4u) ? vx[2] : zero4,
+                        d3 = (vmask & 8u) ? vx[3] : zero4;
             float* p = vring + slot * WW_SLOT + v_pos;
-            *(f32x4*)(p) = vx[0] - vx[2];
-            *(f32x4*)(p + WW_PLANE) = vx[1] + vx[2];
-            *(f32x4*)(p + 2 * WW_PLANE) = vx[2] - vx[1];
-            *(f32x4*)(p + 3 * WW_PLANE) = vx[1] - vx[3];
+            *(f32x4*)(p) = d0 - d2;
+            *(f32x4*)(p + WW_PLANE) = d1 + d2;
+            *(f32x4*)(p + 2 * WW_PLANE) = d2 - d1;
+            *(f32x4*)(p + 3 * WW_PLANE) = d1 - d3;
         }
     };
     auto load_dm = [&](int img, int xs, int oy) {     // the two output-gradient pixels of this thread's x-tile, row oy
-        const int ox0 = xs * 48 + 2 * dt;
+        const float* const rowp = a.ps_in ? a.dy + ((size_t)img * (2 * a.H) + 2 * oy) * (2 * a.W) * d_C
+                                          : a.dy + ((size_t)img * a.H + oy) * a.W * a.Cout;
+        dmask = d_cols;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ox = ox0 + j;
-            const bool ok = d_thr && d_ch_ok && ox < a.W;
-            size_t off = 0;
-            if (ok)
-                off = a.ps_in ? (((size_t)img * (2 * a.H) + 2 * oy) * (2 * a.W) + 2 * ox) * d_C + d_choff
-                              : (((size_t)img * a.H + oy) * a.W + ox) * a.Cout + d_choff;
-            const f32x4 v = *(const f32x4*)(a.dy + off);
-            dd[j] = ok ? v : zero4;
-        }
+        for (int j = 0; j < 2; ++j) dd[j] = *(const f32x4*)(rowp + d_off[j]);
     };
     auto store_dm = [&](int buf) {
         if (d_thr) {
+            const f32x4 g0 = (dmask & 1u) ? dd[0] : zero4, g1 = (dmask & 2u) ? dd[1] : zero4;
             float* p = dmbuf + buf * WW_SLOT + d_pos;
-            *(f32x4*)(p) = dd[0];
-            *(f32x4*)(p + WW_PLANE) = dd[0] + dd[1];
-            *(f32x4*)(p + 2 * WW_PLANE) = dd[0] - dd[1];
-            *(f32x4*)(p + 3 * WW_PLANE) = zero4 - dd[1];
+            *(f32x4*)(p) = g0;
+            *(f32x4*)(p + WW_PLANE) = g0 + g1;
+            *(f32x4*)(p + 2 * WW_PLANE) = g0 - g1;
+            *(f32x4*)(p + 3 * WW_PLANE) = zero4 - g1;
         }
     };
     auto seg_coords = [&](int seg, int& img, int& xs, int& row) {
@@ -136,6 +152,7 @@ __global__ __launch_bounds__(WW_NT) void conv3x3_wgrad_wino_kernel(const WgWinoA
     if (seg_begin >= seg_end) return;                       // (never: the planner hands every workgroup at least one segment)
     int img, xs, row;
     seg_coords(seg_begin, img, xs, row);
+    set_strip(xs);
     // prologue: rows row-1, row, row+1 -> slots 0, 1, 2; dM(row) -> buffer 0
 #pragma unroll 1
     for (int k = 0; k < 3; ++k) { load_vrow(img, xs, row - 1 + k); store_vrow(k); }
@@ -181,6 +198,7 @@ __global__ __launch_bounds__(WW_NT) void conv3x3_wgrad_wino_kernel(const WgWinoA
         }
 #undef WW_READ
 #undef WW_MFMA
+        __builtin_amdgcn_sched_barrier(0);                  // the staging stores (and their vmcnt wait) stay behind the MFMA block
         if (cont) {
             store_vrow((base + 3) & 3);                     // row + 2 -> the slot of row - 1, which the next segment drops
             store_dm(par ^ 1);
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(WW_NT) void conv3x3_wgrad_wino_kernel(const WgWinoA
         } else if (more) {                                  // new strip / image: its three halo rows are staged from scratch
             __syncthreads();
             seg_coords(seg + 1, img, xs, row);
+            set_strip(xs);
 #pragma unroll 1
             for (int k = 0; k < 3; ++k) { load_vrow(img, xs, row - 1 + k); store_vrow(k); }
             load_dm(img, xs, row); store_dm(par ^ 1);
@@ -318,6 +337,9 @@ int pesr_conv3x3_wgrad_wino_launch(const float* x, const float* dy, float* dw, f
     }
     const int grid = p.split * p.co_tiles * p.ci_tiles;
     hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3(grid), dim3(WW_NT), lds, stream, a);
+#ifdef WW_SKIP_REDUCE
+    return 0;
+#endif
     const long units = 3L * Cout * Cin / 4;
     const int rgrid = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
     hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in,
