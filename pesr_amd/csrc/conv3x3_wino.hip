@@ -140,21 +140,36 @@ __global__ __launch_bounds__(WINO_NT) void conv3x3_wino_kernel(const WinoArgs a)
         }
     };
     // raw -> V: item = (halo row, x-tile, 4-channel group)
+    // (at most 2 items per thread: HT*WT <= 512 pixels; both items' reads are issued before the first write, and the item
+    //  coordinates - the same for every chunk - are computed once)
+    const int tr_items = a.HT * a.TXT * 4;
+    int tr_src[2], tr_dst[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = tid + u * WINO_NT;
+        const int q = it & 3, rest = it >> 2;
+        const int hrow = rest / a.TXT, txt = rest - hrow * a.TXT;
+        tr_src[u] = it < tr_items ? (hrow * a.WT + 2 * txt) * 64 + q * 16 : -1;
+        tr_dst[u] = (hrow * 4 * a.TXT + txt) * 64 + (q ^ ((txt >> 1) & 3)) * 16;
+    }
     auto transform = [&]() {
-        const int items = a.HT * a.TXT * 4;
-        for (int it = tid; it < items; it += WINO_NT) {
-            const int q = it & 3;
-            const int rest = it >> 2;
-            const int hrow = rest / a.TXT, txt = rest - hrow * a.TXT;
-            const char* src = raw + ((hrow * a.WT + 2 * txt) * 64 + q * 16);
-            const f32x4 d0 = *(const f32x4*)(src), d1 = *(const f32x4*)(src + 64), d2 = *(const f32x4*)(src + 128),
-                        d3 = *(const f32x4*)(src + 192);
-            char* dst = vbuf + ((hrow * 4 * a.TXT + txt) * 64 + (q ^ ((txt >> 1) & 3)) * 16);
-            *(f32x4*)(dst) = d0 - d2;
-            *(f32x4*)(dst + xi_stride) = d1 + d2;
-            *(f32x4*)(dst + 2 * xi_stride) = d2 - d1;
-            *(f32x4*)(dst + 3 * xi_stride) = d1 - d3;
-        }
+        f32x4 d[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tr_src[u] >= 0) {
+                const char* src = raw + tr_src[u];
+                d[u][0] = *(const f32x4*)(src); d[u][1] = *(const f32x4*)(src + 64);
+                d[u][2] = *(const f32x4*)(src + 128); d[u][3] = *(const f32x4*)(src + 192);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tr_src[u] >= 0) {
+                char* dst = vbuf + tr_dst[u];
+                *(f32x4*)(dst) = d[u][0] - d[u][2];
+                *(f32x4*)(dst + xi_stride) = d[u][1] + d[u][2];
+                *(f32x4*)(dst + 2 * xi_stride) = d[u][2] - d[u][1];
+                *(f32x4*)(dst + 3 * xi_stride) = d[u][1] - d[u][3];
+            }
     };
 
     f32x4 acc[4][WINO_MG];
