@@ -77,6 +77,11 @@ def lib() -> ctypes.CDLL:
             raise PesrHipError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m pesr_amd.build` "
                 "(or __graft_entry__.build()). pesr_amd has no CPU fallback.")
+        # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE libpesr_hip.so
+        # is loaded, so that the library's libamdhip64 dependency binds to that same runtime; loaded first, the library would
+        # pull in /opt/rocm's copy and its kernels would then launch into a runtime that never saw torch's device context
+        # (hipErrorNoDevice on the first launch).
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             try:

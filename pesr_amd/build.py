@@ -28,7 +28,7 @@ def _digest() -> str:
     files = _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     files.append(os.path.join(HERE, "..", "include", "pesr_hip.h"))
     for f in files:
-        h.update(f.encode())
+        h.update(os.path.basename(f).encode())      # names, not absolute paths: the tree is moved to the GPU box as it is
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
