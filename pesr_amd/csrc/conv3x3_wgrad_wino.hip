@@ -303,7 +303,7 @@ static bool ww_plan(int N, int H, int W, int Cin, int Cout, WwPlan* p) {
     // whole strips per workgroup where possible: a strip change re-stages three halo rows synchronously
     if (p->segs_per_split > H) p->segs_per_split = (p->segs_per_split + H - 1) / H * H;
     p->split = (p->total_segs + p->segs_per_split - 1) / p->segs_per_split;
-    if ((long)tiles * p->split < 128) return false;        // cannot fill the chip: leave it to the direct kernel
+    if ((long)tiles * p->split < 8) return false;          // a handful of workgroups: leave it to the direct kernel
     p->slab_bytes = ((size_t)p->split * 12 * Cout * Cin * sizeof(float) + 255) / 256 * 256;
     p->total_bytes = p->slab_bytes + (size_t)Cout * sizeof(double) + (size_t)p->split * Cout * sizeof(float) + 1024;
     return true;

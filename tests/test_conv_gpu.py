@@ -209,3 +209,31 @@ def test_winograd_dispatch_rule():
     assert ops.wino_eligible(16, 24, 24, 512, 512)              # 128 tiles: split-K over the Cin chunks fills the chip
     assert not ops.wino_eligible(16, 12, 12, 512, 512)          # half-empty tiles: the direct kernel (smaller tiles) instead
     assert not ops.wino_eligible(16, 48, 48, 256, 64)
+
+
+def test_winograd_random_shape_sweep():
+    """Seeded sweep of the Winograd kernels over odd heights, ragged widths (partial tiles, partial last strip), batch sizes
+    and channel counts: forward, input gradient and - through the ordinary wgrad entry point, which picks the Winograd form
+    where it applies - weight + bias gradient."""
+    from pesr_amd import ops
+    import random
+    rng = random.Random(11)
+    for it in range(10):
+        N = rng.choice([1, 2, 3]); H = rng.randint(1, 30); W = 2 * rng.randint(1, 50)
+        Cin = rng.choice([16, 64, 128]); Cout = rng.choice([128, 256])
+        x = _rand(N, Cin, H, W, seed=500 + it); w = _rand(Cout, Cin, 3, 3, seed=600 + it, scale=0.1); b = _rand(Cout, seed=700 + it)
+        ref = O.conv3x3(x, w, b)
+        y = ops.conv3x3_fwd(_nhwc(x), ops.pack_conv3x3_wino(w.cuda(), 0), b.cuda(), Cout)
+        _close(_nchw(y), ref, 1e-5)
+        if Cin % 128 == 0:
+            dy = _rand(N, Cout, H, W, seed=800 + it)
+            dx_ref, _, _ = O.conv3x3_grads(x, w, dy)
+            dx = ops.conv3x3_dgrad(_nhwc(dy), ops.pack_conv3x3_wino(w.cuda(), 1), (N, H, W, Cin))
+            _close(_nchw(dx), dx_ref, 1e-5)
+    for it, (N, H, W, Cin, Cout) in enumerate([(2, 9, 48, 64, 64), (1, 5, 94, 64, 128), (3, 4, 96, 128, 64), (1, 50, 48, 64, 192),
+                                               (2, 3, 144, 64, 64)]):
+        x = _rand(N, Cin, H, W, seed=900 + it); w = _rand(Cout, Cin, 3, 3, seed=910 + it, scale=0.1)
+        dy = _rand(N, Cout, H, W, seed=920 + it)
+        _, dw_ref, db_ref = O.conv3x3_grads(x, w, dy)
+        dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1)
+        _close(dw.cpu(), dw_ref, 2e-5); _close(db.cpu(), db_ref, 2e-5)
