@@ -194,14 +194,20 @@ __global__ __launch_bounds__(WW_NT) void conv3x3_wgrad_wino_kernel(const WgWinoA
             WW_READ(av1, bv1, k4 + 1)
             WW_MFMA(av0, bv0)
             if (k4 + 2 < WW_TXT / 4) WW_READ(av0, bv0, k4 + 2)
+            if (k4 == 4) {
+                // The staging stores go to LDS that nobody reads in this segment (the free ring slot, the other dM buffer),
+                // so they need not wait for the end of the MFMA block: placed here - two thirds in, the loads have landed -
+                // their ds_writes run under the last MFMAs, and only the barrier is left at the end of the segment.
+                __builtin_amdgcn_sched_barrier(0);
+                if (cont) { store_vrow((base + 3) & 3); store_dm(par ^ 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             WW_MFMA(av1, bv1)
         }
 #undef WW_READ
 #undef WW_MFMA
-        __builtin_amdgcn_sched_barrier(0);                  // the staging stores (and their vmcnt wait) stay behind the MFMA block
-        if (cont) {
-            store_vrow((base + 3) & 3);                     // row + 2 -> the slot of row - 1, which the next segment drops
-            store_dm(par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cont) {                                         // row + 2 went to the slot of row - 1, which the next segment drops
             __syncthreads();
             base = (base + 1) & 3; ++row;
         } else if (more) {                                  // new strip / image: its three halo rows are staged from scratch
