@@ -269,14 +269,23 @@ __global__ void wgrad_wino_reduce_kernel(const float* __restrict__ slab, float* 
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < 3 * plane4; e += (long)gridDim.x * blockDim.x) {
         const int ky = (int)(e / plane4);
         const long q = e - ky * plane4;                    // (co, ci4)
-        f32x4 u[4];
+        f32x4 u[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const f32x4* src = slab4 + (size_t)(ky * 4) * plane4 + q;
+        int k = 0;
+        for (; k + 4 <= split; k += 4) {      // 16 independent 16-byte loads in flight; each xi still sums its splits in slab order
+            f32x4 v[4][4];
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            const f32x4* src = slab4 + (size_t)(ky * 4 + xi) * plane4 + q;
-            for (int k = 0; k < split; ++k) s += src[(size_t)k * total4];
-            u[xi] = s;
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) v[kk][xi] = src[(size_t)(k + kk) * total4 + (size_t)xi * plane4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) u[xi] += v[kk][xi];
         }
+        for (; k < split; ++k)
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) u[xi] += src[(size_t)k * total4 + (size_t)xi * plane4];
         const f32x4 h = 0.5f * (u[1] + u[2]);
         const f32x4 w0 = alpha * (u[0] + h), w1 = alpha * (0.5f * (u[1] - u[2])), w2 = alpha * (h + u[3]);
         const int ci = (int)((q * 4) % Cin);
