@@ -28,7 +28,7 @@ def wrap(name):
     setattr(ops, name, g)
 for n in ["conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "conv3x3_wgrad_rgb", "conv3x3_rgb_dgrad", "bn_lrelu_fwd", "bn_lrelu_bwd", "linear_fwd", "linear_dgrad",
           "linear_wgrad", "maxpool2x2_fwd", "maxpool2x2_bwd", "meanshift_fwd", "meanshift_bwd", "relu_mask", "loss_l1_tv", "loss_mse",
-          "adam_step", "pack_conv3x3", "pixel_shuffle_fwd", "pixel_shuffle_bwd"]:
+          "adam_step", "pack_conv3x3", "pack_conv3x3_wino", "pixel_shuffle_fwd", "pixel_shuffle_bwd"]:
     wrap(n)
 
 torch.manual_seed(0)
