@@ -137,7 +137,10 @@ class PackedConvWeights:
 # kernels only consume their outputs, so with two streams the workgroups of a wgrad fill the CUs that the previous
 # dgrad frees during its tail (each 256-workgroup launch otherwise idles the matrix pipes for ~25 us of ramp + epilogue).
 _SIDE = {}
-USE_SIDE_STREAM = __import__("os").environ.get("PESR_SIDE_STREAM", "1") != "0"   # PESR_SIDE_STREAM=0: everything on one stream
+# PESR_SIDE_STREAM: "0" everything on one stream, "1" every conv block's wgrad on the side stream, "g" only the blocks
+# without BatchNorm (the Generator's), "d" only the conv+BN blocks (the Discriminator's)
+SIDE_MODE = __import__("os").environ.get("PESR_SIDE_STREAM", "0")
+USE_SIDE_STREAM = SIDE_MODE != "0"
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -171,8 +174,8 @@ class _OnSide:
     backward pass).  Anything else - a temporary that autograd itself will add to another contribution on the main
     stream - makes the main stream wait for the side stream on exit (`fast=False`)."""
 
-    def __init__(self, device, *tensors, fast=False):
-        self.enabled = USE_SIDE_STREAM
+    def __init__(self, device, *tensors, fast=False, where="g"):
+        self.enabled = SIDE_MODE == "1" or SIDE_MODE == where
         self.fast, self.device = fast, device
         if self.enabled:
             if not _JOIN_QUEUED[0]:
@@ -430,7 +433,7 @@ class ConvBnLReluFn(Function):
         wpd = ctx.cache.for_dgrad(weight, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
         if ctx.needs_input_grad[1]:
             o_w = grad_out(weight)
-            with _OnSide(dz.device, x, dz, fast=o_w is not None):
+            with _OnSide(dz.device, x, dz, fast=o_w is not None, where="d"):
                 if x.shape[3] == 3:
                     dw, _ = ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=False, dw_out=o_w)
                 else:
