@@ -133,10 +133,10 @@ class PackedConvWeights:
         return self._bias
 
 
-# Weight-gradient kernels run on a side stream: in a backward chain the dgrad kernels depend on each other but the wgrad
-# kernels only consume their outputs, so with two streams the workgroups of a wgrad fill the CUs that the previous
-# dgrad frees during its tail (each 256-workgroup launch otherwise idles the matrix pipes for ~25 us of ramp + epilogue).
-_SIDE = {}
+# Optional side stream for the weight-gradient kernels (off by default): in a backward chain the dgrad kernels
+# depend on each other but the wgrad kernels only consume their outputs, so with two streams the workgroups of a wgrad can
+# fill the CUs that the previous dgrad frees during its tail.  It paid with the direct kernels; with the Winograd kernels
+# the fork / join costs more than the tails it fills.
 # PESR_SIDE_STREAM: "0" everything on one stream, "1" every conv block's wgrad on the side stream, "g" only the blocks
 # without BatchNorm (the Generator's), "d" only the conv+BN blocks (the Discriminator's)
 SIDE_MODE = __import__("os").environ.get("PESR_SIDE_STREAM", "0")

@@ -120,7 +120,7 @@ class GradBuckets:
         lo, hi = self.bounds[b]
         self._launched[b] = True
         if self.flat.flat_g.is_cuda:
-            PF.join_side_stream(self.flat.flat_g.device)    # weight gradients are produced on the side stream
+            PF.join_side_stream(self.flat.flat_g.device)    # (no-op unless PESR_SIDE_STREAM routes weight gradients to the side stream)
         self._works.append(dist.all_reduce(self.flat.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self) -> float:
