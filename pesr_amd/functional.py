@@ -137,6 +137,7 @@ class PackedConvWeights:
 # depend on each other but the wgrad kernels only consume their outputs, so with two streams the workgroups of a wgrad can
 # fill the CUs that the previous dgrad frees during its tail.  It paid with the direct kernels; with the Winograd kernels
 # the fork / join costs more than the tails it fills.
+_SIDE = {}
 # PESR_SIDE_STREAM: "0" everything on one stream, "1" every conv block's wgrad on the side stream, "g" only the blocks
 # without BatchNorm (the Generator's), "d" only the conv+BN blocks (the Discriminator's)
 SIDE_MODE = __import__("os").environ.get("PESR_SIDE_STREAM", "0")
