@@ -8,7 +8,9 @@ One "step" = one full GAN train step of reference train.py:194-259 (G forward, 4
 RSGAN + focal losses, D and G backward, both Adam updates) on a per-GPU batch of 16 synthetic
 DIV2K-shaped crops (LR 48x48, HR 192x192, integers 0..255 as fp32) already resident in HBM.  Weak scaling:
 per-GPU batch fixed, global batch 16*N, gradients all-reduced over RCCL inside the optimizers.
-Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the roofline / cpu_baseline definitions.
+Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the roofline / cpu_baseline / parity_check definitions.
+`python bench.py --gpus N` without a launcher environment starts the N ranks itself (torch.distributed.run as a child
+process, before this process touches a GPU); it exits non-zero rather than report fewer GPUs than asked for.
 """
 import argparse
 import json
@@ -28,22 +30,47 @@ GFLOP_PER_PATCH = {"gan": 844.10, "pretrain": 694.69}   # SURVEY.md 8(d), necess
 K1_GFLOP = 2.0 * 16 * 48 * 48 * 256 * 256 * 9 / 1e9     # body conv 256->256 @48x48, batch 16: 43.487 GFLOP per launch
 
 
+PMC_SUMMARIES = ("r02_k1_pmc_summary.csv", "r01_final3_k1_pmc_summary.csv")     # newest first
+
+
 def k1_hbm_traffic_bytes(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot read PMCs
-    live): 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB in the profile."""
+    """HBM bytes per launch of a body-shape kernel from the committed rocprofv3 --pmc passes (bench.py cannot read PMCs
+    live): 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB in the profile.
+    -> (bytes | None, file name | None)"""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final3_k1_pmc_summary.csv")
-    try:
-        fetch = write = None
-        for r in csv.DictReader(open(path)):
-            if kernel_substr in r["kernel"]:
-                if r["counter"] == "FETCH_SIZE":
-                    fetch = float(r["mean_per_launch"])
-                elif r["counter"] == "WRITE_SIZE":
-                    write = float(r["mean_per_launch"])
-        return int((2 * fetch + write) * 1024) if fetch and write else None
-    except OSError:
-        return None
+    for name in PMC_SUMMARIES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            fetch = write = None
+            for r in csv.DictReader(open(path)):
+                if kernel_substr in r["kernel"]:
+                    if r["counter"] == "FETCH_SIZE":
+                        fetch = float(r["mean_per_launch"])
+                    elif r["counter"] == "WRITE_SIZE":
+                        write = float(r["mean_per_launch"])
+            if fetch and write:
+                return int((2 * fetch + write) * 1024), name
+        except OSError:
+            continue
+    return None, None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) with no launcher environment: start one process per GPU.  Runs BEFORE this
+    process makes any HIP call (device_count() does not initialise the GPU on this image) and never execs."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver supports dmabuf IPC only
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def build(args, device, world):
@@ -89,25 +116,54 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(args, G, D, vgg):
-    """The same train step on the host cores through the CPU oracle (oracle/step.py), on a bounded sample."""
+def snapshot_state(G, D, vgg):
+    """CPU copies of the three state dicts (taken BEFORE the first GPU step, for the oracle's parity step)."""
+    f = lambda m: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()} if m is not None else None
+    return f(G), f(D), f(vgg)
+
+
+def cpu_baseline(args, state, batch):
+    """The same train step on the host cores through the CPU oracle (oracle/step.py): 1 warm-up + 3 timed steps
+    (BASELINE.md section 3), best and median.  The warm-up step starts from the weights and the batch of GPU step 0, so
+    its losses double as the parity check of the benchmarked configuration.  Also: BASELINE config 1 (G inference
+    [1,3,48,48] -> [1,3,192,192] on the CPU), 1 warm-up + 5 timed.  -> (cpu_baseline dict, losses of the parity step)"""
+    import statistics
+    from oracle import model as OM
     from oracle import step as OS
     nthreads = host_cores()
     torch.set_num_threads(nthreads)
-    B = args.cpu_batch
+    g_sd, d_sd, v_sd = state
+    lr, hr = batch
+    B = lr.size(0)
     cfg = {"depth": args.num_blocks, "res_scale": 0.1, "learning_rate": 5e-5}
-    g_sd = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
-    d_sd = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()} if D is not None else None
-    v_sd = {k: v.detach().cpu().clone() for k, v in vgg.state_dict().items()} if vgg is not None else None
     st = OS.TrainState(g_sd, d_sd, v_sd, cfg)
-    lr, hr = synth_batch(B, args.patch_size, 4321, "cpu")
     step = OS.gan_step if args.workload == "gan" else OS.pretrain_step
-    t0 = time.perf_counter()
-    step(st, lr, hr)
-    dt = time.perf_counter() - t0
-    return {"value": B / dt, "unit": "patches/s", "cores": nthreads, "kind": "port",
-            "sample": f"1 {args.workload} step of the CPU oracle (torch {torch.__version__} CPU ops) at batch {B} "
-                      f"(1/{16 // B} of a GPU step's batch), full model size, {dt:.1f} s"}
+    first = step(st, lr, hr)                       # warm-up = parity step
+    times = []
+    for _ in range(args.cpu_steps):
+        t0 = time.perf_counter()
+        step(st, lr, hr)
+        times.append(time.perf_counter() - t0)
+    best, med = min(times), statistics.median(times)
+    x1 = lr[:1]
+    with torch.no_grad():
+        OM.generator_forward(g_sd, x1, args.num_blocks, 0.1)
+        t1 = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            OM.generator_forward(g_sd, x1, args.num_blocks, 0.1)
+            t1.append(time.perf_counter() - t0)
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        cpu_model = "unknown"
+    return {"value": B / best, "unit": "patches/s", "cores": nthreads, "kind": "port", "median": B / med,
+            "step_s_best": round(best, 3), "step_s_median": round(med, 3), "cpu_model": cpu_model,
+            "sample": f"{args.cpu_steps} timed {args.workload} steps (after 1 warm-up) of the CPU oracle (torch {torch.__version__} "
+                      f"CPU ops) at batch {B}, full model size; value = best, median alongside",
+            "config1_infer": {"workload": "BASELINE config 1: G forward no_grad [1,3,48,48] -> [1,3,192,192], CPU oracle",
+                              "s_best": round(min(t1), 4), "s_median": round(statistics.median(t1), 4),
+                              "images_per_s": round(1.0 / min(t1), 3)}}, first
 
 
 def bench_infer512(args, device):
@@ -147,23 +203,32 @@ def main():
     ap.add_argument("--patch_size", type=int, default=48)
     ap.add_argument("--num_channels", type=int, default=256)
     ap.add_argument("--num_blocks", type=int, default=32)
-    ap.add_argument("--cpu_batch", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu_steps", type=int, default=3, help="timed CPU-oracle steps (after one warm-up / parity step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (cpu_baseline and parity_check)")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        self_launch(args)                         # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
-    if world > 1 or under_launcher:
+    n_seen = 1
+    if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                     # the GPU count RCCL really spans
+        n_seen = int(ones.item())
+        if n_seen != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: the RCCL group spans {n_seen} rank(s)")
 
     from pesr_amd import ops
     if args.workload == "infer512":
@@ -171,9 +236,13 @@ def main():
     trainer, G, D, vgg = build(args, device, world)
     lr, hr = synth_batch(args.batch, args.patch_size, 1234 + rank, device)
     step = trainer.gan_step if args.workload == "gan" else trainer.pretrain_step
+    want_cpu = not args.no_cpu_baseline and world == 1
+    state0 = snapshot_state(G, D, vgg) if want_cpu else None
 
+    first_log = None
     for _ in range(args.warmup):
-        step(lr, hr)
+        log = step(lr, hr)
+        first_log = first_log or log
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -183,12 +252,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         logs = step(lr, hr)
+        first_log = first_log or logs
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = ops.KERNEL_EVENTS.drain()
+    kern = ops.KERNEL_EVENTS.drain()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,7 +272,7 @@ def main():
     flop_patch = GFLOP_PER_PATCH[args.workload] * 1e9
     out = {
         "metric": "HR-patches/sec (x4 SR GAN train step, 48->192)",
-        "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 3), "unit": "patches/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("full GAN phase (G + D + VGG + RSGAN focal loss), " if args.workload == "gan"
@@ -214,27 +284,61 @@ def main():
         "step_frac_of_mfma_peak": round(value / world * flop_patch / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         "losses": {k: float(v) for k, v in logs.items()},
     }
-    if kern_n:
-        ach = K1_GFLOP * (args.batch / 16) * (args.patch_size / 48) ** 2 * (args.num_channels / 256) ** 2 / kern_ms  # TFLOP/s
-        from pesr_amd import ops as _ops
-        wino = _ops.wino_eligible(args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels)
-        kname = "conv3x3_wino_kernel" if wino else "conv3x3_mfma_kernel<1, 8, 9, 2, 1, 2"
-        out["roofline"] = {"kernel": (kname if wino else "conv3x3_mfma_kernel<1,8,9,2,1,2>") +
-                                     " forward (G body 256->256 @48x48, 65 launches/step)",
-                           "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": k1_hbm_traffic_bytes(kname),
-                           "traffic_note": "HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in "
-                                           "profiles/r01_final3_k1_pmc_summary.csv (mean of fwd and dgrad launches); algorithmic: 78-116 MB",
-                           "launches_timed": kern_n, "avg_launch_us": round(kern_ms * 1e3, 2)}
-        if wino:   # `achieved` counts the conv's ALGORITHMIC flops; the Winograd kernel executes 2/3 of them
-            out["roofline"]["note"] = ("1-D Winograd F(2,3): the kernel issues 2/3 of the direct conv's MFMA flops, so achieved/peak may "
-                                       "exceed 1; matrix-pipe utilisation = mfma_util")
-            out["roofline"]["mfma_util"] = round(ach * (2.0 / 3.0) / PEAK_F32_MFMA_TFLOPS, 4)
-    if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args, G, D, vgg)
+    if kern:
+        out.update(roofline_objects(args, kern))
+    if want_cpu:
+        out["cpu_baseline"], ref0 = cpu_baseline(args, state0, (lr.cpu(), hr.cpu()))
+        got0 = {k: float(v) for k, v in first_log.items()}
+        rel = {k: abs(got0[k] - ref0[k]) / max(abs(ref0[k]), 1e-12) for k in ref0 if abs(ref0[k]) > 0 or abs(got0[k]) > 0}
+        worst = max(rel.values()) if rel else 0.0
+        out["parity_check"] = {"what": "losses of GPU step 0 vs the CPU oracle's step from the same initial weights and batch "
+                                       "(benchmarked configuration and kernel dispatch)",
+                               "max_rel_loss_err": worst, "tol": 5e-5, "ok": bool(worst <= 5e-5),
+                               "gpu": got0, "cpu_oracle": ref0}
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def roofline_objects(args, kern):
+    """`roofline` (the dominant kernel: forward of the G body conv) + `roofline_kernels` (the other two body kernels).
+    achieved = ALGORITHMIC flops of the conv / mean HIP-event duration of its launches inside the timed steps;
+    frac = flops the kernel ISSUES on the matrix pipe (2/3 of the algorithmic ones for the 1-D Winograd F(2,3) kernels)
+    / duration / peak, i.e. matrix-pipe utilisation - the honest hardware fraction; algorithmic_frac = achieved / peak."""
+    from pesr_amd import ops as _ops
+    scale = (args.batch / 16) * (args.patch_size / 48) ** 2 * (args.num_channels / 256) ** 2
+    wino = _ops.wino_eligible(args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels)
+    wg_wino = _ops.USE_WGRAD_WINO and args.patch_size % 2 == 0 and args.patch_size >= 48 and args.num_channels % 64 == 0
+    shape = f"G body {args.num_channels}->{args.num_channels} @{args.patch_size}x{args.patch_size}, batch {args.batch}"
+    names = {"fwd": ("conv3x3_wino_kernel" if wino else "conv3x3_mfma_kernel<1, 8, 9, 2, 1, 2", wino,
+                     f"forward ({shape}: 65 G launches + the 6 same-shaped VGG conv3_2..3_4 launches per GAN step)"),
+             "dgrad": ("conv3x3_wino_kernel" if wino else "conv3x3_mfma_kernel<1, 8, 9, 2, 1, 2", wino,
+                       f"input gradient ({shape}: 65 G + 3 VGG launches per GAN step)"),
+             "wgrad": ("conv3x3_wgrad_wino_kernel" if wg_wino else "conv3x3_wgrad_kernel", wg_wino,
+                       f"weight gradient incl. its split-K reduce kernel ({shape}: 65 launches per step)")}
+    objs = {}
+    for kind, (ms, n) in kern.items():
+        kname, is_wino, label = names[kind]
+        ach = K1_GFLOP * scale / ms                                  # algorithmic TFLOP/s
+        issued = ach * (2.0 / 3.0 if is_wino else 1.0)
+        traffic, src = k1_hbm_traffic_bytes(kname)
+        o = {"kernel": f"{kname} {label}", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+             "unit": "TFLOP/s", "frac": round(issued / PEAK_F32_MFMA_TFLOPS, 4),
+             "algorithmic_frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "issued_tflops": round(issued, 2),
+             "traffic": traffic,
+             "traffic_note": (f"HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in profiles/{src}"
+                              if src else "no committed PMC summary found"),
+             "launches_timed": n, "avg_launch_us": round(ms * 1e3, 2)}
+        if is_wino:
+            o["note"] = ("1-D Winograd F(2,3): the kernel issues 2/3 of the direct conv's MFMA flops; frac counts the ISSUED flops "
+                         "(matrix-pipe utilisation), algorithmic_frac the conv's algorithmic flops")
+        objs[kind] = o
+    out = {}
+    if "fwd" in objs:
+        out["roofline"] = objs.pop("fwd")
+    if objs:
+        out["roofline_kernels"] = [objs[k] for k in ("dgrad", "wgrad") if k in objs]
+    return out
 
 
 if __name__ == "__main__":

@@ -65,10 +65,15 @@ int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float
                        size_t ws_bytes, void* stream);
 
 /* dw[O][I][3][3] (OIHW, the parameter's own layout) = alpha * sum_pixels dy (x) x ;  db[O] = alpha * sum dy.
- * db may be NULL.  ps_in as above.  Workspace: pesr_conv3x3_wgrad_workspace_bytes. */
-size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride);
+ * db may be NULL.  ps_in as above.  Workspace: pesr_conv3x3_wgrad_workspace_bytes (same algo).
+ * algo: PESR_WGRAD_AUTO = the transposed-Winograd kernel where it applies (stride 1, even width >= 48, 64-multiple
+ * channels), the direct kernel elsewhere; PESR_WGRAD_DIRECT = the direct kernel everywhere.  Both produce the same
+ * gradient up to fp32 summation order; the choice is an argument, never process state. */
+#define PESR_WGRAD_AUTO 0
+#define PESR_WGRAD_DIRECT 1
+size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo);
 int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                       int stride, float alpha, int ps_in, void* workspace, size_t ws_bytes, void* stream);
+                       int stride, float alpha, int ps_in, int algo, void* workspace, size_t ws_bytes, void* stream);
 
 /* Stride-1 3x3 conv (pad 1) with a 1-D Winograd F(2,3) transform along x: 2/3 of the multiplies of pesr_conv3x3_fwd, same
  * tensors and fused epilogue (y = act(alpha * (conv + bias) [masked] + skip)), for even W, Cin % 16 == 0, Cout % 128 == 0

@@ -63,7 +63,14 @@ class TrainState:
         return M.generator_forward(self.g, x, self.cfg["depth"], self.cfg["res_scale"])
 
     def D(self, x):
-        return M.discriminator_forward(self.d, x, update_running_stats=True)
+        """Discriminator forward.  cfg["dp_replicas"] = R > 1 restates what nn.DataParallel(D) (train.py:116) computes on R
+        devices: the batch is scattered into R contiguous shards and every replica normalises with ITS shard's BatchNorm
+        statistics (no SyncBN); only replica 0's running-stat update survives (its buffers are the module's own)."""
+        R = int(self.cfg.get("dp_replicas", 1))
+        if R <= 1:
+            return M.discriminator_forward(self.d, x, update_running_stats=True)
+        outs = [M.discriminator_forward(self.d, xs, update_running_stats=(i == 0)) for i, xs in enumerate(x.chunk(R, 0))]
+        return torch.cat(outs, 0)
 
 
 def pretrain_step(st: TrainState, lr, hr):
@@ -124,5 +131,8 @@ def gan_step(st: TrainState, lr, hr):
 
 
 def step_lr(base_lr, epoch, lr_step, gamma=0.5):
-    """StepLR stepped at EPOCH START (train.py:156,185-186): epoch e (1-based) trains at base*gamma^floor(e/lr_step)."""
-    return base_lr * math.pow(gamma, epoch // lr_step)
+    """StepLR stepped at EPOCH START (train.py:156,185-186) under the reference's pinned torch 0.4 (README.md:22), whose
+    `_LRScheduler.__init__` runs step(0) and then resets last_epoch to -1: the step() at the start of epoch e (1-based)
+    gives last_epoch = e-1, so epoch e trains at base*gamma^floor((e-1)/lr_step) - epochs 1..120 at lr, 121..240 at lr/2.
+    (Run unchanged on torch >= 1.1 the same script halves one epoch earlier, because the constructor already counts a step.)"""
+    return base_lr * math.pow(gamma, (epoch - 1) // lr_step)

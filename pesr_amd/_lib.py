@@ -25,8 +25,8 @@ SIGNATURES = {
                                  c_float, c_int, _P, c_size_t, _P]),
     "pesr_conv3x3_dgrad": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P,
                                    c_size_t, _P]),
-    "pesr_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "pesr_conv3x3_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P,
+    "pesr_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pesr_conv3x3_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P,
                                    c_size_t, _P]),
 }
 

@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 1; }
+PESR_API int pesr_abi_version(void) { return 2; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -44,12 +44,12 @@ PESR_API size_t pesr_conv3x3_workspace_bytes(int N, int OH, int OW, int Cout) {
     return tiles < 640 ? (size_t)8 * N * OH * OW * Cout * sizeof(float) : 0;
 }
 
-PESR_API size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride) {
-    return pesr_conv3x3_wgrad_ws_bytes(N, H, W, Cin, Cout, stride);
+PESR_API size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo) {
+    return pesr_conv3x3_wgrad_ws_bytes(N, H, W, Cin, Cout, stride, algo);
 }
 PESR_API int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                                int stride, float alpha, int ps_in, void* workspace, size_t ws_bytes, void* stream) {
-    return pesr_conv3x3_wgrad_launch(x, dy, dw, db, N, H, W, Cin, Cout, stride, alpha, ps_in, workspace, ws_bytes,
+                                int stride, float alpha, int ps_in, int algo, void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_conv3x3_wgrad_launch(x, dy, dw, db, N, H, W, Cin, Cout, stride, alpha, ps_in, algo, workspace, ws_bytes,
                                      (hipStream_t)stream);
 }
 

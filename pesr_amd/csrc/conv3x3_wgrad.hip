@@ -406,26 +406,23 @@ static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
 }
 }  // namespace
 
-// PESR_WGRAD_WINO=0 keeps every layer on the direct kernel (A/B runs)
-static bool wgrad_wino_enabled() {
-    static const bool on = [] { const char* e = getenv("PESR_WGRAD_WINO"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int stride) {
+// algo: PESR_WGRAD_AUTO (0) = the Winograd form where it applies, PESR_WGRAD_DIRECT (1) = the direct kernel everywhere (A/B runs,
+// parity cross-checks).  An explicit argument: the library keeps no hidden state.
+size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo) {
     WgradPlan p;
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return 0;
-    const size_t ww = (stride == 1 && wgrad_wino_enabled()) ? pesr_conv3x3_wgrad_wino_ws_bytes(N, H, W, Cin, Cout) : 0;
+    const size_t ww = (stride == 1 && algo == 0) ? pesr_conv3x3_wgrad_wino_ws_bytes(N, H, W, Cin, Cout) : 0;
     return p.total_bytes > ww ? p.total_bytes : ww;
 }
 
 int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                              int stride, float alpha, int ps_in, void* ws, size_t ws_bytes, hipStream_t stream) {
+                              int stride, float alpha, int ps_in, int algo, void* ws, size_t ws_bytes, hipStream_t stream) {
     WgradPlan p;
+    if (algo != 0 && algo != 1) return PESR_EINVAL;
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return PESR_EINVAL;
     if (ws_bytes < p.total_bytes || !ws) return PESR_EWORKSPACE;
     if (ps_in && (stride != 1 || Cout % 16)) return PESR_EINVAL;
-    if (stride == 1 && wgrad_wino_enabled()) {   // the Winograd form where it applies (even width >= 48, 64-multiple channels)
+    if (stride == 1 && algo == 0) {   // the Winograd form where it applies (even width >= 48, 64-multiple channels)
         const int rc = pesr_conv3x3_wgrad_wino_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, ws, ws_bytes, stream);
         if (rc != PESR_EINVAL && rc != PESR_EWORKSPACE) return rc;
     }

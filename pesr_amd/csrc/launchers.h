@@ -13,9 +13,9 @@ int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, cons
 int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* mask, float* dx, int N, int H, int W,
                                  int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream);
 
-size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int stride);
+size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo);
 int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                              int stride, float alpha, int ps_in, void* ws, size_t ws_bytes, hipStream_t stream);
+                              int stride, float alpha, int ps_in, int algo, void* ws, size_t ws_bytes, hipStream_t stream);
 int pesr_bias_grad_launch(const float* dy, float* db, long pixels, int Cout, int OW, float alpha, int ps_in, float* part,
                           size_t part_bytes, hipStream_t stream);
 

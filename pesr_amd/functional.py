@@ -12,14 +12,21 @@ from torch.autograd import Function
 from . import ops
 
 # Our fused Adam writes parameters through raw pointers and cannot bump Tensor._version, so every parameter it owns
-# carries an explicit epoch here (bumped by FlatAdam.step for ITS parameters only - the static VGG weights and the
-# other network's weights keep their packed copies).  Part of every packed-weight cache key.
-_PARAM_EPOCH = {}   # id(param) -> int
+# carries an explicit epoch (bumped by FlatAdam.step for ITS parameters only - the static VGG weights and the other
+# network's weights keep their packed copies).  Part of every packed-weight cache key.  The epoch is an attribute of the
+# parameter object itself: it lives and dies with the parameter (a registry keyed by id() would outlive it and hand a
+# recycled id a dead optimizer's state).
+_EPOCH_ATTR = "_pesr_epoch"
+_GRAD_VIEW_ATTR = "_pesr_grad_view"
+
+
+def weight_epoch(p) -> int:
+    return getattr(p, _EPOCH_ATTR, 0)
 
 
 def bump_weight_epoch(params) -> None:
     for p in params:
-        _PARAM_EPOCH[id(p)] = _PARAM_EPOCH.get(id(p), 0) + 1
+        setattr(p, _EPOCH_ATTR, getattr(p, _EPOCH_ATTR, 0) + 1)
 
 
 # Flat-gradient fast path.  pesr_amd.optim.FlatParams registers, per parameter, a factory of fresh views into its flat
@@ -27,87 +34,110 @@ def bump_weight_epoch(params) -> None:
 # writes straight into such a view and returns it; autograd then adopts it as .grad without a copy or an add kernel
 # (AccumulateGrad steals a uniquely-referenced, contiguous gradient).  The slice is handed out ONCE per step: a
 # parameter used twice in one graph (the Discriminator sees hr and sr in the same backward) gets a temporary for its
-# second contribution, which autograd's input buffer adds to the first.
-_GRAD_VIEWS = {}   # id(param) -> [factory, claimed]
-
-
+# second contribution, which autograd's input buffer adds to the first.  Stored as [factory, claimed] on the parameter
+# object (same lifetime argument as the epoch); the factory holds only a weak reference to its FlatParams.
 def register_grad_view(param: torch.Tensor, factory) -> None:
-    _GRAD_VIEWS[id(param)] = [factory, False]
+    setattr(param, _GRAD_VIEW_ATTR, [factory, False])
+
+
+def unregister_grad_view(param: torch.Tensor) -> None:
+    if hasattr(param, _GRAD_VIEW_ATTR):
+        delattr(param, _GRAD_VIEW_ATTR)
 
 
 def release_grad_views(params) -> None:
     """New step (zero_grad): every registered slice may be claimed again."""
     for p in params:
-        e = _GRAD_VIEWS.get(id(p))
+        e = getattr(p, _GRAD_VIEW_ATTR, None)
         if e is not None:
             e[1] = False
 
 
 def grad_out(param):
     """A fresh view of the parameter's flat-gradient slice if its first gradient may be written there, else None."""
-    if param is None or param.grad is not None:
+    if param is None or not param.is_leaf or param.grad is not None:      # (replicas of nn.DataParallel are non-leaf)
         return None
-    e = _GRAD_VIEWS.get(id(param))
+    e = getattr(param, _GRAD_VIEW_ATTR, None)
     if e is None or e[1]:
         return None
+    view = e[0]()
+    if view is None:          # the owning FlatParams is gone
+        return None
     e[1] = True
-    return e[0]()
+    return view
 
 
 _ALL_PACKS = []   # weak registry of every PackedConvWeights (for the batched repack after an optimizer step)
 
 
+class _PackSlot:
+    """The packed layouts of one weight tensor ON ONE DEVICE."""
+    __slots__ = ("fwd", "dgrad", "bias", "wfwd", "wdgrad", "kf", "kd", "kb", "kwf", "kwd", "wref")
+
+    def __init__(self):
+        self.fwd = self.dgrad = self.bias = self.wfwd = self.wdgrad = None
+        self.kf = self.kd = self.kb = self.kwf = self.kwd = None
+        self.wref = None            # weakref to the weight tensor this slot was last built from
+
+
 class PackedConvWeights:
-    """Per-parameter cache of the kernel-side weight layouts (forward / dgrad packing, PS-permuted bias)."""
+    """Per-module cache of the kernel-side weight layouts (forward / dgrad packing, PS-permuted bias).
+
+    One slot per device: nn.DataParallel's replicas are shallow copies that SHARE this object while their weights live
+    on different GPUs and their forwards run on concurrent threads (SURVEY 8b "Threading") - every replica works on its
+    own device's slot, and the lock makes the check-then-pack step atomic."""
 
     def __init__(self, ps: bool = False):
+        import threading
         import weakref
         self.ps = ps
-        self._fwd = self._dgrad = self._bias = self._wfwd = self._wdgrad = None
-        self._kf = self._kd = self._kb = self._kwf = self._kwd = None
-        self._wref = None            # weakref to the weight parameter once it has been seen
+        self._slots = {}            # device index -> _PackSlot
+        self._lock = threading.Lock()
         _ALL_PACKS.append(weakref.ref(self))
+
+    def __deepcopy__(self, memo):   # copy.deepcopy(module): a fresh, empty cache (locks cannot be copied)
+        return PackedConvWeights(self.ps)
+
+    def __getstate__(self):         # pickling a module (torch.save(model)): drop the device buffers and the lock
+        return {"ps": self.ps}
+
+    def __setstate__(self, st):
+        self.__init__(st["ps"])
 
     @staticmethod
     def _key(t: torch.Tensor):
-        return (t.data_ptr(), t._version, _PARAM_EPOCH.get(id(t), 0))
+        return (t.data_ptr(), t._version, weight_epoch(t))
 
-    def _note(self, w):
-        if self._wref is None or self._wref() is not w:
+    def _slot(self, w) -> _PackSlot:
+        idx = w.device.index if w.is_cuda else -1
+        sl = self._slots.get(idx)
+        if sl is None:
+            sl = self._slots[idx] = _PackSlot()
+        if sl.wref is None or sl.wref() is not w:
             import weakref
-            self._wref = weakref.ref(w)
+            sl.wref = weakref.ref(w)
+        return sl
+
+    def _get(self, w, field, keyf, build):
+        with self._lock:
+            sl = self._slot(w)
+            k = self._key(w)
+            if getattr(sl, keyf) != k:
+                setattr(sl, field, build())
+                setattr(sl, keyf, k)
+            return getattr(sl, field)
 
     def fwd(self, w: torch.Tensor) -> torch.Tensor:
-        self._note(w)
-        k = self._key(w)
-        if self._kf != k:
-            self._fwd = ops.pack_conv3x3(w.detach(), 0, self.ps)
-            self._kf = k
-        return self._fwd
+        return self._get(w, "fwd", "kf", lambda: ops.pack_conv3x3(w.detach(), 0, self.ps))
 
     def dgrad(self, w: torch.Tensor) -> torch.Tensor:
-        self._note(w)
-        k = self._key(w)
-        if self._kd != k:
-            self._dgrad = ops.pack_conv3x3(w.detach(), 1, self.ps)
-            self._kd = k
-        return self._dgrad
+        return self._get(w, "dgrad", "kd", lambda: ops.pack_conv3x3(w.detach(), 1, self.ps))
 
     def wino_fwd(self, w: torch.Tensor):
-        self._note(w)
-        k = self._key(w)
-        if self._kwf != k:
-            self._wfwd = ops.pack_conv3x3_wino(w.detach(), 0, self.ps)
-            self._kwf = k
-        return self._wfwd
+        return self._get(w, "wfwd", "kwf", lambda: ops.pack_conv3x3_wino(w.detach(), 0, self.ps))
 
     def wino_dgrad(self, w: torch.Tensor):
-        self._note(w)
-        k = self._key(w)
-        if self._kwd != k:
-            self._wdgrad = ops.pack_conv3x3_wino(w.detach(), 1, self.ps)
-            self._kwd = k
-        return self._wdgrad
+        return self._get(w, "wdgrad", "kwd", lambda: ops.pack_conv3x3_wino(w.detach(), 1, self.ps))
 
     def for_fwd(self, w: torch.Tensor, x_shape, stride: int = 1):
         """Packed weights for y = conv(x, w): the Winograd packing where that kernel applies, else the direct one."""
@@ -126,11 +156,16 @@ class PackedConvWeights:
     def bias(self, b):
         if b is None or not self.ps:
             return None if b is None else b.detach()
-        k = self._key(b)
-        if self._kb != k:
-            self._bias = ops.pack_bias_ps(b.detach())
-            self._kb = k
-        return self._bias
+        with self._lock:
+            idx = b.device.index if b.is_cuda else -1
+            sl = self._slots.get(idx)
+            if sl is None:
+                sl = self._slots[idx] = _PackSlot()
+            k = self._key(b)
+            if sl.kb != k:
+                sl.bias = ops.pack_bias_ps(b.detach())
+                sl.kb = k
+            return sl.bias
 
 
 # Optional side stream for the weight-gradient kernels (off by default): in a backward chain the dgrad kernels
@@ -217,39 +252,40 @@ def repack_all(params) -> None:
         if c is None:
             _ALL_PACKS.remove(ref)
             continue
-        w = c._wref() if c._wref is not None else None
-        if w is None or id(w) not in ids or not w.is_cuda:
-            continue
-        O, I = w.shape[0], w.shape[1]
-        for mode, buf in ((0, c._fwd), (1, c._dgrad)):
-            if buf is None:
+        for sl in list(c._slots.values()):
+            w = sl.wref() if sl.wref is not None else None
+            if w is None or id(w) not in ids or not w.is_cuda:
                 continue
-            R, Nn = (I, O) if mode == 0 else (O, I)
-            jobs.append((c, mode, (w.data_ptr(), buf.data_ptr(), O, I, mode, int(c.ps), (R + 15) // 16 * 16, 16 if Nn <= 16 else (Nn + 63) // 64 * 64)))
-        for mode, wpk in ((2, c._wfwd), (3, c._wdgrad)):      # Winograd packings (batched kernel modes 2 / 3)
-            if wpk is not None:
-                jobs.append((c, mode, (w.data_ptr(), wpk.t.data_ptr(), O, I, mode, int(c.ps), I if mode == 2 else O, O if mode == 2 else I)))
+            O, I = w.shape[0], w.shape[1]
+            for mode, buf in ((0, sl.fwd), (1, sl.dgrad)):
+                if buf is None:
+                    continue
+                R, Nn = (I, O) if mode == 0 else (O, I)
+                jobs.append((sl, w, mode, (w.data_ptr(), buf.data_ptr(), O, I, mode, int(c.ps), (R + 15) // 16 * 16, 16 if Nn <= 16 else (Nn + 63) // 64 * 64)))
+            for mode, wpk in ((2, sl.wfwd), (3, sl.wdgrad)):      # Winograd packings (batched kernel modes 2 / 3)
+                if wpk is not None:
+                    jobs.append((sl, w, mode, (w.data_ptr(), wpk.t.data_ptr(), O, I, mode, int(c.ps), I if mode == 2 else O, O if mode == 2 else I)))
     if not jobs:
         return
-    dev = jobs[0][0]._wref().device
-    key = (tuple(sorted(ids)), tuple(j[2] for j in jobs))
+    dev = jobs[0][1].device
+    key = (tuple(sorted(ids)), tuple(j[3] for j in jobs))
     table = _REPACK_TABLES.get(key)
     if table is None:
         _REPACK_TABLES.clear()
-        table = _REPACK_TABLES[key] = torch.from_numpy(np.array([j[2] for j in jobs], dtype=np.int64)).to(dev)
+        table = _REPACK_TABLES[key] = torch.from_numpy(np.array([j[3] for j in jobs], dtype=np.int64)).to(dev)
     from . import _lib
     _lib.check(_lib.lib().pesr_pack_conv3x3_batched(table.data_ptr(), len(jobs), torch.cuda.current_stream(dev).cuda_stream),
                "pesr_pack_conv3x3_batched")
-    for c, mode, _ in jobs:
-        k = PackedConvWeights._key(c._wref())
+    for sl, w, mode, _ in jobs:
+        k = PackedConvWeights._key(w)
         if mode == 0:
-            c._kf = k
+            sl.kf = k
         elif mode == 1:
-            c._kd = k
+            sl.kd = k
         elif mode == 2:
-            c._kwf = k
+            sl.kwf = k
         else:
-            c._kwd = k
+            sl.kwd = k
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:

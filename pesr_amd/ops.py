@@ -34,25 +34,36 @@ def _stream() -> int:
 
 
 class _KernelEvents:
-    """Optional HIP-event bracket around every launch of ONE conv shape (bench.py's live roofline figure).
-    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+    """Optional HIP-event bracket around every launch of ONE conv shape (bench.py's live roofline figures), kept per kind
+    ("fwd", "dgrad", "wgrad").  Events are recorded on the stream the kernel is launched on (torch's current stream)."""
 
     def __init__(self):
-        self.shape, self.pairs = None, []
+        self.shape, self.pairs = None, {}
 
     def enable(self, shape):
-        self.shape, self.pairs = tuple(shape), []
+        self.shape, self.pairs = tuple(shape), {}
 
-    def match(self, N, H, W, Cin, Cout, stride):
-        return self.shape is not None and self.shape == (N, H, W, Cin, Cout, stride)
+    def begin(self, kind, N, H, W, Cin, Cout, stride):
+        """-> an open bracket (or None when this launch is not the watched shape); close it with end()."""
+        if self.shape is None or self.shape != (N, H, W, Cin, Cout, stride):
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (kind, e0)
+
+    def end(self, br):
+        if br is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.pairs.setdefault(br[0], []).append((br[1], e1))
 
     def drain(self):
-        """-> (average milliseconds per launch, launches); disables recording."""
-        pairs, self.pairs, self.shape = self.pairs, [], None
+        """-> {kind: (average milliseconds per launch, launches)}; disables recording."""
+        pairs, self.pairs, self.shape = self.pairs, {}, None
         if not pairs:
-            return 0.0, 0
+            return {}
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs), len(pairs)
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in pairs.items()}
 
 
 KERNEL_EVENTS = _KernelEvents()
@@ -104,6 +115,8 @@ class WinoPacked:
 
 
 USE_WINO = __import__("os").environ.get("PESR_WINO", "1") != "0"     # PESR_WINO=0: direct kernel everywhere
+# PESR_WGRAD_WINO=0: direct weight-gradient kernel everywhere (passed to the library as the explicit `algo` argument)
+USE_WGRAD_WINO = __import__("os").environ.get("PESR_WGRAD_WINO", "1") != "0"
 
 
 def wino_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1) -> bool:
@@ -162,12 +175,9 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         rc = _lib.lib().pesr_conv3x3_rgb_fwd(_p(x), _p(w_oihw), _p(bias), _p(y), N, H, W, cout, act, slope, _stream())
         _lib.check(rc, f"pesr_conv3x3_rgb_fwd[{N}x{H}x{W}x3->{cout}]")
         return y
-    timed = KERNEL_EVENTS.match(N, H, W, Cin, cout, stride)
-    if timed:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     if callable(wp):
         wp = wp()
+    br = KERNEL_EVENTS.begin("fwd", N, H, W, Cin, cout, stride)
     L = _lib.lib()
     if isinstance(wp, WinoPacked):
         assert stride == 1
@@ -178,9 +188,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         ws = workspace(nws, x.device) if nws else None
         rc = L.pesr_conv3x3_fwd(_p(x), _p(wp), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, stride,
                                 alpha, act, slope, int(ps_out), _p(ws), nws, _stream())
-    if timed:
-        e1.record()
-        KERNEL_EVENTS.pairs.append((e0, e1))
+    KERNEL_EVENTS.end(br)
     _lib.check(rc, f"pesr_conv3x3_fwd[{N}x{H}x{W}x{Cin}->{cout},s{stride}]")
     return y
 
@@ -198,14 +206,17 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
             _chk(t, f"conv3x3_dgrad.{n}")
             assert t.shape == dx.shape
     L = _lib.lib()
+    br = KERNEL_EVENTS.begin("dgrad", N, H, W, Cin, cout, stride)
     if isinstance(wpd, WinoPacked):     # the input gradient is the conv of dy with the flipped, transposed kernel
         assert stride == 1
         _conv3x3_wino(dy, wpd, None, skip, mask, dx, N, H, W, cout, Cin, alpha, ACT_NONE, 0.0, "dgrad", ps_in=ps_in)
+        KERNEL_EVENTS.end(br)
         return dx
     nws = L.pesr_conv3x3_workspace_bytes(N, H, W, Cin) if stride == 1 else 0
     ws = workspace(nws, dy.device) if nws else None
     rc = L.pesr_conv3x3_dgrad(_p(dy), _p(wpd), _p(mask), _p(skip), _p(dx), N, H, W, Cin, cout, stride, alpha,
                               int(ps_in), _p(ws), nws, _stream())
+    KERNEL_EVENTS.end(br)
     _lib.check(rc, f"pesr_conv3x3_dgrad[{N}x{H}x{W}x{Cin}<-{cout},s{stride}]")
     return dx
 
@@ -237,14 +248,17 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
     N, H, W, Cin = x.shape
     cout = dy.shape[3] * (4 if ps_in else 1)
     L = _lib.lib()
-    nbytes = L.pesr_conv3x3_wgrad_workspace_bytes(N, H, W, Cin, cout, stride)
+    algo = 0 if USE_WGRAD_WINO else 1
+    nbytes = L.pesr_conv3x3_wgrad_workspace_bytes(N, H, W, Cin, cout, stride, algo)
     if nbytes == 0:
         raise _lib.PesrHipError(f"pesr_conv3x3_wgrad: unsupported shape Cin={Cin} Cout={cout} stride={stride}")
     ws = workspace(nbytes, x.device)
     dw = _out(dw_out, (cout, Cin, 3, 3), x.device)
     db = _out(db_out, (cout,), x.device) if want_bias else None
-    rc = L.pesr_conv3x3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, H, W, Cin, cout, stride, alpha, int(ps_in), _p(ws),
+    br = KERNEL_EVENTS.begin("wgrad", N, H, W, Cin, cout, stride)
+    rc = L.pesr_conv3x3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, H, W, Cin, cout, stride, alpha, int(ps_in), algo, _p(ws),
                               ws.numel(), _stream())
+    KERNEL_EVENTS.end(br)
     _lib.check(rc, f"pesr_conv3x3_wgrad[{N}x{H}x{W}x{Cin}->{cout},s{stride}]")
     return dw, db
 

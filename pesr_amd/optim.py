@@ -39,7 +39,16 @@ class FlatParams:
             self.flat_p[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[o:o + n].view(p.shape)
             p.grad = None
-            PF.register_grad_view(p, (lambda o=o, n=n, shape=p.shape: self.flat_g[o:o + n].view(shape)))
+        import weakref
+        me = weakref.ref(self)      # the factories must not keep this object (and its buffers) alive through the parameters
+
+        def factory(o, n, shape):
+            def make():
+                owner = me()
+                return None if owner is None else owner.flat_g[o:o + n].view(shape)
+            return make
+        for p, o in zip(self.params, self.offsets):
+            PF.register_grad_view(p, factory(o, p.numel(), p.shape))
 
     def attach_one(self, i: int) -> None:
         p, o = self.params[i], self.offsets[i]
@@ -151,6 +160,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_p)
         self.buckets = GradBuckets(self.flat, process_group, bucket_bytes)
         self.steps = 0
+        self.last_scale = 1.0        # the 1/world factor of the latest step (flat_g holds the SUM over ranks)
         PF.bump_weight_epoch(self.flat.params)
 
     def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: ARG002 (kept for API compatibility)
@@ -164,7 +174,7 @@ class FlatAdam(torch.optim.Optimizer):
         if self.flat.flat_g.is_cuda:
             PF.join_side_stream(self.flat.flat_g.device)
         self.flat.attach_grads()
-        scale = self.buckets.finish()
+        scale = self.last_scale = self.buckets.finish()
         g = self.param_groups[0]
         self.steps += 1
         ops.adam_step(self.flat.flat_p, self.flat.flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],

@@ -1,0 +1,116 @@
+"""GPU: the RCCL data-parallel path on hardware (replaces reference train.py:114-118 nn.DataParallel).
+
+* single process, single-rank `nccl` group, PESR_FORCE_DP=1: the hook / bucket / flat-gradient fast path / communication
+  stream machinery must leave two GAN steps BIT-IDENTICAL to the plain run (an all-reduce over one rank is the identity);
+* N ranks under torch.distributed.run (N = 1 always, N = 2 when two GPUs are visible): losses, gradients and post-Adam
+  parameters against the CPU oracle's step on the GLOBAL batch with DataParallel's per-replica BatchNorm statistics
+  (oracle/step.py TrainState.D, dp_replicas) - covers the TV x N term, per-rank BN, D's parameters used twice per backward.
+"""
+import os
+import socket
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from helpers import adam_close, close, dis_sd, gen_sd, vgg_sd
+from oracle import detrand
+from oracle import step as OS
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore", message=".*pretrained vgg19.*")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _two_steps(C=64, depth=2, ps=8, B=4):
+    from model import Discriminator, Generator, VGG
+    from pesr_amd.optim import FlatAdam
+    from pesr_amd.step import Trainer
+    G = Generator({"num_channels": C, "depth": depth, "res_scale": 0.1}); G.load_state_dict(gen_sd(C, depth)); G.cuda()
+    D = Discriminator({"patch_size": ps, "spectral_norm": False}); D.load_state_dict(dis_sd(ps)); D.cuda()
+    V = VGG(); V.load_state_dict(vgg_sd()); V.cuda()
+    oG = FlatAdam(G.parameters(), lr=5e-5, bucket_bytes=64 << 10)
+    oD = FlatAdam(D.parameters(), lr=5e-5, bucket_bytes=256 << 10)
+    tr = Trainer(G, D, V, oG, oD)
+    logs = []
+    for it in range(2):
+        lr = detrand.image_batch((B, 3, ps, ps), 700 + it).cuda()
+        hr = detrand.image_batch((B, 3, 4 * ps, 4 * ps), 800 + it).cuda()
+        log = tr.gan_step(lr, hr)
+        logs.append(torch.stack([log[k].float() for k in ("l1", "vgg", "g", "tv", "d")]).cpu())
+    return torch.stack(logs), oG, oD
+
+
+def test_single_rank_nccl_forced_dp_is_bit_identical(monkeypatch):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        calls = []
+        real = dist.all_reduce
+
+        def counted(t, *a, **k):
+            calls.append(t.numel())
+            return real(t, *a, **k)
+        monkeypatch.setattr(dist, "all_reduce", counted)
+        monkeypatch.setenv("PESR_FORCE_DP", "1")
+        la, oGa, oDa = _two_steps()
+        assert oGa.buckets.enabled and oDa.buckets.enabled and len(oGa.buckets.bounds) > 2 and len(oDa.buckets.bounds) > 2
+        n_dp = len(calls)
+        # 2 steps x (every G bucket + every D bucket), each launched exactly once
+        assert n_dp == 2 * (len(oGa.buckets.bounds) + len(oDa.buckets.bounds)), (n_dp, len(oGa.buckets.bounds), len(oDa.buckets.bounds))
+        assert sum(calls) == 2 * (oGa.flat.numel + oDa.flat.numel)
+        monkeypatch.delenv("PESR_FORCE_DP")
+        lb, oGb, oDb = _two_steps()
+        assert not oGb.buckets.enabled and len(calls) == n_dp
+        assert torch.equal(la, lb), (la, lb)
+        for a, b in ((oGa, oGb), (oDa, oDb)):
+            assert torch.equal(a.flat.flat_p, b.flat.flat_p) and torch.equal(a.flat.flat_g, b.flat.flat_g)
+            assert torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nproc", [1, 2])
+def test_n_rank_gan_steps_vs_full_batch_oracle(nproc, tmp_path):
+    if torch.cuda.device_count() < nproc:
+        pytest.skip(f"{nproc} GPUs needed, {torch.cuda.device_count()} visible")
+    out = str(tmp_path / "dp.pt")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("PESR_FORCE_DP", None)
+    if nproc == 1:
+        env["PESR_FORCE_DP"] = "1"       # a 1-rank group still runs the hooks / buckets / RCCL calls
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_worker.py"), "--out", out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(out)
+    assert got["world"] == nproc
+    C, depth, ps, B = 64, 2, 8, 4
+    st = OS.TrainState(gen_sd(C, depth), dis_sd(ps), vgg_sd(), {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5,
+                                                                "dp_replicas": nproc})
+    for it in range(2):
+        lr = detrand.image_batch((B * nproc, 3, ps, ps), 700 + it)
+        hr = detrand.image_batch((B * nproc, 3, 4 * ps, 4 * ps), 800 + it)
+        ref = OS.gan_step(st, lr, hr)
+        close(got["losses"][it].numpy(), np.array([ref[k] for k in ("l1", "vgg", "g", "tv", "d")]), 5e-5 if it == 0 else 5e-4,
+              what=f"losses step {it}")
+    for k, v in st.g.items():                      # gradients of the LAST step (averaged over ranks = the full-batch ones)
+        close(got["G.grad"][k], v.grad, 2e-4, what="grad G." + k)
+    for k, v in st.d.items():
+        if k in got["D.grad"]:
+            close(got["D.grad"][k], v.grad, 5e-4, what="grad D." + k)
+    for k, v in st.g.items():
+        adam_close(got["G"][k], v, 5e-5, 2, "G." + k)
+    for k, v in st.d.items():
+        if v.is_floating_point() and "running" not in k:
+            adam_close(got["D"][k], v, 5e-5, 2, "D." + k)

@@ -129,3 +129,30 @@ print("identical")
 ''' % (ROOT, ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "identical" in out.stdout, out.stderr[-2000:]
+
+
+def test_lr_schedule_order_matches_reference_under_its_pinned_torch():
+    """train.py steps its StepLR at the END of each epoch; on this torch that reproduces the reference's schedule under
+    torch 0.4 (epoch e trains at lr*0.5^((e-1)//lr_step): epochs 1..lr_step at lr, the first halving at lr_step+1)."""
+    import re
+    import torch.optim.lr_scheduler as S
+    from oracle import step as OS
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=5e-5)
+    sch = S.StepLR(opt, step_size=3, gamma=0.5)
+    seen = []
+    for epoch in range(1, 9):
+        seen.append(opt.param_groups[0]["lr"])      # the rate epoch `epoch` trains with
+        opt.step()
+        sch.step()
+    assert seen == [pytest_approx(OS.step_lr(5e-5, e, 3)) for e in range(1, 9)]
+    assert seen[2] == 5e-5 and seen[3] == 2.5e-5     # epochs lr_step and lr_step + 1
+    # and train.py really has that order: the scheduler steps come after the epoch's validation block
+    src = open(os.path.join(ROOT, "train.py")).read()
+    body = src[src.index("for epoch in range(1, args.num_epochs + 1):"):]
+    assert body.index("scheduler_G.step()") > body.index("Finish valid")
+
+
+def pytest_approx(v):
+    import pytest
+    return pytest.approx(v, rel=1e-12)

@@ -134,6 +134,71 @@ def test_gv8_two_gan_steps():
         close(v.detach().reshape(-1).float()[g["D.idx." + k]], g["D.val." + k], 1e-5)
 
 
-@pytest.mark.parametrize("epoch,expect", [(1, 5e-5), (119, 5e-5), (120, 2.5e-5), (239, 2.5e-5), (240, 1.25e-5)])
+def _sampled(leaves, g, prefix, rel):
+    n = 0
+    for key in [k[len(prefix) + 5:] for k in g.files if k.startswith(prefix + "gidx.")]:
+        got = leaves[key].grad.reshape(-1)[g[f"{prefix}gidx.{key}"]]
+        close(got, g[f"{prefix}gval.{key}"], 0.0, atol=rel * float(g[f"{prefix}gmax.{key}"]))
+        n += 1
+    return n
+
+
+def test_gv4b_discriminator_ps48():
+    """Full-size Discriminator (patch_size 48, batch 16, Linear(73728, 1024)) vs the imported reference."""
+    g = load("gv4b_discriminator_ps48")
+    sd = dis_sd(48)
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    a = detrand.image_batch((16, 3, 192, 192), 21)
+    b = detrand.image_batch((16, 3, 192, 192), 22).requires_grad_(True)
+    o1 = OM.discriminator_forward(leaves, a)
+    o2 = OM.discriminator_forward(leaves, b)
+    close(o1.detach(), g["o1"], 1e-5); close(o2.detach(), g["o2"], 1e-5)
+    l = F.binary_cross_entropy_with_logits(o1 - o2, torch.ones(16, 1))
+    close(l.item(), g["loss"], 1e-6)
+    l.backward()
+    close(b.grad.reshape(-1)[g["gin_idx"]], g["gin_val"], 0.0, atol=1e-4 * float(g["gin_max"]))
+    assert _sampled(leaves, g, "", 1e-4) == 28
+    for k, v in leaves.items():
+        if "running" in k:
+            close(v, g["buf." + k], 1e-5)
+
+
+def test_gv7b_vgg_192():
+    g = load("gv7b_vgg_192")
+    sd = vgg_sd()
+    a = detrand.image_batch((2, 3, 192, 192), 31).requires_grad_(True)
+    b = detrand.image_batch((2, 3, 192, 192), 32)
+    fa, fb = OM.vgg_forward(sd, a, b)
+    close(fa.detach().reshape(-1)[g["f_idx"]], g["f_sr"], 1e-5); close(fb.reshape(-1)[g["f_idx"]], g["f_hr"], 1e-5)
+    m = F.mse_loss(fa, fb)
+    close(m.item(), g["mse"], 1e-5)
+    m.backward()
+    close(a.grad.reshape(-1)[g["gin_idx"]], g["gin_val"], 0.0, atol=1e-4 * float(g["gin_max"]))
+
+
+def test_gv8b_full_gan_step():
+    """The oracle's whole GAN step at the BENCHMARKED size (batch 16, 256 ch x 32 blocks, ps 48) against the step made with
+    the reference's own modules: losses, sampled gradients of all 170 parameter tensors, post-Adam parameters.  (Also covers
+    GV2b - the full generator forward/backward at batch 16 - which the GPU tests use directly.)  ~1 minute on 8 cores."""
+    g = load("gv8b_gan_step_full")
+    cfg = {"depth": 32, "res_scale": 0.1, "learning_rate": 5e-5}
+    st = OS.TrainState(gen_sd(256, 32), dis_sd(48), vgg_sd(), cfg)
+    lr = detrand.image_batch((16, 3, 48, 48), 100)
+    hr = detrand.image_batch((16, 3, 192, 192), 200)
+    log = OS.gan_step(st, lr, hr)
+    close([log["l1"], log["vgg"], log["g"], log["tv"], log["d"]], g["losses"], 2e-5)
+    assert _sampled(st.g, g, "G.", 2e-5) == 142
+    assert _sampled({k: v for k, v in st.d.items() if v.requires_grad or v.grad is not None}, g, "D.", 2e-5) == 28
+    for k, v in st.g.items():
+        close(v.detach().reshape(-1)[g["G.idx." + k]], g["G.val." + k], 1e-5)
+    for k, v in st.d.items():
+        close(v.detach().reshape(-1).float()[g["D.idx." + k]], g["D.val." + k], 1e-5)
+
+
+@pytest.mark.parametrize("epoch,expect", [(1, 5e-5), (120, 5e-5), (121, 2.5e-5), (240, 2.5e-5), (241, 1.25e-5)])
 def test_step_lr_schedule(epoch, expect):
+    """Under the reference's pinned torch 0.4 (README.md:22) `_LRScheduler.__init__` leaves last_epoch = -1, so the
+    `scheduler.step()` at the start of epoch e (train.py:156,185-186) sets last_epoch = e-1: the first halving is epoch
+    lr_step + 1 = 121."""
     assert OS.step_lr(5e-5, epoch, 120) == pytest.approx(expect)

@@ -158,10 +158,9 @@ def main(argv=None):
     keys = ("l1", "vgg", "g", "tv", "d") if gan else ("l1",)
 
     for epoch in range(1, args.num_epochs + 1):
-        # the reference steps its schedulers at epoch START (train.py:156,185-186): epoch e trains at lr*0.5^(e//lr_step)
-        scheduler_G.step()
-        if gan:
-            scheduler_D.step()
+        # The reference calls scheduler.step() at epoch START (train.py:156,185-186); under its pinned torch 0.4 the
+        # constructor leaves last_epoch = -1, so epoch e trains at lr*0.5^((e-1)//lr_step) (first halving: epoch lr_step+1).
+        # On torch >= 1.1 the constructor already counts one step, so the same schedule is: step at the END of every epoch.
         cur_lr = optim_G.param_groups[0]["lr"]
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -204,6 +203,9 @@ def main(argv=None):
                 torch.save(G.state_dict(), os.path.join(check_point, "best_model.pt"))
             elif gan and epoch % args.snapshot_every == 0:
                 torch.save(G.state_dict(), os.path.join(check_point, "model_%d.pt" % epoch))
+        scheduler_G.step()
+        if gan:
+            scheduler_D.step()
         if world > 1:
             dist.barrier()
     if world > 1:
