@@ -39,7 +39,8 @@ int pesr_abi_version(void);
  * (reference model/basic.py:56-59). w is OIHW [O][I][3][3]. */
 int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream);
 /* many packs in one launch: desc is a DEVICE array of `count` rows of 8 int64 {w ptr, out ptr, O, I, mode, ps, R, Nn}
- * with R = ceil16(reduction channels), Nn = 16 if n-channels <= 16 else ceil64 (the sizes pesr_pack_conv3x3 derives itself) */
+ * with R = ceil16(reduction channels), Nn = 16 if n-channels <= 16 else ceil64 (the sizes pesr_pack_conv3x3 derives itself);
+ * modes 2 / 3: the F(2,3) Winograd packing of mode 0 / 1 (pesr_pack_conv3x3_wino), modes 4 / 5: the F(4,3) one */
 int pesr_pack_conv3x3_batched(const long long* desc, int count, void* stream);
 int pesr_pack_bias_ps(const float* b, float* out, int O, void* stream);
 
@@ -87,6 +88,19 @@ int pesr_pack_conv3x3_wino(const float* w, float* w_packed, int Cout, int Cin, i
 int pesr_conv3x3_wino(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask, float* y,
                       int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in,
                       void* workspace, size_t ws_bytes, void* stream);
+
+/* Stride-1 3x3 conv (pad 1) with a 1-D Winograd F(4,3) transform along x (interpolation points 0, +-1, +-2, inf): HALF of
+ * the multiplies of pesr_conv3x3_fwd, same tensors and fused epilogue as pesr_conv3x3_wino, for W % 4 == 0, Cin % 16 == 0,
+ * Cout % 64 == 0 (Cout % 256 == 0 with ps_out).  Same ATen calls of the reference `Conv` (model/basic.py:4-7).
+ * Measured relative error vs fp64: 1.2e-6 .. 1.7e-6 of the output maximum at 256 input channels (direct kernel: 3e-7).
+ * w_packed: 18 * Cin * Cout floats from pesr_pack_conv3x3_wino4 (mode 0 forward / mode 1 input gradient, as above).
+ * pesr_conv3x3_wino4_score: per-mille of the kernel's MFMA slots that do useful work for this shape (tile cover x chip
+ * fill), 0 if the shape is not supported; allow_split = 1 when the split-K workspace (pesr_conv3x3_workspace_bytes) is passed. */
+int pesr_conv3x3_wino4_score(int N, int H, int W, int Cin, int Cout, int allow_split);
+int pesr_pack_conv3x3_wino4(const float* w, float* w_packed, int Cout, int Cin, int mode, int ps, void* stream);
+int pesr_conv3x3_wino4(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask, float* y,
+                       int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in,
+                       void* workspace, size_t ws_bytes, void* stream);
 
 /* Forward 3x3 conv from a 3-channel input, stride 1 (reference `embed` model/pesr.py:23, Discriminator features.0
  * model/pesr.py:53, vgg19 features.0): x [N][H][W][3], w OIHW [Cout][3][3][3] (NOT packed), y [N][H][W][Cout]. */

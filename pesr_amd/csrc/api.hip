@@ -154,6 +154,19 @@ PESR_API int pesr_conv3x3_wino(const float* x, const float* w_packed, const floa
                                     workspace, ws_bytes, (hipStream_t)stream);
 }
 
+PESR_API int pesr_conv3x3_wino4_score(int N, int H, int W, int Cin, int Cout, int allow_split) {
+    return pesr_conv3x3_wino4_score_impl(N, H, W, Cin, Cout, allow_split);
+}
+PESR_API int pesr_pack_conv3x3_wino4(const float* w, float* w_packed, int Cout, int Cin, int mode, int ps, void* stream) {
+    return pesr_pack_conv3x3_wino4_launch(w, w_packed, Cout, Cin, mode, ps, (hipStream_t)stream);
+}
+PESR_API int pesr_conv3x3_wino4(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask,
+                                float* y, int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out,
+                                int ps_in, void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_conv3x3_wino4_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, ps_out, ps_in,
+                                     workspace, ws_bytes, (hipStream_t)stream);
+}
+
 PESR_API int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, void* stream) {
     return pesr_crop_augment_launch(pool, desc, out, B, P, nhwc, (hipStream_t)stream);
 }

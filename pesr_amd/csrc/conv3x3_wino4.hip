@@ -1,0 +1,388 @@
+// 3x3 stride-1 convolution with a 1-D Winograd F(4,3) transform along x, on the fp32-input MFMA, gfx950.
+//
+// Same contract as conv3x3_mfma.hip / conv3x3_wino.hip (reference nn.Conv2d(k=3, padding=1), model/basic.py:4-7, forward
+// and - with dgrad-transformed weights - input gradient) for widths that are multiples of 4 and Cout % 64 == 0, with HALF of
+// the direct conv's multiplies (F(2,3): 2/3).  For an x-tile of four output pixels (4t .. 4t+3) of a row and the six input
+// columns d0..d5 = x[4t-1 .. 4t+4]  (interpolation points 0, +-1, +-2, inf):
+//     V0 = 4d0 - 5d2 + d4        V1 = (d4 - 4d2) + (d3 - 4d1)     V2 = (d4 - 4d2) - (d3 - 4d1)
+//     V3 = (d4 - d2) + 2(d3 - d1)  V4 = (d4 - d2) - 2(d3 - d1)     V5 = 4d1 - 5d3 + d5
+//     U  = G g  (pack time, wino4_pack.h)
+//     M_xi = sum_{ky, ci} V_xi[row + ky - 1][ci] * U_xi[ky][ci]          (6 accumulators instead of 4 outputs x 3 taps)
+//     y0 = M0 + (M1+M2) + (M3+M4),  y1 = (M1-M2) + 2(M3-M4),  y2 = (M1+M2) + 4(M3+M4),  y3 = (M1-M2) + 8(M3-M4) + M5.
+// Measured against an fp64 conv the relative error is ~1.2e-6..1.7e-6 of the output's maximum at 256 input channels (direct
+// / F(2,3): 3..4e-7; scripts/wino4_error.py), a factor 60 inside the stated gradient tolerance (1e-4).
+//
+// One workgroup = 144 x-tiles (TR rows x TXT tiles = 576 output pixels) x 64 output channels, 8 waves.  Wave w owns the
+// 16 channels cb = w & 3 and HALF of the xi planes (xh = w >> 2: xi 3xh .. 3xh+2) for all 9 m-tiles: 27 accumulator tiles
+// (108 VGPRs).  The two halves meet in the epilogue (partial output transforms summed through LDS, fixed order).
+// Per 16-channel chunk:
+//   * A = V[halo row][xi][x-tile][16 ch] in LDS, double buffered.  The chunk's raw input goes global -> registers (issued
+//     at the top of the previous chunk) -> transform on the VALU -> ds_write into the OTHER V buffer two thirds into the
+//     previous chunk's MFMA stream: no raw image in LDS, no transform pass, ONE barrier per chunk.
+//   * B = the wave's nine [16 ch][16 k] weight slabs, loaded straight from global memory into registers two slabs ahead
+//     (a wave reads only its own 1 KiB of a slab, so there is nothing to share through LDS).
+//   * fragments in groups of 3 m-tiles, the next group's A reads issued under the current group's 12 MFMAs.
+// The 16-byte k-groups of a V entry are XOR-swizzled by ((x-tile >> 1) ^ row term) so that the ds_read_b128 fragment reads
+// are bank-conflict free for TXT = 12 (48-wide images: row term 2 * (halo row & 1)) and TXT = 8 / 16 / 24 (no row term).
+// Layers with too few tiles split the Cin chunks over workgroups (raw partial sums + the direct kernel's finish kernel).
+#include "common.h"
+#include "launchers.h"
+#include "wino4_pack.h"
+
+struct Wino4Args {
+    const float* x;     // [N][H][W][Cin]
+    const float* wp;    // packed, transformed weights [3*6][Cin/16][Cout][16]
+    const float* bias;  // [Cout] or null
+    const float* skip;  // [N][H][W][Cout] or null
+    const float* mask;  // [N][H][W][Cout] or null : result zeroed where mask <= 0
+    float* y;           // [N][H][W][Cout]
+    int N, H, W, Cin, Cout;
+    int TR, TXT;        // tile: TR output rows x TXT x-tiles (TR * TXT == 144)
+    int tiles_x, tiles_y, n_tiles;
+    int HT;             // V rows: TR + 2
+    int row_key;        // 2 when the swizzle key carries the halo-row parity (TXT % 8 == 4), else 0
+    float alpha, slope;
+    int act;
+    int ps;             // 1: output stored pixel-shuffled (r = 2): packed channel (2*si+sj)*C + c -> y[n][2oy+si][2ox+sj][c], C = Cout/4
+    int ps_in;          // 1: x is a pixel-shuffled tensor [N][2H][2W][Cin/4] read as its sub-pixel-major [N][H][W][Cin] view
+    int ksplit;         // > 1: the Cin chunks are split over ksplit workgroups per tile; raw partial sums go to slab[ks][...]
+    int chunks_per_split;
+    float* slab;
+};
+
+constexpr int W4_NT = 512, W4_BN = 64, W4_MG = 9;
+
+__global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int plane = a.TXT * 64;                          // bytes of one xi plane of a V row
+    const int v_row = 6 * plane;
+    const int v_bytes = a.HT * v_row;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int cb = wave & 3, xh = wave >> 2;
+
+    // blockIdx -> (split-K slice, pixel tile, n-tile).  Workgroups b and b + 8 share an XCD (round-robin dispatch): give every
+    // XCD a contiguous range of logical tiles, n-tile fastest, so the n_tiles workgroups that read the same pixels share an L2.
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int tiles_total = a.n_tiles * a.tiles_x * a.tiles_y * a.N;
+    const int ks = b / tiles_total;
+    int bid = b - ks * tiles_total;
+    const int nt = bid % a.n_tiles;  bid /= a.n_tiles;
+    const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int gy0 = ty * a.TR, gt0 = tx * a.TXT;          // first output row / first x-tile of the tile
+    const int n0 = nt * W4_BN;
+    const int C16T = a.Cin >> 4;
+    const int CB = ks * a.chunks_per_split;                // this workgroup's chunk range [CB, CB + C16)
+    const int C16 = (C16T - CB) < a.chunks_per_split ? (C16T - CB) : a.chunks_per_split;
+
+    // ---- A fragment offsets: lane (r, g) reads k-group g of x-tile m = 16 i + r (for an even ky; odd ky: ^ kxor) -------------
+    int a_off[W4_MG];
+#pragma unroll
+    for (int i = 0; i < W4_MG; ++i) {
+        const int m = i * 16 + r;
+        const int trow = m / a.TXT, txt = m - trow * a.TXT;
+        a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
+    }
+    const int kxor = a.row_key * 16;                       // the key's row term flips with the parity of ky
+
+    // ---- B: this lane's 16 bytes of slab (ky, xi, chunk) ---------------------------------------------------------------------
+    // (wave-uniform slab base in SGPRs + one per-lane 32-bit byte offset: no 64-bit address VGPRs)
+    const size_t slab_stride = (size_t)a.Cout * 16;        // floats between consecutive chunks of one (ky, xi)
+    const unsigned b_lane = (unsigned)(((n0 + cb * 16 + r) * 16 + g * 4) * 4);
+    auto ldb = [&](int ky, int xl, int cc) -> f32x4 {      // cc = absolute chunk
+        const char* const base = (const char*)(a.wp + ((size_t)((ky * 6 + xh * 3 + xl) * C16T + cc)) * slab_stride);
+        return *(const f32x4*)(base + b_lane);
+    };
+
+    // ---- staging items: (halo row, x-tile, 4-channel group); six input columns each; at most 2 items per thread -------------
+    const float* const x_img = a.x + (size_t)img * a.H * a.W * a.Cin;
+    const int n_items = a.HT * a.TXT * 4;
+    const int Cq = a.Cin >> 2;
+    unsigned st_off[2][6], st_mask[2];                     // byte offsets inside the image (< 4 GB per image)
+    int st_dst[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = tid + u * W4_NT;
+        const int q = it & 3, rest = it >> 2;
+        const int hrow = rest / a.TXT, txt = rest - hrow * a.TXT;
+        const int iy = gy0 - 1 + hrow, ix0 = 4 * (gt0 + txt) - 1;
+        const bool item_ok = it < n_items && iy >= 0 && iy < a.H;
+        unsigned mk = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ix = ix0 + j;
+            const bool ok = item_ok && ix >= 0 && ix < a.W;
+            mk |= ok ? (1u << j) : 0u;
+            const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
+            st_off[u][j] = (unsigned)((ok ? pix + q * 4 : q * 4) * 4);   // an out-of-image column reads a dummy in-range address, zeroed later
+        }
+        st_mask[u] = it < n_items ? (mk | 0x100u) : 0u;    // bit 8: the item exists (its V entries must be written, zeros included)
+        st_dst[u] = hrow * v_row + txt * 64 + ((q ^ (txt >> 1) ^ (a.row_key * (hrow & 1))) & 3) * 16;
+    }
+    auto chunk_off = [&](int cc) -> int {                  // channel part of an input address (floats), chunk cc (absolute)
+        int coff = cc * 16;
+        if (a.ps_in) {   // chunk = channels [16cc, 16cc+16) of sub-pixel `sub`: one pixel of the shuffled tensor
+            const int sub = coff / Cq, cc0 = coff - sub * Cq;
+            coff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * Cq + cc0;
+        }
+        return coff;
+    };
+    // The two items go through the SAME six staging registers one after the other (24 VGPRs instead of 48): item 0 is loaded
+    // at the top of a chunk and stored a third in, item 1 is loaded right there and stored two thirds in.
+    f32x4 sx[6];
+    auto stage_load = [&](int u, int cc) {
+        const char* const xc = (const char*)(x_img + chunk_off(cc));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sx[j] = *(const f32x4*)(xc + st_off[u][j]);
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto stage_store = [&](int u, char* vdst) {
+        if (st_mask[u]) {
+            const unsigned mk = st_mask[u];
+            const f32x4 d0 = (mk & 1u) ? sx[0] : zero4, d1 = (mk & 2u) ? sx[1] : zero4, d2 = (mk & 4u) ? sx[2] : zero4,
+                        d3 = (mk & 8u) ? sx[3] : zero4, d4 = (mk & 16u) ? sx[4] : zero4, d5 = (mk & 32u) ? sx[5] : zero4;
+            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
+            char* p = vdst + st_dst[u];
+            *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
+            *(f32x4*)(p + plane) = t1 + t2;
+            *(f32x4*)(p + 2 * plane) = t1 - t2;
+            *(f32x4*)(p + 3 * plane) = t3 + 2.0f * t4;
+            *(f32x4*)(p + 4 * plane) = t3 - 2.0f * t4;
+            *(f32x4*)(p + 5 * plane) = 4.0f * d1 + (d5 - 5.0f * d3);
+        }
+    };
+
+    f32x4 acc[3][W4_MG];
+#pragma unroll
+    for (int xl = 0; xl < 3; ++xl)
+#pragma unroll
+        for (int i = 0; i < W4_MG; ++i) acc[xl][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 fa[2][3], fb[3];
+#define W4_READ_A(FA, VB, KY, XL, GRP)                                                                   \
+    {                                                                                                    \
+        const char* const vb_ = (VB) + (KY) * v_row + (xh * 3 + (XL)) * plane;                           \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
+            FA[i] = *(const f32x4*)(vb_ + (a_off[(GRP) * 3 + i] ^ (((KY) & 1) ? kxor : 0)));             \
+    }
+#define W4_MFMA(FA, FB, XL, GRP)                                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
+            acc[XL][(GRP) * 3 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[i][kk], FB[kk], acc[XL][(GRP) * 3 + i], 0, 0, 0);
+
+    // ---- prologue: chunk CB staged synchronously, the first two weight slabs -------------------------------------------------
+    stage_load(0, CB);
+    fb[0] = ldb(0, 0, CB);
+    fb[1] = ldb(0, 1, CB);
+    stage_store(0, smem);
+    stage_load(1, CB);
+    stage_store(1, smem);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < C16; ++c) {
+        char* const vcur = smem + (c & 1) * v_bytes;
+        char* const vnext = smem + ((c & 1) ^ 1) * v_bytes;
+        const bool more = c + 1 < C16;
+        if (more) stage_load(0, CB + c + 1);               // lands while this chunk computes
+        W4_READ_A(fa[0], vcur, 0, 0, 0)
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {                      // slab s = (ky, xl)
+            const int ky = s / 3, xl = s - ky * 3;
+            // weight slab s + 2 (of this chunk, or the first ones of the next)
+            if (s + 2 < 9) fb[(s + 2) % 3] = ldb((s + 2) / 3, (s + 2) % 3, CB + c);
+            else if (more) fb[(s + 2) % 3] = ldb(0, s + 2 - 9, CB + c + 1);
+#pragma unroll
+            for (int grp = 0; grp < 3; ++grp) {
+                const int t = s * 3 + grp, cur = t & 1;
+                if (grp < 2) W4_READ_A(fa[cur ^ 1], vcur, ky, xl, grp + 1)
+                else if (s < 8) W4_READ_A(fa[cur ^ 1], vcur, (s + 1) / 3, (s + 1) % 3, 0)
+                __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of the MFMA group (hipcc sinks it next to its use)
+                W4_MFMA(fa[cur], fb[s % 3], xl, grp)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // a third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs
+            if (s == 2 && more) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
+            if (s == 6 && more) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
+        }
+        __syncthreads();                                   // V[next] complete and visible; everyone is done with V[cur]
+    }
+#undef W4_READ_A
+#undef W4_MFMA
+
+    // ---- epilogue: partial output transforms of the two xi halves summed through LDS, coalesced stores ------------------------
+    constexpr int RS = W4_BN * 4 + 16;                     // padded row stride of the staged tile (bytes)
+    constexpr int C4 = W4_BN / 4;
+    char* const ob = smem;
+    const int prow = 4 * a.TXT;                            // output pixels per tile row
+    if (xh == 0) {
+#pragma unroll
+        for (int i = 0; i < W4_MG; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = i * 16 + g * 4 + jj;
+                const int trow = m / a.TXT, txt = m - trow * a.TXT;
+                const float m0 = acc[0][i][jj], m1 = acc[1][i][jj], m2 = acc[2][i][jj];
+                const float sm = m1 + m2, df = m1 - m2;
+                char* o = ob + (trow * prow + 4 * txt) * RS + (cb * 16 + r) * 4;
+                *(float*)(o) = m0 + sm;
+                *(float*)(o + RS) = df;
+                *(float*)(o + 2 * RS) = sm;
+                *(float*)(o + 3 * RS) = df;
+            }
+    }
+    __syncthreads();
+    if (xh == 1) {
+#pragma unroll
+        for (int i = 0; i < W4_MG; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = i * 16 + g * 4 + jj;
+                const int trow = m / a.TXT, txt = m - trow * a.TXT;
+                const float m3 = acc[0][i][jj], m4 = acc[1][i][jj], m5 = acc[2][i][jj];
+                const float sm = m3 + m4, df = m3 - m4;
+                char* o = ob + (trow * prow + 4 * txt) * RS + (cb * 16 + r) * 4;
+                *(float*)(o) += sm;
+                *(float*)(o + RS) += 2.0f * df;
+                *(float*)(o + 2 * RS) += 4.0f * sm;
+                *(float*)(o + 3 * RS) += 8.0f * df + m5;
+            }
+    }
+    __syncthreads();
+    const size_t img_out = (size_t)img * a.H * a.W;
+    const int npix = 576;
+    for (int u = tid; u < npix * C4; u += W4_NT) {
+        const int p = u / C4, c4 = u - p * C4;
+        const int co = n0 + c4 * 4;
+        const int py = p / prow, px = p - py * prow;
+        const int oy = gy0 + py, ox = 4 * gt0 + px;
+        if (oy >= a.H || ox >= a.W) continue;
+        f32x4 v = *(const f32x4*)(ob + p * RS + c4 * 16);
+        size_t idx;
+        if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
+            const int C = a.Cout >> 2;
+            const int sub = co / C, cc = co - sub * C;
+            idx = (((size_t)img * (2 * a.H) + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1)) * C + cc;
+        } else {
+            idx = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+        }
+        if (a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
+            *(f32x4*)(a.slab + (size_t)ks * ((size_t)a.N * a.H * a.W * a.Cout) + idx) = v;
+            continue;
+        }
+        if (a.bias) v += *(const f32x4*)(a.bias + co);
+        v *= a.alpha;
+        if (a.mask) {
+            const f32x4 mk = *(const f32x4*)(a.mask + idx);
+            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
+        if (a.skip) v += *(const f32x4*)(a.skip + idx);
+        if (a.act == PESR_ACT_RELU) {
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        } else if (a.act == PESR_ACT_LRELU) {
+            v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+            v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+        }
+        *(f32x4*)(a.y + idx) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight transform + packing (wino4_pack.h)
+__global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode, int ps) {
+    const long total = 18L * O * I;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+        out[e] = pesr_wino4_pack_elem(w, O, I, mode, ps, e);
+}
+
+int pesr_pack_conv3x3_wino4_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream) {
+    if (O % 16 || I % 16 || (mode != 0 && mode != 1) || (ps && O % 64)) return PESR_EINVAL;
+    const long total = 18L * O * I;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_wino4_kernel, dim3(grid), dim3(256), 0, stream, w, out, O, I, mode, ps);
+    return pesr_launch_status();
+}
+
+namespace {
+struct W4Plan { int TR, TXT, tiles_x, tiles_y, n_tiles, ksplit, chunks_per_split; long tiles; size_t lds; int score; };
+
+// Tile shape TR x TXT == 144 x-tiles with the least out-of-image area that fits LDS (two V buffers) and the 2 staging items per
+// thread; split-K over the Cin chunks when the tiles alone cannot fill the 256 CUs.  score = per-mille of the issued MFMA
+// slots that do useful work (tile cover x last-round fill), 0 when the shape is not supported.
+static bool w4_plan(int N, int H, int W, int Cin, int Cout, bool allow_split, size_t ws_bytes, W4Plan* p) {
+    if (N < 1 || H < 1 || W < 4 || W % 4 || Cin % 16 || Cin < 16 || Cout % W4_BN) return false;
+    const int XT = W / 4;
+    long best = -1;
+    for (int TXT = 1; TXT <= 144; ++TXT) {
+        if (144 % TXT) continue;
+        const int TR = 144 / TXT, HT = TR + 2;
+        const size_t vb = (size_t)2 * HT * 6 * TXT * 64;
+        if (vb > 160 * 1024 || HT * TXT * 4 > 2 * W4_NT) continue;
+        const long cover = (long)pesr_cdiv(H, TR) * TR * pesr_cdiv(XT, TXT) * TXT;
+        const long score = cover * 4096 + (long)HT * TXT;      // least waste first, then the smallest halo
+        if (best < 0 || score < best) { best = score; p->TR = TR; p->TXT = TXT; }
+    }
+    if (best < 0) return false;
+    p->tiles_y = pesr_cdiv(H, p->TR); p->tiles_x = pesr_cdiv(XT, p->TXT); p->n_tiles = Cout / W4_BN;
+    p->tiles = (long)N * p->tiles_y * p->tiles_x * p->n_tiles;
+    const size_t vb = (size_t)2 * (p->TR + 2) * 6 * p->TXT * 64, ob = (size_t)576 * (W4_BN * 4 + 16);
+    p->lds = vb > ob ? vb : ob;
+    const int C16T = Cin / 16;
+    p->ksplit = 1; p->chunks_per_split = C16T;
+    const size_t out_bytes = (size_t)N * H * W * Cout * sizeof(float);
+    if (allow_split && p->tiles < 160 && C16T >= 8) {
+        int want = (int)((256 + p->tiles - 1) / p->tiles);
+        if (want > 8) want = 8;
+        if (want > C16T / 4) want = C16T / 4;
+        while (want > 1 && (size_t)want * out_bytes > ws_bytes) --want;
+        if (want > 1) {
+            p->chunks_per_split = (C16T + want - 1) / want;
+            p->ksplit = (C16T + p->chunks_per_split - 1) / p->chunks_per_split;
+        }
+    }
+    const long wgs = p->tiles * p->ksplit;
+    const long rounds = (wgs + 255) / 256;
+    const double cover_eff = (double)((long)H * XT) / ((double)p->tiles_y * p->TR * p->tiles_x * p->TXT);
+    const double fill = (double)wgs / (double)(rounds * 256);
+    p->score = (int)(1000.0 * cover_eff * fill);
+    return true;
+}
+}  // namespace
+
+// per-mille of useful MFMA slots (0: unsupported shape).  allow_split = 1 assumes the caller passes the split-K workspace.
+int pesr_conv3x3_wino4_score_impl(int N, int H, int W, int Cin, int Cout, int allow_split) {
+    W4Plan p;
+    if (!w4_plan(N, H, W, Cin, Cout, allow_split != 0, (size_t)-1, &p)) return 0;
+    return p.score;
+}
+
+int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
+                              int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
+                              void* ws, size_t ws_bytes, hipStream_t stream) {
+    W4Plan p;
+    if (!w4_plan(N, H, W, Cin, Cout, ws != nullptr && !ps, ws_bytes, &p)) return PESR_EINVAL;
+    if (ps && (Cout % 256 || skip || mask)) return PESR_EINVAL;    // a 64-channel n-tile must stay inside one sub-pixel plane
+    if (ps_in && Cin % 64) return PESR_EINVAL;
+    Wino4Args a{};
+    a.x = x; a.wp = wp; a.bias = bias; a.skip = skip; a.mask = mask; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
+    a.TR = p.TR; a.TXT = p.TXT; a.HT = p.TR + 2;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
+    a.row_key = (p.TXT % 8 == 4) ? 2 : 0;
+    a.ksplit = p.ksplit; a.chunks_per_split = p.chunks_per_split; a.slab = (float*)ws;
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)(p.tiles * p.ksplit)), dim3(W4_NT), p.lds, stream, a);
+    if (p.ksplit > 1)
+        return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, act,
+                                              slope, stream);
+    return pesr_launch_status();
+}

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "launchers.h"
 #include "wino_pack.h"
+#include "wino4_pack.h"
 
 // R (reduction channels) is zero-padded to a multiple of 16 and Nn ("n" channels) to 16 (if <= 16) or a multiple of 64, so
 // the 3-channel RGB layers run on the same MFMA kernels.
@@ -39,6 +40,12 @@ __global__ void pack_conv3x3_batched_kernel(const long long* __restrict__ desc) 
     const float* __restrict__ w = (const float*)d[0];
     float* __restrict__ out = (float*)d[1];
     const int O = (int)d[2], I = (int)d[3], mode = (int)d[4], ps = (int)d[5], R = (int)d[6], Nn = (int)d[7];
+    if (mode >= 4) {   // Winograd F(4,3) packing (conv3x3_wino4.hip): mode 4 = forward, 5 = dgrad
+        const long total_w = 18L * O * I;
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total_w; e += (long)gridDim.x * blockDim.x)
+            out[e] = pesr_wino4_pack_elem(w, O, I, mode - 4, ps, e);
+        return;
+    }
     if (mode >= 2) {   // Winograd packing (conv3x3_wino.hip): mode 2 = forward, 3 = dgrad
         const long total_w = 12L * O * I;
         for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total_w; e += (long)gridDim.x * blockDim.x)

@@ -72,11 +72,11 @@ _ALL_PACKS = []   # weak registry of every PackedConvWeights (for the batched re
 
 class _PackSlot:
     """The packed layouts of one weight tensor ON ONE DEVICE."""
-    __slots__ = ("fwd", "dgrad", "bias", "wfwd", "wdgrad", "kf", "kd", "kb", "kwf", "kwd", "wref")
+    __slots__ = ("fwd", "dgrad", "bias", "wfwd", "wdgrad", "w4fwd", "w4dgrad", "kf", "kd", "kb", "kwf", "kwd", "k4f", "k4d", "wref")
 
     def __init__(self):
-        self.fwd = self.dgrad = self.bias = self.wfwd = self.wdgrad = None
-        self.kf = self.kd = self.kb = self.kwf = self.kwd = None
+        self.fwd = self.dgrad = self.bias = self.wfwd = self.wdgrad = self.w4fwd = self.w4dgrad = None
+        self.kf = self.kd = self.kb = self.kwf = self.kwd = self.k4f = self.k4d = None
         self.wref = None            # weakref to the weight tensor this slot was last built from
 
 
@@ -139,9 +139,18 @@ class PackedConvWeights:
     def wino_dgrad(self, w: torch.Tensor):
         return self._get(w, "wdgrad", "kwd", lambda: ops.pack_conv3x3_wino(w.detach(), 1, self.ps))
 
+    def wino4_fwd(self, w: torch.Tensor):
+        return self._get(w, "w4fwd", "k4f", lambda: ops.pack_conv3x3_wino4(w.detach(), 0, self.ps))
+
+    def wino4_dgrad(self, w: torch.Tensor):
+        return self._get(w, "w4dgrad", "k4d", lambda: ops.pack_conv3x3_wino4(w.detach(), 1, self.ps))
+
     def for_fwd(self, w: torch.Tensor, x_shape, stride: int = 1):
-        """Packed weights for y = conv(x, w): the Winograd packing where that kernel applies, else the direct one."""
+        """Packed weights for y = conv(x, w): Winograd F(4,3) where that kernel applies and fills the chip, else F(2,3)
+        where THAT applies, else the direct packing."""
         N, H, W, Cin = x_shape
+        if ops.wino4_eligible(N, H, W, Cin, w.shape[0], stride, ps_out=self.ps):
+            return self.wino4_fwd(w)
         if ops.wino_eligible(N, H, W, Cin, w.shape[0], stride):
             return self.wino_fwd(w)
         return self.fwd(w)
@@ -149,6 +158,8 @@ class PackedConvWeights:
     def for_dgrad(self, w: torch.Tensor, x_shape, stride: int = 1):
         """Packed weights for dx of y = conv(x, w) with x of NHWC shape x_shape."""
         N, H, W, Cin = x_shape
+        if ops.wino4_eligible(N, H, W, w.shape[0], Cin, stride):
+            return self.wino4_dgrad(w)
         if ops.wino_eligible(N, H, W, w.shape[0], Cin, stride):
             return self.wino_dgrad(w)
         return self.dgrad(w)
@@ -262,9 +273,11 @@ def repack_all(params) -> None:
                     continue
                 R, Nn = (I, O) if mode == 0 else (O, I)
                 jobs.append((sl, w, mode, (w.data_ptr(), buf.data_ptr(), O, I, mode, int(c.ps), (R + 15) // 16 * 16, 16 if Nn <= 16 else (Nn + 63) // 64 * 64)))
-            for mode, wpk in ((2, sl.wfwd), (3, sl.wdgrad)):      # Winograd packings (batched kernel modes 2 / 3)
+            # Winograd packings (batched kernel modes 2 / 3: F(2,3), 4 / 5: F(4,3))
+            for mode, wpk in ((2, sl.wfwd), (3, sl.wdgrad), (4, sl.w4fwd), (5, sl.w4dgrad)):
                 if wpk is not None:
-                    jobs.append((sl, w, mode, (w.data_ptr(), wpk.t.data_ptr(), O, I, mode, int(c.ps), I if mode == 2 else O, O if mode == 2 else I)))
+                    fwd_like = mode in (2, 4)
+                    jobs.append((sl, w, mode, (w.data_ptr(), wpk.t.data_ptr(), O, I, mode, int(c.ps), I if fwd_like else O, O if fwd_like else I)))
     if not jobs:
         return
     dev = jobs[0][1].device
@@ -284,8 +297,12 @@ def repack_all(params) -> None:
             sl.kd = k
         elif mode == 2:
             sl.kwf = k
-        else:
+        elif mode == 3:
             sl.kwd = k
+        elif mode == 4:
+            sl.k4f = k
+        else:
+            sl.k4d = k
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:

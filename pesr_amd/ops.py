@@ -134,6 +134,42 @@ def wino_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1) 
     return per_img * 144 <= 1.15 * H * (W // 2) and wgs * min(8, Cin // 64) >= 192
 
 
+class Wino4Packed:
+    """Weights packed for the Winograd F(4,3)-along-x kernel (pesr_pack_conv3x3_wino4)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
+USE_WINO4 = __import__("os").environ.get("PESR_WINO4", "1") != "0"   # PESR_WINO4=0: no F(4,3) kernel (F(2,3) / direct instead)
+_W4_SCORE = {}
+
+
+def wino4_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps_out: bool = False) -> bool:
+    """The F(4,3) kernel applies (stride 1, W % 4 == 0, Cin % 16 == 0, Cout % 64 == 0; Cout % 256 == 0 with a fused
+    PixelShuffle store) AND at least 78 % of its MFMA slots do useful work for this shape (576-pixel x 64-channel tiles
+    covering the image x filling the 256 CUs, split-K included): it issues 1/2 of the direct conv's MFMAs where F(2,3)
+    issues 2/3, so it wins from ~0.75 of F(2,3)'s efficiency up.  Cin / Cout are those of the problem the kernel runs."""
+    if not (USE_WINO and USE_WINO4) or stride != 1 or W % 4 or Cin % 16 or Cout % 64 or (ps_out and Cout % 256):
+        return False
+    key = (N, H, W, Cin, Cout, ps_out)
+    sc = _W4_SCORE.get(key)
+    if sc is None:
+        sc = _W4_SCORE[key] = _lib.lib().pesr_conv3x3_wino4_score(N, H, W, Cin, Cout, 0 if ps_out else 1)
+    return sc >= 780
+
+
+def pack_conv3x3_wino4(w: torch.Tensor, mode: int, ps: bool = False) -> Wino4Packed:
+    """OIHW [O, I, 3, 3] -> transformed [18, R/16, Nn, 16] (mode 0: forward, mode 1: dgrad; ps: sub-pixel-major O order)."""
+    _chk(w, "pack_conv3x3_wino4.w")
+    O, I = w.shape[0], w.shape[1]
+    out = torch.empty(18 * O * I, dtype=torch.float32, device=w.device)
+    rc = _lib.lib().pesr_pack_conv3x3_wino4(_p(w), _p(out), O, I, mode, int(ps), _stream())
+    _lib.check(rc, f"pesr_pack_conv3x3_wino4[{O}x{I},mode{mode}]")
+    return Wino4Packed(out)
+
+
 def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacked:
     """OIHW [O, I, 3, 3] -> transformed [12, R/16, Nn, 16] (mode 0: forward, mode 1: dgrad; ps: sub-pixel-major O order)."""
     _chk(w, "pack_conv3x3_wino.w")
@@ -144,13 +180,16 @@ def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacke
     return WinoPacked(out)
 
 
-def _conv3x3_wino(x, wp: WinoPacked, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, what, ps_out=False, ps_in=False):
+def _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, what, ps_out=False, ps_in=False):
+    """Both Winograd kernels (WinoPacked -> F(2,3), Wino4Packed -> F(4,3)): same arguments, same fused epilogue."""
     L = _lib.lib()
     nws = L.pesr_conv3x3_workspace_bytes(N, H, W, cout) if not ps_out else 0     # split-K scratch for layers with few tiles
     ws = workspace(nws, x.device) if nws else None
-    rc = L.pesr_conv3x3_wino(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope,
-                             int(ps_out), int(ps_in), _p(ws), nws, _stream())
-    _lib.check(rc, f"pesr_conv3x3_wino[{what} {N}x{H}x{W}x{Cin}->{cout}]")
+    four = isinstance(wp, Wino4Packed)
+    fn = L.pesr_conv3x3_wino4 if four else L.pesr_conv3x3_wino
+    rc = fn(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope,
+            int(ps_out), int(ps_in), _p(ws), nws, _stream())
+    _lib.check(rc, f"pesr_conv3x3_wino{'4' if four else ''}[{what} {N}x{H}x{W}x{Cin}->{cout}]")
 
 
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout: int, stride: int = 1,
@@ -179,7 +218,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         wp = wp()
     br = KERNEL_EVENTS.begin("fwd", N, H, W, Cin, cout, stride)
     L = _lib.lib()
-    if isinstance(wp, WinoPacked):
+    if isinstance(wp, (WinoPacked, Wino4Packed)):
         assert stride == 1
         _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, "fwd", ps_out=ps_out)
         rc = 0
@@ -207,7 +246,7 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
             assert t.shape == dx.shape
     L = _lib.lib()
     br = KERNEL_EVENTS.begin("dgrad", N, H, W, Cin, cout, stride)
-    if isinstance(wpd, WinoPacked):     # the input gradient is the conv of dy with the flipped, transposed kernel
+    if isinstance(wpd, (WinoPacked, Wino4Packed)):     # the input gradient is the conv of dy with the flipped, transposed kernel
         assert stride == 1
         _conv3x3_wino(dy, wpd, None, skip, mask, dx, N, H, W, cout, Cin, alpha, ACT_NONE, 0.0, "dgrad", ps_in=ps_in)
         KERNEL_EVENTS.end(br)

@@ -54,6 +54,9 @@ def main():
         t = t / world
         t[keys.index("tv")] *= world
         losses.append(t.cpu())
+        if it == 0:      # gradients of the FIRST step (averaged over ranks = the full-batch ones): the tight comparison
+            g0 = {"G": {k: (p.grad * oG.last_scale).cpu() for k, p in G.named_parameters()},
+                  "D": {k: (p.grad * oD.last_scale).cpu() for k, p in D.named_parameters()}}
     # replicas must hold bit-identical parameters (same all-reduced gradients, same Adam)
     for opt in (oG, oD):
         mine = opt.flat.flat_p.clone()
@@ -63,8 +66,7 @@ def main():
     if rank == 0:
         torch.save({"losses": torch.stack(losses),
                     "G": {k: v.cpu() for k, v in G.state_dict().items()}, "D": {k: v.cpu() for k, v in D.state_dict().items()},
-                    "G.grad": {k: (p.grad * oG.last_scale).cpu() for k, p in G.named_parameters()},
-                    "D.grad": {k: (p.grad * oD.last_scale).cpu() for k, p in D.named_parameters()},
+                    "G.grad": g0["G"], "D.grad": g0["D"],
                     "world": world}, args.out)
     dist.barrier()
     dist.destroy_process_group()
