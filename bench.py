@@ -303,24 +303,30 @@ def main():
 def roofline_objects(args, kern):
     """`roofline` (the dominant kernel: forward of the G body conv) + `roofline_kernels` (the other two body kernels).
     achieved = ALGORITHMIC flops of the conv / mean HIP-event duration of its launches inside the timed steps;
-    frac = flops the kernel ISSUES on the matrix pipe (2/3 of the algorithmic ones for the 1-D Winograd F(2,3) kernels)
+    frac = flops the kernel ISSUES on the matrix pipe (1/2 of the algorithmic ones for the 1-D Winograd F(4,3) kernel, 2/3 for F(2,3))
     / duration / peak, i.e. matrix-pipe utilisation - the honest hardware fraction; algorithmic_frac = achieved / peak."""
     from pesr_amd import ops as _ops
     scale = (args.batch / 16) * (args.patch_size / 48) ** 2 * (args.num_channels / 256) ** 2
-    wino = _ops.wino_eligible(args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels)
+    bs = (args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels)
+    # (kernel name, fraction of the conv's algorithmic flops the kernel issues on the matrix pipe)
+    if _ops.wino4_eligible(*bs):
+        conv_k = ("conv3x3_wino4_kernel", 0.5)
+    elif _ops.wino_eligible(*bs):
+        conv_k = ("conv3x3_wino_kernel", 2.0 / 3.0)
+    else:
+        conv_k = ("conv3x3_mfma_kernel<1, 8, 9, 2, 1, 2", 1.0)
     wg_wino = _ops.USE_WGRAD_WINO and args.patch_size % 2 == 0 and args.patch_size >= 48 and args.num_channels % 64 == 0
+    wg_k = _ops.wgrad_kernel_for(*bs) if hasattr(_ops, "wgrad_kernel_for") else \
+        (("conv3x3_wgrad_wino_kernel", 2.0 / 3.0) if wg_wino else ("conv3x3_wgrad_kernel", 1.0))
     shape = f"G body {args.num_channels}->{args.num_channels} @{args.patch_size}x{args.patch_size}, batch {args.batch}"
-    names = {"fwd": ("conv3x3_wino_kernel" if wino else "conv3x3_mfma_kernel<1, 8, 9, 2, 1, 2", wino,
-                     f"forward ({shape}: 65 G launches + the 6 same-shaped VGG conv3_2..3_4 launches per GAN step)"),
-             "dgrad": ("conv3x3_wino_kernel" if wino else "conv3x3_mfma_kernel<1, 8, 9, 2, 1, 2", wino,
-                       f"input gradient ({shape}: 65 G + 3 VGG launches per GAN step)"),
-             "wgrad": ("conv3x3_wgrad_wino_kernel" if wg_wino else "conv3x3_wgrad_kernel", wg_wino,
-                       f"weight gradient incl. its split-K reduce kernel ({shape}: 65 launches per step)")}
+    names = {"fwd": conv_k + (f"forward ({shape}: 65 G launches + the 6 same-shaped VGG conv3_2..3_4 launches per GAN step)",),
+             "dgrad": conv_k + (f"input gradient ({shape}: 65 G + 3 VGG launches per GAN step)",),
+             "wgrad": wg_k + (f"weight gradient incl. its split-K reduce kernel ({shape}: 65 launches per step)",)}
     objs = {}
     for kind, (ms, n) in kern.items():
-        kname, is_wino, label = names[kind]
+        kname, issue_frac, label = names[kind]
         ach = K1_GFLOP * scale / ms                                  # algorithmic TFLOP/s
-        issued = ach * (2.0 / 3.0 if is_wino else 1.0)
+        issued = ach * issue_frac
         traffic, src = k1_hbm_traffic_bytes(kname)
         o = {"kernel": f"{kname} {label}", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
              "unit": "TFLOP/s", "frac": round(issued / PEAK_F32_MFMA_TFLOPS, 4),
@@ -329,8 +335,9 @@ def roofline_objects(args, kern):
              "traffic_note": (f"HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in profiles/{src}"
                               if src else "no committed PMC summary found"),
              "launches_timed": n, "avg_launch_us": round(ms * 1e3, 2)}
-        if is_wino:
-            o["note"] = ("1-D Winograd F(2,3): the kernel issues 2/3 of the direct conv's MFMA flops; frac counts the ISSUED flops "
+        if issue_frac < 1.0:
+            o["note"] = (f"1-D Winograd {'F(4,3)' if issue_frac == 0.5 else 'F(2,3)'}: the kernel issues "
+                         f"{'1/2' if issue_frac == 0.5 else '2/3'} of the direct conv's MFMA flops; frac counts the ISSUED flops "
                          "(matrix-pipe utilisation), algorithmic_frac the conv's algorithmic flops")
         objs[kind] = o
     out = {}

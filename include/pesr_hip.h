@@ -94,8 +94,8 @@ int pesr_conv3x3_wino(const float* x, const float* w_packed, const float* bias, 
  * Cout % 64 == 0 (Cout % 256 == 0 with ps_out).  Same ATen calls of the reference `Conv` (model/basic.py:4-7).
  * Measured relative error vs fp64: 1.2e-6 .. 1.7e-6 of the output maximum at 256 input channels (direct kernel: 3e-7).
  * w_packed: 18 * Cin * Cout floats from pesr_pack_conv3x3_wino4 (mode 0 forward / mode 1 input gradient, as above).
- * pesr_conv3x3_wino4_score: per-mille of the kernel's MFMA slots that do useful work for this shape (tile cover x chip
- * fill), 0 if the shape is not supported; allow_split = 1 when the split-K workspace (pesr_conv3x3_workspace_bytes) is passed. */
+ * pesr_conv3x3_wino4_score: per-mille of the kernel's 576-pixel tiles that lies inside the image, or 0 if the shape is not
+ * supported or gives fewer than 192 workgroups; allow_split = 1 when the split-K workspace (pesr_conv3x3_workspace_bytes) is passed. */
 int pesr_conv3x3_wino4_score(int N, int H, int W, int Cin, int Cout, int allow_split);
 int pesr_pack_conv3x3_wino4(const float* w, float* w_packed, int Cout, int Cin, int mode, int ps, void* stream);
 int pesr_conv3x3_wino4(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask, float* y,

@@ -311,8 +311,8 @@ namespace {
 struct W4Plan { int TR, TXT, tiles_x, tiles_y, n_tiles, ksplit, chunks_per_split; long tiles; size_t lds; int score; };
 
 // Tile shape TR x TXT == 144 x-tiles with the least out-of-image area that fits LDS (two V buffers) and the 2 staging items per
-// thread; split-K over the Cin chunks when the tiles alone cannot fill the 256 CUs.  score = per-mille of the issued MFMA
-// slots that do useful work (tile cover x last-round fill), 0 when the shape is not supported.
+// thread; split-K over the Cin chunks when the tiles alone cannot fill the 256 CUs.  score = per-mille of the tiles' x-tile
+// slots that lie inside the image, or 0 when the shape is not supported or yields fewer than 192 workgroups.
 static bool w4_plan(int N, int H, int W, int Cin, int Cout, bool allow_split, size_t ws_bytes, W4Plan* p) {
     if (N < 1 || H < 1 || W < 4 || W % 4 || Cin % 16 || Cin < 16 || Cout % W4_BN) return false;
     const int XT = W / 4;
@@ -344,16 +344,17 @@ static bool w4_plan(int N, int H, int W, int Cin, int Cout, bool allow_split, si
             p->ksplit = (C16T + p->chunks_per_split - 1) / p->chunks_per_split;
         }
     }
+    // The F(2,3) kernel's tiles (288 pixels x 128 channels) give the same workgroup count, so chip fill does not separate the
+    // two; below ~3/4 of a round neither beats the direct kernel's smaller tiles.
     const long wgs = p->tiles * p->ksplit;
-    const long rounds = (wgs + 255) / 256;
     const double cover_eff = (double)((long)H * XT) / ((double)p->tiles_y * p->TR * p->tiles_x * p->TXT);
-    const double fill = (double)wgs / (double)(rounds * 256);
-    p->score = (int)(1000.0 * cover_eff * fill);
+    p->score = wgs >= 192 ? (int)(1000.0 * cover_eff) : 0;
     return true;
 }
 }  // namespace
 
-// per-mille of useful MFMA slots (0: unsupported shape).  allow_split = 1 assumes the caller passes the split-K workspace.
+// per-mille of tile area inside the image (0: unsupported shape or too few workgroups).  allow_split = 1 assumes the caller
+// passes the split-K workspace.
 int pesr_conv3x3_wino4_score_impl(int N, int H, int W, int Cin, int Cout, int allow_split) {
     W4Plan p;
     if (!w4_plan(N, H, W, Cin, Cout, allow_split != 0, (size_t)-1, &p)) return 0;

@@ -148,9 +148,9 @@ _W4_SCORE = {}
 
 def wino4_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps_out: bool = False) -> bool:
     """The F(4,3) kernel applies (stride 1, W % 4 == 0, Cin % 16 == 0, Cout % 64 == 0; Cout % 256 == 0 with a fused
-    PixelShuffle store) AND at least 78 % of its MFMA slots do useful work for this shape (576-pixel x 64-channel tiles
-    covering the image x filling the 256 CUs, split-K included): it issues 1/2 of the direct conv's MFMAs where F(2,3)
-    issues 2/3, so it wins from ~0.75 of F(2,3)'s efficiency up.  Cin / Cout are those of the problem the kernel runs."""
+    PixelShuffle store), its 576-pixel x 64-channel tiles (split-K included) give at least 192 workgroups, AND at least 78 %
+    of the tile area lies inside the image: it issues 1/2 of the direct conv's MFMAs where F(2,3) issues 2/3, so it wins
+    from ~0.75 of F(2,3)'s tile efficiency up.  Cin / Cout are those of the problem the kernel runs."""
     if not (USE_WINO and USE_WINO4) or stride != 1 or W % 4 or Cin % 16 or Cout % 64 or (ps_out and Cout % 256):
         return False
     key = (N, H, W, Cin, Cout, ps_out)

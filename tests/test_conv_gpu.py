@@ -199,6 +199,72 @@ def test_conv3x3_winograd_kernel(N, H, W, Cin, Cout):
         _close(_nchw(dx), torch.where(x > 0, dx_ref, torch.zeros_like(dx_ref)) + x, 2e-6 * (Cout * 9) ** 0.5)
 
 
+WINO4_CASES = [
+    # N, H, W, Cin, Cout     (W % 4 == 0, Cout % 64 == 0)
+    (1, 12, 48, 16, 64),
+    (2, 7, 12, 32, 64),       # ragged: partial tile rows, 3 x-tiles per row
+    (1, 48, 48, 256, 256),    # K1 shape, one image
+    (1, 13, 96, 64, 128),
+    (2, 5, 4, 16, 64),        # one x-tile per row
+    (1, 9, 196, 16, 64),      # wider than one tile
+    (16, 24, 24, 512, 512),   # few tiles: split-K over the Cin chunks + finish kernel
+    (1, 30, 20, 48, 192),     # 5 x-tiles per row, Cin not a multiple of 64
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", WINO4_CASES)
+def test_conv3x3_winograd4_kernel(N, H, W, Cin, Cout):
+    """Winograd F(4,3)-along-x kernel (conv3x3_wino4.hip) against the oracle: forward with every fused epilogue, input
+    gradient.  Its measured error vs fp64 is <= 2.3e-6 of the output maximum (scripts/wino4_test.py); the bound here is 1e-5."""
+    from pesr_amd import ops
+    x = _rand(N, Cin, H, W, seed=1); w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.1); b = _rand(Cout, seed=3)
+    skip = _rand(N, Cout, H, W, seed=4); mk = _rand(N, Cout, H, W, seed=5)
+    ref = O.conv3x3(x, w, b)
+    wf = ops.pack_conv3x3_wino4(w.cuda(), 0)
+    y = ops.conv3x3_fwd(_nhwc(x), wf, b.cuda(), Cout, act=ops.ACT_RELU)
+    _close(_nchw(y), torch.relu(ref), 1e-5)
+    y = ops.conv3x3_fwd(_nhwc(x), wf, b.cuda(), Cout, alpha=0.1, skip=_nhwc(skip), mask=_nhwc(mk))
+    _close(_nchw(y), torch.where(mk > 0, ref * 0.1, torch.zeros_like(ref)) + skip, 1e-5)
+    if Cin % 64 == 0:
+        dy = _rand(N, Cout, H, W, seed=6)
+        dx_ref, _, _ = O.conv3x3_grads(x, w, dy)
+        dx = ops.conv3x3_dgrad(_nhwc(dy), ops.pack_conv3x3_wino4(w.cuda(), 1), (N, H, W, Cin), mask=_nhwc(x), skip=_nhwc(x))
+        _close(_nchw(dx), torch.where(x > 0, dx_ref, torch.zeros_like(dx_ref)) + x, 1e-5)
+
+
+def test_conv3x3_winograd4_pixel_shuffle_fused():
+    """The upsampler convs on the F(4,3) kernel: fused PixelShuffle store (forward) and pixel-unshuffle load (input gradient)."""
+    import torch.nn.functional as F
+    from pesr_amd import ops
+    N, H, W, C = 2, 12, 24, 64
+    x = _rand(N, C, H, W, seed=1); w = _rand(4 * C, C, 3, 3, seed=2, scale=0.1); b = _rand(4 * C, seed=3)
+    ref = F.pixel_shuffle(O.conv3x3(x, w, b), 2)
+    y = ops.conv3x3_fwd(_nhwc(x), ops.pack_conv3x3_wino4(w.cuda(), 0, ps=True), ops.pack_bias_ps(b.cuda()), 4 * C, ps_out=True)
+    _close(_nchw(y), ref, 1e-5)
+    dys = _rand(N, C, 2 * H, 2 * W, seed=4)
+    dx_ref, _, _ = O.conv3x3_grads(x, w, F.pixel_unshuffle(dys, 2))
+    dx = ops.conv3x3_dgrad(_nhwc(dys), ops.pack_conv3x3_wino4(w.cuda(), 1, ps=True), (N, H, W, C), ps_in=True)
+    _close(_nchw(dx), dx_ref, 1e-5)
+
+
+def test_winograd4_random_shape_sweep():
+    from pesr_amd import ops
+    import random
+    rng = random.Random(13)
+    for it in range(10):
+        N = rng.choice([1, 2, 3]); H = rng.randint(1, 30); W = 4 * rng.randint(1, 26)
+        Cin = rng.choice([16, 64, 128]); Cout = rng.choice([64, 128, 192])
+        x = _rand(N, Cin, H, W, seed=500 + it); w = _rand(Cout, Cin, 3, 3, seed=600 + it, scale=0.1); b = _rand(Cout, seed=700 + it)
+        ref = O.conv3x3(x, w, b)
+        y = ops.conv3x3_fwd(_nhwc(x), ops.pack_conv3x3_wino4(w.cuda(), 0), b.cuda(), Cout)
+        _close(_nchw(y), ref, 1e-5)
+        if Cin % 64 == 0:
+            dy = _rand(N, Cout, H, W, seed=800 + it)
+            dx_ref, _, _ = O.conv3x3_grads(x, w, dy)
+            dx = ops.conv3x3_dgrad(_nhwc(dy), ops.pack_conv3x3_wino4(w.cuda(), 1), (N, H, W, Cin))
+            _close(_nchw(dx), dx_ref, 1e-5)
+
+
 def test_winograd_dispatch_rule():
     """functional picks the Winograd packing only where the kernel applies and fills the chip (the G body shape), and the
     direct one elsewhere (odd widths, fused PixelShuffle, stride 2, small layers)."""
@@ -209,6 +275,14 @@ def test_winograd_dispatch_rule():
     assert ops.wino_eligible(16, 24, 24, 512, 512)              # 128 tiles: split-K over the Cin chunks fills the chip
     assert not ops.wino_eligible(16, 12, 12, 512, 512)          # half-empty tiles: the direct kernel (smaller tiles) instead
     assert not ops.wino_eligible(16, 48, 48, 256, 64)
+    # F(4,3) (preferred where it applies): W % 4 == 0, Cout % 64 == 0, >= 192 workgroups, tiles mostly inside the image
+    assert ops.wino4_eligible(16, 48, 48, 256, 256) and ops.wino4_eligible(16, 48, 48, 256, 64)
+    assert ops.wino4_eligible(16, 24, 24, 512, 512)             # split-K fills the chip
+    assert ops.wino4_eligible(16, 96, 96, 256, 1024, ps_out=True)
+    assert not ops.wino4_eligible(16, 48, 50, 256, 256)         # width not a multiple of 4
+    assert not ops.wino4_eligible(16, 12, 12, 512, 512)         # 36 x-tiles per image: tiles would span images
+    assert not ops.wino4_eligible(1, 48, 48, 256, 256)          # 16 workgroups: the direct kernel's small tiles instead
+    assert not ops.wino4_eligible(16, 48, 48, 256, 256, stride=2)
 
 
 def test_winograd_random_shape_sweep():
