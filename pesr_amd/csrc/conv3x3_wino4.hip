@@ -135,12 +135,22 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
     // at the top of a chunk and stored a third in, item 1 is loaded right there and stored two thirds in.
     f32x4 sx[6];
     auto stage_load = [&](int u, int cc) {
+#ifdef W4_ABL_LOADS     // timing-only: no staging loads (the stores transform stale registers)
+        if (a.slope != 12345.f && cc != CB) return;
+#endif
         const char* const xc = (const char*)(x_img + chunk_off(cc));
 #pragma unroll
         for (int j = 0; j < 6; ++j) sx[j] = *(const f32x4*)(xc + st_off[u][j]);
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto stage_store = [&](int u, char* vdst) {
+#ifdef W4_ABL_STORES    // timing-only: loads stay (kept alive), no transform / ds_write
+        if (a.slope != 12345.f && vdst != smem) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(sx[j]));
+            return;
+        }
+#endif
         if (st_mask[u]) {
             const unsigned mk = st_mask[u];
             const f32x4 d0 = (mk & 1u) ? sx[0] : zero4, d1 = (mk & 2u) ? sx[1] : zero4, d2 = (mk & 4u) ? sx[2] : zero4,
@@ -187,15 +197,24 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
     for (int c = 0; c < C16; ++c) {
         char* const vcur = smem + (c & 1) * v_bytes;
         char* const vnext = smem + ((c & 1) ^ 1) * v_bytes;
+#ifdef W4_ABL_STAGE     // timing-only ablation builds (scripts/wino4_ab.py): the condition is false at run time, nothing is DCE'd
+        const bool more = c + 1 < C16 && a.slope == 12345.f;
+#else
         const bool more = c + 1 < C16;
+#endif
         if (more) stage_load(0, CB + c + 1);               // lands while this chunk computes
         W4_READ_A(fa[0], vcur, 0, 0, 0)
 #pragma unroll
         for (int s = 0; s < 9; ++s) {                      // slab s = (ky, xl)
             const int ky = s / 3, xl = s - ky * 3;
             // weight slab s + 2 (of this chunk, or the first ones of the next)
-            if (s + 2 < 9) fb[(s + 2) % 3] = ldb((s + 2) / 3, (s + 2) % 3, CB + c);
-            else if (more) fb[(s + 2) % 3] = ldb(0, s + 2 - 9, CB + c + 1);
+#ifdef W4_ABL_B
+            if (a.slope == 12345.f)
+#endif
+            {
+                if (s + 2 < 9) fb[(s + 2) % 3] = ldb((s + 2) / 3, (s + 2) % 3, CB + c);
+                else if (c + 1 < C16) fb[(s + 2) % 3] = ldb(0, s + 2 - 9, CB + c + 1);
+            }
 #pragma unroll
             for (int grp = 0; grp < 3; ++grp) {
                 const int t = s * 3 + grp, cur = t & 1;
@@ -205,9 +224,16 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
                 W4_MFMA(fa[cur], fb[s % 3], xl, grp)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // a third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs
+            // A third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs.
+            // The two waves of a SIMD (w and w + 4: the two xi halves) do this at DIFFERENT slabs, so that one of them keeps
+            // the matrix pipe busy while the other issues its VALU / ds_write burst.
+#ifndef W4_NO_STAGGER
+            if (more && s == (xh ? 4 : 2)) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
+            if (more && s == (xh ? 8 : 6)) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
+#else
             if (s == 2 && more) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
             if (s == 6 && more) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
+#endif
         }
         __syncthreads();                                   // V[next] complete and visible; everyone is done with V[cur]
     }
@@ -215,6 +241,9 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
 #undef W4_MFMA
 
     // ---- epilogue: partial output transforms of the two xi halves summed through LDS, coalesced stores ------------------------
+#ifdef W4_ABL_EPI
+    if (a.slope != 12345.f) return;
+#endif
     constexpr int RS = W4_BN * 4 + 16;                     // padded row stride of the staged tile (bytes)
     constexpr int C4 = W4_BN / 4;
     char* const ob = smem;
@@ -254,40 +283,64 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
     }
     __syncthreads();
     const size_t img_out = (size_t)img * a.H * a.W;
-    const int npix = 576;
-    for (int u = tid; u < npix * C4; u += W4_NT) {
-        const int p = u / C4, c4 = u - p * C4;
-        const int co = n0 + c4 * 4;
-        const int py = p / prow, px = p - py * prow;
-        const int oy = gy0 + py, ox = 4 * gt0 + px;
-        if (oy >= a.H || ox >= a.W) continue;
-        f32x4 v = *(const f32x4*)(ob + p * RS + c4 * 16);
-        size_t idx;
-        if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
-            const int C = a.Cout >> 2;
-            const int sub = co / C, cc = co - sub * C;
-            idx = (((size_t)img * (2 * a.H) + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1)) * C + cc;
-        } else {
-            idx = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+    // 576 pixels x 16 float4 units = 18 per thread, in batches of W4_EB: all of a batch's LDS reads and skip / mask loads are
+    // issued before the first store (an un-batched loop pays the full load latency 18 times in a row)
+#ifndef W4_EB
+#define W4_EB 6
+#endif
+    static_assert(18 % W4_EB == 0, "epilogue batch");
+#pragma unroll 1
+    for (int ub = 0; ub < 18; ub += W4_EB) {
+        f32x4 v[W4_EB], mkv[W4_EB], skv[W4_EB];
+        size_t idx[W4_EB];
+        bool ok[W4_EB];
+        int cov[W4_EB];
+#pragma unroll
+        for (int e = 0; e < W4_EB; ++e) {
+            const int u = tid + (ub + e) * W4_NT;
+            const int p = u / C4, c4 = u - p * C4;
+            const int co = n0 + c4 * 4;
+            const int py = p / prow, px = p - py * prow;
+            const int oy = gy0 + py, ox = 4 * gt0 + px;
+            ok[e] = oy < a.H && ox < a.W;
+            cov[e] = co;
+            v[e] = *(const f32x4*)(ob + p * RS + c4 * 16);
+            if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
+                const int C = a.Cout >> 2;
+                const int sub = co / C, cc = co - sub * C;
+                idx[e] = (((size_t)img * (2 * a.H) + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1)) * C + cc;
+            } else {
+                idx[e] = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+            }
+            if (!ok[e]) idx[e] = 0;
+            if (a.ksplit == 1) {
+                if (a.mask) mkv[e] = *(const f32x4*)(a.mask + idx[e]);
+                if (a.skip) skv[e] = *(const f32x4*)(a.skip + idx[e]);
+            }
         }
-        if (a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
-            *(f32x4*)(a.slab + (size_t)ks * ((size_t)a.N * a.H * a.W * a.Cout) + idx) = v;
-            continue;
+#pragma unroll
+        for (int e = 0; e < W4_EB; ++e) {
+            if (!ok[e]) continue;
+            f32x4 o = v[e];
+            if (a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
+                *(f32x4*)(a.slab + (size_t)ks * ((size_t)a.N * a.H * a.W * a.Cout) + idx[e]) = o;
+                continue;
+            }
+            if (a.bias) o += *(const f32x4*)(a.bias + cov[e]);
+            o *= a.alpha;
+            if (a.mask) {
+                const f32x4 mk = mkv[e];
+                o.x = mk.x > 0.f ? o.x : 0.f; o.y = mk.y > 0.f ? o.y : 0.f; o.z = mk.z > 0.f ? o.z : 0.f; o.w = mk.w > 0.f ? o.w : 0.f;
+            }
+            if (a.skip) o += skv[e];
+            if (a.act == PESR_ACT_RELU) {
+                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+            } else if (a.act == PESR_ACT_LRELU) {
+                o.x = o.x > 0.f ? o.x : o.x * a.slope; o.y = o.y > 0.f ? o.y : o.y * a.slope;
+                o.z = o.z > 0.f ? o.z : o.z * a.slope; o.w = o.w > 0.f ? o.w : o.w * a.slope;
+            }
+            *(f32x4*)(a.y + idx[e]) = o;
         }
-        if (a.bias) v += *(const f32x4*)(a.bias + co);
-        v *= a.alpha;
-        if (a.mask) {
-            const f32x4 mk = *(const f32x4*)(a.mask + idx);
-            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-        }
-        if (a.skip) v += *(const f32x4*)(a.skip + idx);
-        if (a.act == PESR_ACT_RELU) {
-            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-        } else if (a.act == PESR_ACT_LRELU) {
-            v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
-            v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
-        }
-        *(f32x4*)(a.y + idx) = v;
     }
 }
 

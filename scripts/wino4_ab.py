@@ -1,0 +1,43 @@
+"""Same-session interleaved A/B of builds of the F(4,3) conv kernel (each a separate libpesr_hip*.so, scripts/build_variant.sh):
+    python scripts/wino4_ab.py [fwd|skip] pesr_amd/libpesr_hip.so exp/libX.so ...     (G-body shape, batch 16)"""
+import ctypes, os, statistics, sys
+import torch
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from pesr_amd import _lib
+what = "fwd"
+args = sys.argv[1:]
+if args and args[0] in ("fwd", "skip"):
+    what = args.pop(0)
+libs = args
+N, H, W, C = 16, 48, 48, 256
+x = torch.rand(N, H, W, C, device="cuda") - 0.5
+w = (torch.rand(C, C, 3, 3, device="cuda") - 0.5) * 0.1
+b = torch.rand(C, device="cuda"); y = torch.empty(N, H, W, C, device="cuda"); sk = torch.rand(N, H, W, C, device="cuda") - 0.5
+wp = torch.empty(18 * C * C, device="cuda")
+handles = []
+for path in libs:
+    l = ctypes.CDLL(os.path.join(R, path))
+    for name, (res, a) in _lib.SIGNATURES.items():
+        f = getattr(l, name); f.restype = res; f.argtypes = a
+    handles.append(l)
+s = torch.cuda.current_stream().cuda_stream
+handles[0].pesr_pack_conv3x3_wino4(w.data_ptr(), wp.data_ptr(), C, C, 0, 0, s)
+def run(l, iters=20):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        if what == "skip":   # dgrad-of-conv1 style epilogue: ReLU mask + residual add
+            rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), None, sk.data_ptr(), x.data_ptr(), y.data_ptr(), N, H, W, C, C, 0.1, 0, 0.0, 0, 0, None, 0, s)
+        else:
+            rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1.0, 1, 0.0, 0, 0, None, 0, s)
+        assert rc == 0, rc
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+for l in handles: run(l, 5)
+res = {p: [] for p in libs}
+for rnd in range(6):
+    for p, l in zip(libs, handles):
+        res[p].append(run(l))
+for p in libs:
+    print(f"{p:34s} median {statistics.median(res[p]):7.1f} us  min {min(res[p]):7.1f}  all {[round(v) for v in res[p]]}")

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
-CONFIGS = {"small": dict(C=64, depth=2, ps=8, B=4, steps=2)}
+CONFIGS = {"small": dict(C=64, depth=2, ps=24, B=4, steps=2)}
 
 
 def main():

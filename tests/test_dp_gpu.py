@@ -95,7 +95,12 @@ def test_n_rank_gan_steps_vs_full_batch_oracle(nproc, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     got = torch.load(out)
     assert got["world"] == nproc
-    C, depth, ps, B = 64, 2, 8, 4
+    C, depth, ps, B = 64, 2, 24, 4
+    # Gradient tolerance = 3 x the reference's OWN fp32 noise floor for this configuration, measured by running the oracle in
+    # fp32 and in fp64 (max-abs difference / max-abs gradient, worst tensor): G 1.9e-3 / D 5.7e-4 on one replica, G 2.2e-2 /
+    # D 1.7e-2 with two replicas (two BatchNorm batches of 4 samples; LeakyReLU / ReLU kinks flip between precisions and the
+    # whole upstream gradient moves).  The exchange itself is pinned bit-exactly by the single-rank test above.
+    tol_g, tol_d = (6e-3, 2e-3) if nproc == 1 else (6e-2, 5e-2)
     st = OS.TrainState(gen_sd(C, depth), dis_sd(ps), vgg_sd(), {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5,
                                                                 "dp_replicas": nproc})
     for it in range(2):
@@ -109,10 +114,10 @@ def test_n_rank_gan_steps_vs_full_batch_oracle(nproc, tmp_path):
             # Adam update whose noise-level sign flips perturb cancellation-heavy sums like sub_mean.weight's by percents -
             # the reference's own fp32-vs-fp64 floor, DESIGN.md section 4 - so step 1 is checked through losses + parameters.)
             for k, v in st.g.items():
-                close(got["G.grad"][k], v.grad, 1e-4, what="grad G." + k)
+                close(got["G.grad"][k], v.grad, tol_g, what="grad G." + k)
             for k, v in st.d.items():
-                if k in got["D.grad"]:
-                    close(got["D.grad"][k], v.grad, 2e-4, what="grad D." + k)
+                if k in got["D.grad"] and k != "classifier.2.bias":      # (identically 0 under RSGAN: pred_real - pred_fake)
+                    close(got["D.grad"][k], v.grad, tol_d, what="grad D." + k)
     for k, v in st.g.items():
         adam_close(got["G"][k], v, 5e-5, 2, "G." + k)
     for k, v in st.d.items():
