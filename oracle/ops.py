@@ -15,7 +15,7 @@ def conv3x3_grads(x, w, dy, stride=1, need_bias=True):
     """(dx, dw, db) of conv3x3 via autograd on CPU (ATen convolution_backward)."""
     x = x.detach().clone().requires_grad_(True)
     w = w.detach().clone().requires_grad_(True)
-    b = torch.zeros(w.shape[0], requires_grad=True) if need_bias else None
+    b = torch.zeros(w.shape[0], dtype=w.dtype, requires_grad=True) if need_bias else None
     y = F.conv2d(x, w, b, stride=stride, padding=1)
     y.backward(dy)
     return x.grad, w.grad, (b.grad if need_bias else None)

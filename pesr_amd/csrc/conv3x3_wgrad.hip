@@ -406,23 +406,44 @@ static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
 }
 }  // namespace
 
-// algo: PESR_WGRAD_AUTO (0) = the Winograd form where it applies, PESR_WGRAD_DIRECT (1) = the direct kernel everywhere (A/B runs,
+int pesr_wgrad_reduce_launch(const float* slab, float* dw, int split, int Cout, int Cin, float alpha, int ps, const float* bias_part,
+                             int bias_rows, float* db, hipStream_t stream) {
+    const long total = 9L * Cout * Cin;
+    const int rgrid = (int)((total / 4 + 255) / 256 < 2048 ? (total / 4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, slab, dw, split, Cout, Cin, alpha, ps, bias_part, bias_rows, db);
+    return pesr_launch_status();
+}
+
+// algo: PESR_WGRAD_AUTO (0) = the Winograd F(4,3) form where it applies, else F(2,3), else the direct kernel;
+// PESR_WGRAD_DIRECT (1) = the direct kernel everywhere; PESR_WGRAD_WINO23 (2) = F(2,3) where it applies, else direct (A/B runs,
 // parity cross-checks).  An explicit argument: the library keeps no hidden state.
 size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo) {
     WgradPlan p;
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return 0;
-    const size_t ww = (stride == 1 && algo == 0) ? pesr_conv3x3_wgrad_wino_ws_bytes(N, H, W, Cin, Cout) : 0;
-    return p.total_bytes > ww ? p.total_bytes : ww;
+    size_t need = p.total_bytes;
+    if (stride == 1 && (algo == 0 || algo == 2)) {
+        const size_t ww = pesr_conv3x3_wgrad_wino_ws_bytes(N, H, W, Cin, Cout);
+        if (ww > need) need = ww;
+    }
+    if (stride == 1 && algo == 0) {
+        const size_t w4 = pesr_conv3x3_wgrad_wino4_ws_bytes(N, H, W, Cin, Cout);
+        if (w4 > need) need = w4;
+    }
+    return need;
 }
 
 int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                               int stride, float alpha, int ps_in, int algo, void* ws, size_t ws_bytes, hipStream_t stream) {
     WgradPlan p;
-    if (algo != 0 && algo != 1) return PESR_EINVAL;
+    if (algo < 0 || algo > 2) return PESR_EINVAL;
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return PESR_EINVAL;
     if (ws_bytes < p.total_bytes || !ws) return PESR_EWORKSPACE;
     if (ps_in && (stride != 1 || Cout % 16)) return PESR_EINVAL;
-    if (stride == 1 && algo == 0) {   // the Winograd form where it applies (even width >= 48, 64-multiple channels)
+    if (stride == 1 && algo == 0) {   // Winograd F(4,3) where it applies (width % 4 == 0 and >= 48, 64-multiple channels)
+        const int rc = pesr_conv3x3_wgrad_wino4_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, ws, ws_bytes, stream);
+        if (rc != PESR_EINVAL && rc != PESR_EWORKSPACE) return rc;
+    }
+    if (stride == 1 && (algo == 0 || algo == 2)) {   // Winograd F(2,3) where it applies (even width >= 48, 64-multiple channels)
         const int rc = pesr_conv3x3_wgrad_wino_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, ws, ws_bytes, stream);
         if (rc != PESR_EINVAL && rc != PESR_EWORKSPACE) return rc;
     }

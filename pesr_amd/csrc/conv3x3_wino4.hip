@@ -87,6 +87,10 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
         const int trow = m / a.TXT, txt = m - trow * a.TXT;
         a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
     }
+#ifdef W4_ABL_ACONF   // timing-only: every lane reads the same address (broadcast: no bank conflict possible)
+#pragma unroll
+    for (int i = 0; i < W4_MG; ++i) a_off[i] = (a.slope == 12345.f) ? a_off[i] : i * 64;
+#endif
     const int kxor = a.row_key * 16;                       // the key's row term flips with the parity of ky
 
     // ---- B: this lane's 16 bytes of slab (ky, xi, chunk) ---------------------------------------------------------------------
@@ -376,7 +380,11 @@ static bool w4_plan(int N, int H, int W, int Cin, int Cout, bool allow_split, si
         const size_t vb = (size_t)2 * HT * 6 * TXT * 64;
         if (vb > 160 * 1024 || HT * TXT * 4 > 2 * W4_NT) continue;
         const long cover = (long)pesr_cdiv(H, TR) * TR * pesr_cdiv(XT, TXT) * TXT;
-        const long score = cover * 4096 + (long)HT * TXT;      // least waste first, then the smallest halo
+        // least waste first; then a row length whose fragment reads are bank-conflict free with the kernel's swizzle key
+        // (measured with scripts/lds_bank_probe.hip: TXT = 12 with the row term, 8 / 16 / 24 without; a 3-x-tile row costs
+        // 14 LDS cycles per ds_read_b128 instead of 4); then the smallest halo
+        const bool clean = TXT == 12 || TXT == 8 || TXT == 16 || TXT == 24;
+        const long score = cover * 8192 + (clean ? 0 : 4096) + (long)HT * TXT;
         if (best < 0 || score < best) { best = score; p->TR = TR; p->TXT = TXT; }
     }
     if (best < 0) return false;

@@ -57,6 +57,13 @@ int pesr_adam_launch(float* p, const float* g, float* m, float* v, long n, float
 // dsum[col] = sum_k part[k*ncols + col] in double, fixed order (reduce.hip)
 int pesr_reduce_rows_launch(const float* part, double* dsum, int nb, int ncols, hipStream_t stream);
 
+// fixed-order split-K reduce of the direct wgrad kernel: slab [split][9][Cout][Cin] -> dw OIHW (+ bias partials -> db)
+int pesr_wgrad_reduce_launch(const float* slab, float* dw, int split, int Cout, int Cin, float alpha, int ps, const float* bias_part,
+                             int bias_rows, float* db, hipStream_t stream);
+// transposed Winograd F(4,3) weight gradient (conv3x3_wgrad_wino4.hip); PESR_EINVAL for shapes it does not cover
+size_t pesr_conv3x3_wgrad_wino4_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                                    float alpha, int ps_in, void* ws, size_t ws_bytes, hipStream_t stream);
 // transposed Winograd weight gradient (conv3x3_wgrad_wino.hip); the launch returns PESR_EINVAL for shapes it does not cover
 size_t pesr_conv3x3_wgrad_wino_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int pesr_conv3x3_wgrad_wino_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,

@@ -117,6 +117,17 @@ class WinoPacked:
 USE_WINO = __import__("os").environ.get("PESR_WINO", "1") != "0"     # PESR_WINO=0: direct kernel everywhere
 # PESR_WGRAD_WINO=0: direct weight-gradient kernel everywhere (passed to the library as the explicit `algo` argument)
 USE_WGRAD_WINO = __import__("os").environ.get("PESR_WGRAD_WINO", "1") != "0"
+USE_WGRAD_WINO4 = __import__("os").environ.get("PESR_WGRAD_WINO4", "1") != "0"   # =0: F(2,3) weight gradient instead of F(4,3)
+
+
+def wgrad_kernel_for(N, H, W, Cin, Cout):
+    """(kernel name, fraction of the algorithmic flops it issues on the matrix pipe) of the stride-1 weight gradient."""
+    if USE_WGRAD_WINO and Cin % 64 == 0 and Cout % 64 == 0 and W >= 48:
+        if USE_WINO4 and USE_WGRAD_WINO4 and W % 4 == 0 and ((W // 4 + 11) // 12) * 12 * 8 <= (W // 4) * 9:
+            return "conv3x3_wgrad_wino4_kernel", 0.5
+        if W % 2 == 0 and ((W // 2 + 23) // 24) * 24 * 8 <= (W // 2) * 9:
+            return "conv3x3_wgrad_wino_kernel", 2.0 / 3.0
+    return "conv3x3_wgrad_kernel", 1.0
 
 
 def wino_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1) -> bool:
@@ -279,15 +290,20 @@ def _out(t, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23 = 0, 1, 2      # include/pesr_hip.h PESR_WGRAD_*
+
+
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: float = 1.0, want_bias: bool = True,
-                  ps_in: bool = False, dw_out=None, db_out=None):
-    """(dw [O, I, 3, 3], db [O] | None)."""
+                  ps_in: bool = False, dw_out=None, db_out=None, algo=None):
+    """(dw [O, I, 3, 3], db [O] | None).  algo: None = by the PESR_* switches (default: auto = F(4,3) where it applies, else
+    F(2,3), else direct), or one of WGRAD_AUTO / WGRAD_DIRECT / WGRAD_WINO23."""
     _chk(x, "conv3x3_wgrad.x")
     _chk(dy, "conv3x3_wgrad.dy")
     N, H, W, Cin = x.shape
     cout = dy.shape[3] * (4 if ps_in else 1)
     L = _lib.lib()
-    algo = 0 if USE_WGRAD_WINO else 1
+    if algo is None:
+        algo = (0 if (USE_WINO4 and USE_WGRAD_WINO4) else 2) if USE_WGRAD_WINO else 1
     nbytes = L.pesr_conv3x3_wgrad_workspace_bytes(N, H, W, Cin, cout, stride, algo)
     if nbytes == 0:
         raise _lib.PesrHipError(f"pesr_conv3x3_wgrad: unsupported shape Cin={Cin} Cout={cout} stride={stride}")

@@ -1,6 +1,7 @@
-"""fp64 companion of GV8b: the SAME full-size GAN step computed by the CPU oracle in float64, sampled at GV8b's indices.
+"""fp64 companions of the full-size goldens: the SAME computations (GV2b generator under L1, GV4b discriminator, GV7b VGG,
+GV8b whole GAN step) done by the CPU oracle in float64, sampled at the goldens' own indices.
 
-Run:  python tests/golden/make_golden_fp64.py        (about 2-3 minutes on 8 cores; needs tests/golden/gv8b_gan_step_full.npz)
+Run:  python tests/golden/make_golden_fp64.py        (about 5 minutes on 8 cores; needs the gv*b_*.npz files next to it)
 Why: through the Discriminator / VGG (ReLU / LeakyReLU kinks, BatchNorm batch statistics) the GAN step's gradients are
 ill-conditioned in fp32 - the reference's OWN fp32 result differs from the fp64 one by up to 3.5e-3 (G) / 6.2e-3 (D) of a
 tensor's maximum (median 1.4e-3), so "1e-4 of the maximum" is not attainable by any fp32 implementation, the reference
@@ -23,10 +24,75 @@ from oracle import detrand  # noqa: E402
 from oracle import step as OS  # noqa: E402
 
 
+def floors(out, g, prefix, named_grads):
+    """fp64 samples at the golden's indices + the reference's own fp32 error against them (worst / median over tensors)."""
+    worst = []
+    for k, grad in named_grads:
+        if (prefix + "gidx." + k) not in g.files:
+            continue
+        idx = g[prefix + "gidx." + k]
+        v64 = grad.reshape(-1)[idx].numpy()
+        mx = float(grad.abs().max())
+        out[prefix + "g64." + k] = v64
+        out[prefix + "gmax64." + k] = np.float64(mx)
+        if mx > 0:
+            worst.append(float(np.abs(g[prefix + "gval." + k].astype(np.float64) - v64).max() / mx))
+    worst.sort()
+    out[prefix + "floor_worst"] = np.float64(worst[-1])
+    out[prefix + "floor_median"] = np.float64(worst[len(worst) // 2])
+    print("   ", prefix or "(all)", "reference fp32 vs fp64: worst", worst[-1], "median", worst[len(worst) // 2], flush=True)
+
+
+def small_ones(dt):
+    """GV2b / GV4b / GV7b in fp64."""
+    import torch.nn.functional as F
+    from oracle import model as OM
+    f = lambda sd: {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+    # GV2b: generator 256 x 32 at batch 16 under L1
+    g = load_golden("gv2b_generator_full_b16")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in f(gen_sd(256, 32)).items()}
+    lr = detrand.image_batch((16, 3, 48, 48), 1234).to(dt); hr = detrand.image_batch((16, 3, 192, 192), 1235).to(dt)
+    sr = OM.generator_forward(leaves, lr, 32, 0.1)
+    loss = F.l1_loss(sr, hr)
+    loss.backward()
+    out = {"loss": np.float64(loss.item()), "sr_val": sr.detach().reshape(-1)[g["sr_idx"]].numpy()}
+    floors(out, g, "", [(k, v.grad) for k, v in leaves.items()])
+    np.savez_compressed(os.path.join(HERE, "gv2b_fp64.npz"), **out)
+    del leaves, sr
+    # GV4b: discriminator ps 48, batch 16, two train-mode calls
+    g = load_golden("gv4b_discriminator_ps48")
+    sd = f(dis_sd(48))
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    a = detrand.image_batch((16, 3, 192, 192), 21).to(dt); b = detrand.image_batch((16, 3, 192, 192), 22).to(dt).requires_grad_(True)
+    o1 = OM.discriminator_forward(leaves, a); o2 = OM.discriminator_forward(leaves, b)
+    l = F.binary_cross_entropy_with_logits(o1 - o2, torch.ones(16, 1, dtype=dt))
+    l.backward()
+    out = {"o1": o1.detach().numpy(), "o2": o2.detach().numpy(), "loss": np.float64(l.item()),
+           "gin64": b.grad.reshape(-1)[g["gin_idx"]].numpy(), "gin_max64": np.float64(b.grad.abs().max())}
+    out["gin_floor"] = np.float64(np.abs(g["gin_val"].astype(np.float64) - out["gin64"]).max() / float(out["gin_max64"]))
+    print("    D input gradient: reference fp32 vs fp64", out["gin_floor"])
+    floors(out, g, "", [(k, v.grad) for k, v in leaves.items() if v.grad is not None])
+    np.savez_compressed(os.path.join(HERE, "gv4b_fp64.npz"), **out)
+    del leaves
+    # GV7b: VGG at 192 x 192
+    g = load_golden("gv7b_vgg_192")
+    sd = f(vgg_sd())
+    a = detrand.image_batch((2, 3, 192, 192), 31).to(dt).requires_grad_(True); b = detrand.image_batch((2, 3, 192, 192), 32).to(dt)
+    fa, fb = OM.vgg_forward(sd, a, b)
+    m = F.mse_loss(fa, fb)
+    m.backward()
+    out = {"mse": np.float64(m.item()), "gin64": a.grad.reshape(-1)[g["gin_idx"]].numpy(), "gin_max64": np.float64(a.grad.abs().max())}
+    out["gin_floor"] = np.float64(np.abs(g["gin_val"].astype(np.float64) - out["gin64"]).max() / float(out["gin_max64"]))
+    print("    VGG input gradient: reference fp32 vs fp64", out["gin_floor"])
+    np.savez_compressed(os.path.join(HERE, "gv7b_fp64.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
-    g = load_golden("gv8b_gan_step_full")
     dt = torch.float64
+    if "gv8b-only" not in sys.argv:
+        small_ones(dt)
+    g = load_golden("gv8b_gan_step_full")
     f = lambda sd: {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
     st = OS.TrainState(f(gen_sd(256, 32)), f(dis_sd(48)), f(vgg_sd()), {"depth": 32, "res_scale": 0.1, "learning_rate": 5e-5})
     lr = detrand.image_batch((16, 3, 48, 48), 100).to(dt)

@@ -58,3 +58,30 @@ def adam_close(got, ref, lr, steps, what=""):
     rest = err[~flipped]
     if rest.size:
         assert rest.mean() <= 0.06 * lr + 2e-6 * scale, f"{what}: mean err of the rest {rest.mean():.3e} = {rest.mean() / lr:.3f} lr"
+
+
+def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0):
+    """Gradient parity where fp32 itself is ill-conditioned (ReLU / LeakyReLU kinks, BatchNorm batch statistics, L1's sign):
+    `g` holds the REFERENCE's fp32 gradient samples, `g64` the same computation done in float64
+    (tests/golden/make_golden_fp64.py).  Per tensor, our error against the fp64 truth may be at most `factor` x the
+    reference's own fp32 error for that tensor, and never has to beat the worst error the reference itself shows on any tensor
+    of the network; the distance to the reference's fp32 values is then bounded by the sum of both errors.
+    get_grad(name) -> our gradient tensor.  Returns (tensors checked, (worst error / allowance, its name))."""
+    keys = [k[len(prefix) + 5:] for k in g.files if k.startswith(prefix + "gidx.")]
+    assert keys
+    net_floor = float(g64[prefix + "floor_worst"])
+    worst = (0.0, None)
+    for key in keys:
+        mx = float(g64[f"{prefix}gmax64.{key}"])
+        if mx == 0.0:        # e.g. classifier.2.bias under RSGAN: pred_real - pred_fake cancels its gradient exactly
+            continue
+        idx = torch.from_numpy(g[f"{prefix}gidx.{key}"])
+        ours = get_grad(key).reshape(-1).cpu()[idx].double().numpy()
+        v64, ref32 = g64[f"{prefix}g64.{key}"], g[f"{prefix}gval.{key}"].astype(np.float64)
+        e_ref = np.abs(ref32 - v64).max() / mx
+        e_ours = np.abs(ours - v64).max() / mx
+        tol = max(factor * e_ref, net_floor, 1e-6)
+        assert e_ours <= tol, f"grad {prefix}{key}: error vs fp64 {e_ours:.2e} > {tol:.2e} (reference's own fp32 error {e_ref:.2e})"
+        if e_ours / tol > worst[0]:
+            worst = (e_ours / tol, key)
+    return len(keys), worst

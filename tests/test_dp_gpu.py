@@ -96,28 +96,34 @@ def test_n_rank_gan_steps_vs_full_batch_oracle(nproc, tmp_path):
     got = torch.load(out)
     assert got["world"] == nproc
     C, depth, ps, B = 64, 2, 24, 4
-    # Gradient tolerance = 3 x the reference's OWN fp32 noise floor for this configuration, measured by running the oracle in
-    # fp32 and in fp64 (max-abs difference / max-abs gradient, worst tensor): G 1.9e-3 / D 5.7e-4 on one replica, G 2.2e-2 /
-    # D 1.7e-2 with two replicas (two BatchNorm batches of 4 samples; LeakyReLU / ReLU kinks flip between precisions and the
-    # whole upstream gradient moves).  The exchange itself is pinned bit-exactly by the single-rank test above.
-    tol_g, tol_d = (6e-3, 2e-3) if nproc == 1 else (6e-2, 5e-2)
-    st = OS.TrainState(gen_sd(C, depth), dis_sd(ps), vgg_sd(), {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5,
-                                                                "dp_replicas": nproc})
+    cfg = {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5, "dp_replicas": nproc}
+    st = OS.TrainState(gen_sd(C, depth), dis_sd(ps), vgg_sd(), cfg)
+    # The GAN step's gradients are ill-conditioned in fp32 (LeakyReLU / ReLU kinks, BatchNorm over 4-sample shards): the same
+    # step is also run in float64, and our gradients may be off from that truth by at most 3 x the fp32 oracle's own error for
+    # the tensor (never asked below the oracle's worst tensor).  The exchange itself is pinned bit-exactly by the test above.
+    f64 = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    st64 = OS.TrainState(f64(gen_sd(C, depth)), f64(dis_sd(ps)), f64(vgg_sd()), cfg)
     for it in range(2):
         lr = detrand.image_batch((B * nproc, 3, ps, ps), 700 + it)
         hr = detrand.image_batch((B * nproc, 3, 4 * ps, 4 * ps), 800 + it)
         ref = OS.gan_step(st, lr, hr)
         close(got["losses"][it].numpy(), np.array([ref[k] for k in ("l1", "vgg", "g", "tv", "d")]), 5e-5 if it == 0 else 5e-4,
               what=f"losses step {it}")
-        if it == 0:
-            # gradients of the FIRST step, averaged over ranks = the full-batch ones.  (Second-step gradients go through an
-            # Adam update whose noise-level sign flips perturb cancellation-heavy sums like sub_mean.weight's by percents -
-            # the reference's own fp32-vs-fp64 floor, DESIGN.md section 4 - so step 1 is checked through losses + parameters.)
-            for k, v in st.g.items():
-                close(got["G.grad"][k], v.grad, tol_g, what="grad G." + k)
-            for k, v in st.d.items():
-                if k in got["D.grad"] and k != "classifier.2.bias":      # (identically 0 under RSGAN: pred_real - pred_fake)
-                    close(got["D.grad"][k], v.grad, tol_d, what="grad D." + k)
+        if it == 0:     # gradients of the FIRST step, averaged over ranks = the full-batch ones
+            OS.gan_step(st64, lr.double(), hr.double())
+            for name, leaves, leaves64 in (("G", st.g, st64.g), ("D", st.d, st64.d)):
+                rows = []
+                for k, v in leaves.items():
+                    if k not in got[name + ".grad"] or v.grad is None:
+                        continue
+                    v64 = leaves64[k].grad
+                    mx = float(v64.abs().max())
+                    if mx == 0.0:
+                        continue
+                    rows.append((k, float((v.grad.double() - v64).abs().max()) / mx, float((got[name + ".grad"][k].double() - v64).abs().max()) / mx))
+                floor = max(r[1] for r in rows)
+                for k, e_ref, e_ours in rows:
+                    assert e_ours <= max(3.0 * e_ref, floor), f"grad {name}.{k}: error vs fp64 {e_ours:.2e}, the fp32 oracle's own {e_ref:.2e} (worst tensor {floor:.2e})"
     for k, v in st.g.items():
         adam_close(got["G"][k], v, 5e-5, 2, "G." + k)
     for k, v in st.d.items():

@@ -205,25 +205,33 @@ def test_train_entrypoint_runs(tmp_path):
 def test_config5_large_tiles_64bit_indexing():
     """BASELINE config 5: G forward on 4 x 512x512 LR tiles (256 ch x 32 blocks).  The 256ch @ 2048^2 x 4 tensor has
     4.29e9 elements (> 2^31), so this exercises the 64-bit offsets.  Size-independent property: every output pixel
-    accumulates its taps/channels in a fixed order whatever the tiling, so the interior of the full result equals
-    the result on a crop (margin >= the 69-LR-pixel receptive field) BIT FOR BIT.  (The crop starts at an even column and is
-    large enough for the body convs to take the same kernel - the Winograd one, which pairs pixels (2t, 2t+1) - as the
-    full image.)"""
+    accumulates its taps / channels in a fixed order whatever the tiling, so the interior rows of the full result equal the
+    result on a full-width STRIP of rows (margin >= the 69-LR-pixel receptive field) BIT FOR BIT.
+    (Rows, not a 2-D crop: along y the Winograd kernels apply the three taps directly and the receptive field is exact.
+    Along x the F(4,3) transform reads six columns for four outputs; the two extra ones cancel exactly in real arithmetic
+    but not in their last fp32 bits, so a crop boundary in x perturbs rounding up to 4 px per layer away - checked below
+    against a tolerance instead.)"""
     G = _G(256, 32, gen_sd(256, 32))
     g = torch.Generator().manual_seed(5)
     x = torch.randint(0, 256, (4, 3, 512, 512), generator=g).float().cuda()
     with torch.no_grad():
         y = G(x)
         assert y.shape == (4, 3, 2048, 2048) and bool(torch.isfinite(y).all())
-        m, (y0, x0, s) = 72, (176, 200, 240)
-        yc = G(x[3:4, :, y0:y0 + s, x0:x0 + s].contiguous())
-        a = y[3, :, 4 * (y0 + m):4 * (y0 + s - m), 4 * (x0 + m):4 * (x0 + s - m)]
-        b = yc[0, :, 4 * m:4 * (s - m), 4 * m:4 * (s - m)]
-        assert a.shape == b.shape == (3, 384, 384)
+        m, (y0, s) = 72, (176, 240)
+        yc = G(x[3:4, :, y0:y0 + s, :].contiguous())
+        a = y[3, :, 4 * (y0 + m):4 * (y0 + s - m), :]
+        b = yc[0, :, 4 * m:4 * (s - m), :]
+        assert a.shape == b.shape == (3, 384, 2048)
         assert torch.equal(a, b), float((a - b).abs().max())
-        # and the first image's corner (zero padding included) against a corner crop
-        yc0 = G(x[0:1, :, :s, :s].contiguous())
-        assert torch.equal(y[0, :, :4 * (s - m), :4 * (s - m)], yc0[0, :, :4 * (s - m), :4 * (s - m)])
+        # and the first image's top rows (zero padding included) against a top strip
+        yc0 = G(x[0:1, :, :s, :].contiguous())
+        assert torch.equal(y[0, :, :4 * (s - m), :], yc0[0, :, :4 * (s - m), :])
+        # a 2-D crop: equal up to fp32 rounding (G-forward tolerance of the parity tests: 2e-3 on the 0..255 scale)
+        x0 = 200
+        yq = G(x[3:4, :, y0:y0 + s, x0:x0 + s].contiguous())
+        a = y[3, :, 4 * (y0 + m):4 * (y0 + s - m), 4 * (x0 + m):4 * (x0 + s - m)]
+        b = yq[0, :, 4 * m:4 * (s - m), 4 * m:4 * (s - m)]
+        assert float((a - b).abs().max()) <= 2e-3
 
 
 @pytest.mark.parametrize("gan_type,focal", [("SGAN", False), ("SGAN", True), ("RSGAN", False)])
