@@ -1,6 +1,8 @@
 // BatchNorm2d (training mode, batch statistics) + LeakyReLU for the Discriminator's BasicBlock
 // (reference model/basic.py:29-30, model/pesr.py:47: eps 1e-5, momentum 0.1, slope 0.2), NHWC fp32.
-//   stats   : per-channel sum and sum of squares  -> per-block partials (no atomics)
+//   stats   : per-channel sum and sum of squares  -> per-block partials (no atomics); every thread accumulates in DOUBLE:
+//             dbeta = sum(dz) and the mean are sums of mixed-sign terms that mostly cancel, and an fp32 running sum over
+//             ~100 rows loses the bits the result lives in (these kernels are HBM-bound, the fp64 adds are free)
 //   finalize: mean, biased var, invstd in double over the partials (fixed order); running stats
 //             (unbiased var, momentum) and num_batches_tracked updated as nn.BatchNorm2d does
 //   apply   : y = lrelu(gamma * (x - mean) * invstd + beta)         (optionally written NCHW for the
@@ -22,9 +24,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
     const long r0 = (long)blockIdx.x * rows_per_block;
     long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
-    __shared__ f32x4 red[2][256];
+    __shared__ f64x4 red[2][256];
     for (int c0 = 0; c0 < C4; c0 += cw) {
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        f64x4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
         const int c4 = c0 + tc;
         if (tr < rl && c4 < C4) {
             f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu, be = mu;
@@ -35,7 +37,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             for (long rr = r0 + tr; rr < r1; rr += rl) {
                 const f32x4 v = ((const f32x4*)x)[rr * C4 + c4];
                 if (WHICH == 0) {
-                    s0 += v; s1 += v * v;
+                    const f64x4 vd = __builtin_convertvector(v, f64x4);
+                    s0 += vd; s1 += vd * vd;
                 } else {
                     f32x4 g;
                     if (dy_sc == 1) g = ((const f32x4*)dy)[rr * C4 + c4];
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                     f32x4 dz;
                     dz.x = z.x > 0.f ? g.x : g.x * slope; dz.y = z.y > 0.f ? g.y : g.y * slope;
                     dz.z = z.z > 0.f ? g.z : g.z * slope; dz.w = z.w > 0.f ? g.w : g.w * slope;
-                    s0 += dz; s1 += dz * xh;
+                    const f64x4 dzd = __builtin_convertvector(dz, f64x4);
+                    s0 += dzd; s1 += dzd * __builtin_convertvector(xh, f64x4);
                 }
             }
         }
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
         if (tr == 0 && c4 < C4) {
             for (int k = 1; k < rl; ++k) { s0 += red[0][k * cw + tc]; s1 += red[1][k * cw + tc]; }
             f32x4* p = (f32x4*)part + (size_t)blockIdx.x * 2 * C4;
-            p[c4] = s0; p[C4 + c4] = s1;
+            p[c4] = __builtin_convertvector(s0, f32x4); p[C4 + c4] = __builtin_convertvector(s1, f32x4);
         }
         __syncthreads();
     }

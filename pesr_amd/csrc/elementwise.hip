@@ -34,9 +34,11 @@ __global__ __launch_bounds__(256) void meanshift_bwd_kernel(const float* __restr
                                                             float* __restrict__ part, int N, long HW, long xsn, long xsc,
                                                             long xsp) {
     const float w00 = w[0], w01 = w[1], w02 = w[2], w10 = w[3], w11 = w[4], w12 = w[5], w20 = w[6], w21 = w[7], w22 = w[8];
-    float s[12];
+    // double accumulators: dw = sum over all pixels of dy * x with x in 0..255 is a sum of large mixed-sign terms that mostly
+    // cancel; an fp32 running sum per thread measured 19 x the error of the CPU reference's fp32 result on this tensor
+    double s[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) s[k] = 0.f;
+    for (int k = 0; k < 12; ++k) s[k] = 0.0;
     const long total = (long)N * HW;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long n = e / HW, p = e - n * HW;
@@ -48,19 +50,19 @@ __global__ __launch_bounds__(256) void meanshift_bwd_kernel(const float* __restr
         }
         const float* xi = x + n * xsn + p * xsp;
         const float x0 = xi[0], x1 = xi[xsc], x2 = xi[2 * xsc];
-        s[0] += g0 * x0; s[1] += g0 * x1; s[2] += g0 * x2;
-        s[3] += g1 * x0; s[4] += g1 * x1; s[5] += g1 * x2;
-        s[6] += g2 * x0; s[7] += g2 * x1; s[8] += g2 * x2;
-        s[9] += g0; s[10] += g1; s[11] += g2;
+        s[0] += (double)(g0 * x0); s[1] += (double)(g0 * x1); s[2] += (double)(g0 * x2);
+        s[3] += (double)(g1 * x0); s[4] += (double)(g1 * x1); s[5] += (double)(g1 * x2);
+        s[6] += (double)(g2 * x0); s[7] += (double)(g2 * x1); s[8] += (double)(g2 * x2);
+        s[9] += (double)g0; s[10] += (double)g1; s[11] += (double)g2;
     }
-    __shared__ float red[4][12];
+    __shared__ double red[4][12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-        const float v = wave_sum(s[k]);
+        const double v = wave_sum_d(s[k]);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 12) part[blockIdx.x * 12 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 12) part[blockIdx.x * 12 + threadIdx.x] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 __global__ void meanshift_bwd_final_kernel(const double* __restrict__ dsum, float* __restrict__ dw, float* __restrict__ db) {
     if (threadIdx.x < 12) {

@@ -64,8 +64,9 @@ def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0):
     """Gradient parity where fp32 itself is ill-conditioned (ReLU / LeakyReLU kinks, BatchNorm batch statistics, L1's sign):
     `g` holds the REFERENCE's fp32 gradient samples, `g64` the same computation done in float64
     (tests/golden/make_golden_fp64.py).  Per tensor, our error against the fp64 truth may be at most `factor` x the
-    reference's own fp32 error for that tensor, and never has to beat the worst error the reference itself shows on any tensor
-    of the network; the distance to the reference's fp32 values is then bounded by the sum of both errors.
+    reference's own fp32 error for that tensor, and never has to beat twice the worst error the reference itself shows on any
+    tensor of the network (the errors are noise - a flipped ReLU mask is a discrete event - so a single tensor's own error is a
+    one-sample estimate); the distance to the reference's fp32 values is then bounded by the sum of both errors.
     get_grad(name) -> our gradient tensor.  Returns (tensors checked, (worst error / allowance, its name))."""
     keys = [k[len(prefix) + 5:] for k in g.files if k.startswith(prefix + "gidx.")]
     assert keys
@@ -80,7 +81,7 @@ def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0):
         v64, ref32 = g64[f"{prefix}g64.{key}"], g[f"{prefix}gval.{key}"].astype(np.float64)
         e_ref = np.abs(ref32 - v64).max() / mx
         e_ours = np.abs(ours - v64).max() / mx
-        tol = max(factor * e_ref, net_floor, 1e-6)
+        tol = max(factor * e_ref, 2.0 * net_floor, 1e-6)
         assert e_ours <= tol, f"grad {prefix}{key}: error vs fp64 {e_ours:.2e} > {tol:.2e} (reference's own fp32 error {e_ref:.2e})"
         if e_ours / tol > worst[0]:
             worst = (e_ours / tol, key)
