@@ -180,15 +180,22 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     seg_coords(seg_begin, img, xs, row);
     set_strip(xs);
     stage_strip_start(img, row, 0);
+    // Staging runs a full segment ahead of its ds_writes: the loads for segment s+1's new rows are issued at the store point
+    // of segment s-1 (or right after a strip start) and land while segment s-1 / s computes; with the loads issued at the top
+    // of segment s they were waited for a third of a segment later - under load an L2 / MALL round trip is longer than that.
+    if (seg_begin + 1 < seg_end && row + 2 < a.H) { load_v(img, row + 3 + v_rr); load_d(img, row + 2 + d_rr); }
     __syncthreads();
     int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
+#ifndef G4_STORE_STEP
+#define G4_STORE_STEP 4
+#endif
 
 #pragma unroll 1
     for (int seg = seg_begin; seg < seg_end; ++seg) {
         const int par = (seg - seg_begin) & 1;
         const bool more = seg + 1 < seg_end;
         const bool cont = more && row + 2 < a.H;            // the next segment is the next row pair of the same strip
-        if (cont) { load_v(img, row + 3 + v_rr); load_d(img, row + 2 + d_rr); }
+        const bool cont2 = cont && seg + 2 < seg_end && row + 4 < a.H;   // ... and so is the one after it
 
         const float* const db = dmbuf + (par * 2) * G4_DROW + a_lane;
         const float* vb[4];
@@ -223,13 +230,14 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             G4_MFMA(av0, bv0)
             __builtin_amdgcn_sched_barrier(0);
             if (stp + 2 < 2 * G4_K4) G4_READ(av0, bv0, stp + 2)
-            if (stp == 2) {
+            if (stp == G4_STORE_STEP) {
                 // The staging stores go to LDS that nobody reads in this segment (the two free ring slots, the other dM
-                // buffer): placed here, half way, the loads have landed and the ds_writes run under the remaining MFMAs.
+                // buffer); right behind them the loads for the segment after next reuse the staging registers.
                 __builtin_amdgcn_sched_barrier(0);
                 if (cont) {
                     int sl = base + 4 + v_rr; if (sl >= G4_RING) sl -= G4_RING;
                     store_v(sl); store_d(par ^ 1);
+                    if (cont2) { load_v(img, row + 5 + v_rr); load_d(img, row + 4 + d_rr); }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -247,6 +255,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             seg_coords(seg + 1, img, xs, row);
             set_strip(xs);
             stage_strip_start(img, row, par ^ 1);
+            if (seg + 2 < seg_end && row + 2 < a.H) { load_v(img, row + 3 + v_rr); load_d(img, row + 2 + d_rr); }
             __syncthreads();
             base = 0;
         }

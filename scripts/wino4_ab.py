@@ -1,5 +1,5 @@
 """Same-session interleaved A/B of builds of the F(4,3) conv kernel (each a separate libpesr_hip*.so, scripts/build_variant.sh):
-    python scripts/wino4_ab.py [fwd|skip] pesr_amd/libpesr_hip.so exp/libX.so ...     (G-body shape, batch 16)"""
+    python scripts/wino4_ab.py [fwd|skip|wgrad] pesr_amd/libpesr_hip.so exp/libX.so ...     (G-body shape, batch 16)"""
 import ctypes, os, statistics, sys
 import torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +7,7 @@ sys.path.insert(0, R)
 from pesr_amd import _lib
 what = "fwd"
 args = sys.argv[1:]
-if args and args[0] in ("fwd", "skip"):
+if args and args[0] in ("fwd", "skip", "wgrad"):
     what = args.pop(0)
 libs = args
 N, H, W, C = 16, 48, 48, 256
@@ -23,11 +23,15 @@ for path in libs:
     handles.append(l)
 s = torch.cuda.current_stream().cuda_stream
 handles[0].pesr_pack_conv3x3_wino4(w.data_ptr(), wp.data_ptr(), C, C, 0, 0, s)
+dw = torch.empty(C, C, 3, 3, device="cuda"); dbias = torch.empty(C, device="cuda")
+ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
 def run(l, iters=20):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        if what == "skip":   # dgrad-of-conv1 style epilogue: ReLU mask + residual add
+        if what == "wgrad":   # transposed F(4,3) weight gradient + its reduce kernel (algo 0 = auto)
+            rc = l.pesr_conv3x3_wgrad(x.data_ptr(), sk.data_ptr(), dw.data_ptr(), dbias.data_ptr(), N, H, W, C, C, 1, 1.0, 0, 0, ws.data_ptr(), ws.numel(), s)
+        elif what == "skip":   # dgrad-of-conv1 style epilogue: ReLU mask + residual add
             rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), None, sk.data_ptr(), x.data_ptr(), y.data_ptr(), N, H, W, C, C, 0.1, 0, 0.0, 0, 0, None, 0, s)
         else:
             rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1.0, 1, 0.0, 0, 0, None, 0, s)
