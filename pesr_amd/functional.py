@@ -282,9 +282,13 @@ def repack_all(params) -> None:
         return
     dev = jobs[0][1].device
     key = (tuple(sorted(ids)), tuple(j[3] for j in jobs))
+    # One descriptor table per (parameter set, pack layout), kept on the device: the H2D copy that builds it SYNCHRONISES the
+    # host with the stream, so it must happen once per optimizer - not once per step (with one shared slot, the G and D
+    # optimizers of the GAN step evicted each other's table every step and the host could never run ahead of the GPU).
     table = _REPACK_TABLES.get(key)
     if table is None:
-        _REPACK_TABLES.clear()
+        if len(_REPACK_TABLES) >= 8:
+            _REPACK_TABLES.clear()
         table = _REPACK_TABLES[key] = torch.from_numpy(np.array([j[3] for j in jobs], dtype=np.int64)).to(dev)
     from . import _lib
     _lib.check(_lib.lib().pesr_pack_conv3x3_batched(table.data_ptr(), len(jobs), torch.cuda.current_stream(dev).cuda_stream),

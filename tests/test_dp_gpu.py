@@ -98,11 +98,34 @@ def test_n_rank_gan_steps_vs_full_batch_oracle(nproc, tmp_path):
     C, depth, ps, B = 64, 2, 24, 4
     cfg = {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5, "dp_replicas": nproc}
     st = OS.TrainState(gen_sd(C, depth), dis_sd(ps), vgg_sd(), cfg)
-    # The GAN step's gradients are ill-conditioned in fp32 (LeakyReLU / ReLU kinks, BatchNorm over 4-sample shards): the same
-    # step is also run in float64, and our gradients may be off from that truth by at most 3 x the fp32 oracle's own error for
-    # the tensor (never asked below twice the oracle's worst tensor).  The exchange itself is pinned bit-exactly by the test above.
-    f64 = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-    st64 = OS.TrainState(f64(gen_sd(C, depth)), f64(dis_sd(ps)), f64(vgg_sd()), cfg)
+    # The GAN step's gradients are ill-conditioned in fp32 (LeakyReLU / ReLU kinks, BatchNorm over 4-sample shards): a rounding-
+    # level change anywhere flips masks and moves whole gradient tensors.  The tolerance is therefore MEASURED here, per tensor:
+    # the fp32 oracle is re-run with every weight perturbed by one relative ulp (w * (1 +- 2^-23), three draws), and our
+    # gradient may differ from the oracle's by at most 5 x the spread those one-ulp perturbations produce (and 1e-4 of the
+    # tensor's maximum where the spread is smaller).  The exchange itself is pinned bit-exactly by the test above.
+    def perturbed(sd, seed):
+        gen = torch.Generator().manual_seed(seed)
+        return {k: (v * (1.0 + (torch.randint(0, 2, v.shape, generator=gen).to(v.dtype) * 2 - 1) * 2.0 ** -23)
+                    if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    lr0 = detrand.image_batch((B * nproc, 3, ps, ps), 700)
+    hr0 = detrand.image_batch((B * nproc, 3, 4 * ps, 4 * ps), 800)
+    spread = {}
+    base_grads = None
+    for draw in range(4):
+        g_sd, d_sd = gen_sd(C, depth), dis_sd(ps)
+        if draw:
+            g_sd, d_sd = perturbed(g_sd, 10 + draw), perturbed(d_sd, 20 + draw)
+        stp = OS.TrainState(g_sd, d_sd, vgg_sd(), cfg)
+        OS.gan_step(stp, lr0, hr0)
+        grads = {("G", k): v.grad.clone() for k, v in stp.g.items()}
+        grads.update({("D", k): v.grad.clone() for k, v in stp.d.items() if v.grad is not None})
+        if draw == 0:
+            base_grads = grads
+        else:
+            for key, gr in grads.items():
+                mx = float(base_grads[key].abs().max())
+                if mx > 0:
+                    spread[key] = max(spread.get(key, 0.0), float((gr - base_grads[key]).abs().max()) / mx)
     for it in range(2):
         lr = detrand.image_batch((B * nproc, 3, ps, ps), 700 + it)
         hr = detrand.image_batch((B * nproc, 3, 4 * ps, 4 * ps), 800 + it)
@@ -110,20 +133,14 @@ def test_n_rank_gan_steps_vs_full_batch_oracle(nproc, tmp_path):
         close(got["losses"][it].numpy(), np.array([ref[k] for k in ("l1", "vgg", "g", "tv", "d")]), 5e-5 if it == 0 else 5e-4,
               what=f"losses step {it}")
         if it == 0:     # gradients of the FIRST step, averaged over ranks = the full-batch ones
-            OS.gan_step(st64, lr.double(), hr.double())
-            for name, leaves, leaves64 in (("G", st.g, st64.g), ("D", st.d, st64.d)):
-                rows = []
+            for name, leaves in (("G", st.g), ("D", st.d)):
                 for k, v in leaves.items():
-                    if k not in got[name + ".grad"] or v.grad is None:
+                    if k not in got[name + ".grad"] or v.grad is None or (name, k) not in spread:
                         continue
-                    v64 = leaves64[k].grad
-                    mx = float(v64.abs().max())
-                    if mx == 0.0:
-                        continue
-                    rows.append((k, float((v.grad.double() - v64).abs().max()) / mx, float((got[name + ".grad"][k].double() - v64).abs().max()) / mx))
-                floor = max(r[1] for r in rows)
-                for k, e_ref, e_ours in rows:
-                    assert e_ours <= max(3.0 * e_ref, 2.0 * floor), f"grad {name}.{k}: error vs fp64 {e_ours:.2e}, the fp32 oracle's own {e_ref:.2e} (worst tensor {floor:.2e})"
+                    mx = float(v.grad.abs().max())
+                    err = float((got[name + ".grad"][k] - v.grad).abs().max()) / mx
+                    tol = max(1e-4, 5.0 * spread[(name, k)])
+                    assert err <= tol, f"grad {name}.{k}: {err:.2e} of the maximum > {tol:.2e} (one-ulp weight perturbations move it by {spread[(name, k)]:.2e})"
     for k, v in st.g.items():
         adam_close(got["G"][k], v, 5e-5, 2, "G." + k)
     for k, v in st.d.items():
