@@ -157,13 +157,16 @@ int pesr_bn_lrelu_bwd(const float* x, const float* dy, const float* gamma, const
                       float* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw,
                       void* workspace, size_t ws_bytes, void* stream);
 
-/* ---- skinny-batch Linear (reference model/pesr.py:69-74; ATen addmm/mm), M <= 32 ---------------- */
+/* ---- skinny-batch Linear (reference model/pesr.py:69-74; ATen addmm/mm), M <= 32 per call ------- */
+/* (the Python binding walks larger batches in chunks of 32 rows: pesr_amd/ops.py linear_*).
+ * pesr_linear_wgrad: accumulate = 1 adds to dw / db instead of overwriting them (the second use of a layer inside one
+ * backward pass - the Discriminator sees hr and sr in the same graph, reference train.py:205-214 - and batch chunks). */
 size_t pesr_linear_workspace_bytes(int M, int N, long K);
 int pesr_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, long K, int act, float slope,
                     void* workspace, size_t ws_bytes, void* stream);
 int pesr_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, long K, void* workspace, size_t ws_bytes,
                       void* stream);
-int pesr_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, long K, void* stream);
+int pesr_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, long K, int accumulate, void* stream);
 
 /* ---- losses, fused forward + gradient (reference train.py:131-140) --------------------------------- */
 /* sr, hr, grad: [N][H][W][3].  out2[0] = mean|sr-hr|, out2[1] = TV sum.  grad = g_l1*sign(sr-hr) + g_tv*dTV/dsr

@@ -58,7 +58,7 @@ SIGNATURES.update({
     "pesr_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_long]),
     "pesr_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_long, c_int, c_float, _P, c_size_t, _P]),
     "pesr_linear_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_long, _P, c_size_t, _P]),
-    "pesr_linear_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_long, _P]),
+    "pesr_linear_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_long, c_int, _P]),
     "pesr_loss_l1_tv_fwd_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "pesr_mse_fwd_bwd": (c_int, [_P, _P, _P, _P, c_long, c_float, _P, c_size_t, _P]),
     "pesr_crop_augment": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 2; }
+PESR_API int pesr_abi_version(void) { return 3; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -115,8 +115,9 @@ PESR_API int pesr_linear_dgrad(const float* dy, const float* w, float* dx, int M
                                void* stream) {
     return pesr_linear_dgrad_launch(dy, w, dx, M, N, K, workspace, ws_bytes, (hipStream_t)stream);
 }
-PESR_API int pesr_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, long K, void* stream) {
-    return pesr_linear_wgrad_launch(dy, x, dw, db, M, N, K, (hipStream_t)stream);
+PESR_API int pesr_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, long K, int accumulate,
+                               void* stream) {
+    return pesr_linear_wgrad_launch(dy, x, dw, db, M, N, K, accumulate, (hipStream_t)stream);
 }
 
 PESR_API int pesr_loss_l1_tv_fwd_bwd(const float* sr, const float* hr, float* grad, float* out2, int N, int H, int W, float g_l1,

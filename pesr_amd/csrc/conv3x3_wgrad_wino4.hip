@@ -234,9 +234,27 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
                 // The staging stores go to LDS that nobody reads in this segment (the two free ring slots, the other dM
                 // buffer); right behind them the loads for the segment after next reuse the staging registers.
                 __builtin_amdgcn_sched_barrier(0);
+#if defined(G4_ABL_STAGE)     // timing-only ablation builds (scripts/wino4_ab.py wgrad): false at run time, nothing is DCE'd
+                if (cont && a.ps_in == 12345) {
+#else
                 if (cont) {
+#endif
                     int sl = base + 4 + v_rr; if (sl >= G4_RING) sl -= G4_RING;
-                    store_v(sl); store_d(par ^ 1);
+#ifdef G4_ABL_STORES
+                    if (a.ps_in == 12345)
+#endif
+                    { store_v(sl); store_d(par ^ 1); }
+#ifdef G4_ABL_STORES
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(vx[j]));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(dd[j]));
+                    }
+#endif
+#ifdef G4_ABL_LOADS
+                    if (a.ps_in == 12345)
+#endif
                     if (cont2) { load_v(img, row + 5 + v_rr); load_d(img, row + 4 + d_rr); }
                 }
             }

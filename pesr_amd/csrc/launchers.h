@@ -45,7 +45,8 @@ int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float
                            void* ws, size_t ws_bytes, hipStream_t stream);
 int pesr_linear_dgrad_launch(const float* dy, const float* W, float* dx, int M, int N, long K, void* ws, size_t ws_bytes,
                              hipStream_t stream);
-int pesr_linear_wgrad_launch(const float* dy, const float* x, float* dW, float* db, int M, int N, long K, hipStream_t stream);
+int pesr_linear_wgrad_launch(const float* dy, const float* x, float* dW, float* db, int M, int N, long K, int accumulate,
+                             hipStream_t stream);
 
 int pesr_loss_l1_tv_launch(const float* sr, const float* hr, float* grad, float* out2, int N, int H, int W, float g_l1, float g_tv,
                            void* ws, size_t ws_bytes, hipStream_t stream);

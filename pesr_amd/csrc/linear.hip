@@ -142,7 +142,7 @@ __global__ void linear_dgrad_final_kernel(const f32x4* __restrict__ part, f32x4*
 // thread: 4 consecutive k with x[0..M)[k4] held in registers; loops over an N slice writing dW rows.
 template <int MB>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           float* __restrict__ dW, int M, int N, long K, int nchunk) {
+                                                           float* __restrict__ dW, int M, int N, long K, int nchunk, int accumulate) {
     const long k = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const int n0 = blockIdx.y * nchunk;
     int n1 = n0 + nchunk; if (n1 > N) n1 = N;
@@ -155,15 +155,16 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 #pragma unroll
         for (int m = 0; m < MB; ++m)
             if (m < M) s += xv[m] * dy[(size_t)m * N + n];
+        if (accumulate) s += *(const f32x4*)(dW + (size_t)n * K + k);     // dW += ... : a second use of the layer in one backward
         *(f32x4*)(dW + (size_t)n * K + k) = s;
     }
 }
-__global__ void linear_bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N) {
+__global__ void linear_bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N, int accumulate) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float s = 0.f;
     for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
-    db[n] = s;
+    db[n] = accumulate ? db[n] + s : s;
 }
 
 namespace {
@@ -227,12 +228,13 @@ int pesr_linear_dgrad_launch(const float* dy, const float* W, float* dx, int M, 
     return pesr_launch_status();
 }
 
-int pesr_linear_wgrad_launch(const float* dy, const float* x, float* dW, float* db, int M, int N, long K, hipStream_t stream) {
+int pesr_linear_wgrad_launch(const float* dy, const float* x, float* dW, float* db, int M, int N, long K, int accumulate,
+                             hipStream_t stream) {
     if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
     int nchunk = 64; if (nchunk > N) nchunk = N;
     const dim3 grid((unsigned)((K / 4 + 255) / 256), (unsigned)((N + nchunk - 1) / nchunk));
-    if (M <= 16) hipLaunchKernelGGL(linear_wgrad_kernel<16>, grid, dim3(256), 0, stream, dy, x, dW, M, N, K, nchunk);
-    else hipLaunchKernelGGL(linear_wgrad_kernel<32>, grid, dim3(256), 0, stream, dy, x, dW, M, N, K, nchunk);
-    if (db) hipLaunchKernelGGL(linear_bgrad_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dy, db, M, N);
+    if (M <= 16) hipLaunchKernelGGL(linear_wgrad_kernel<16>, grid, dim3(256), 0, stream, dy, x, dW, M, N, K, nchunk, accumulate);
+    else hipLaunchKernelGGL(linear_wgrad_kernel<32>, grid, dim3(256), 0, stream, dy, x, dW, M, N, K, nchunk, accumulate);
+    if (db) hipLaunchKernelGGL(linear_bgrad_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dy, db, M, N, accumulate);
     return pesr_launch_status();
 }

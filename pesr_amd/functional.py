@@ -53,6 +53,22 @@ def release_grad_views(params) -> None:
             e[1] = False
 
 
+def grad_out_again(param):
+    """The parameter's flat-gradient slice AFTER it has been claimed in this step (by grad_out), for a kernel that can
+    accumulate into it - the second use of a layer inside one backward pass; else None."""
+    if param is None or not param.is_leaf:
+        return None
+    e = getattr(param, _GRAD_VIEW_ATTR, None)
+    if e is None or not e[1]:
+        return None
+    return e[0]()
+
+
+def grad_view_claimed(param) -> bool:
+    e = getattr(param, _GRAD_VIEW_ATTR, None)
+    return bool(e is not None and e[1])
+
+
 def grad_out(param):
     """A fresh view of the parameter's flat-gradient slice if its first gradient may be written there, else None."""
     if param is None or not param.is_leaf or param.grad is not None:      # (replicas of nn.DataParallel are non-leaf)
@@ -525,7 +541,16 @@ class LinearFn(Function):
         dx = ops.linear_dgrad(gy, weight.detach()) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1]:
-            dw, db = ops.linear_wgrad(gy, x, want_bias=True, dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref))
+            o_w, o_b = grad_out(weight), grad_out(ctx.bias_ref)
+            if o_w is None and o_b is None and weight.grad is None:
+                # second use of this layer in the same backward pass (the Discriminator sees hr and sr in one graph,
+                # reference train.py:205-214): accumulate straight into the flat-gradient slices the first use wrote,
+                # and hand autograd nothing to add - for classifier.0 that add was a 302 MB elementwise kernel
+                a_w, a_b = grad_out_again(weight), grad_out_again(ctx.bias_ref)
+                if a_w is not None and a_b is not None:
+                    ops.linear_wgrad(gy, x, want_bias=True, dw_out=a_w, db_out=a_b, accumulate=True)
+                    return dx, None, None, None, None
+            dw, db = ops.linear_wgrad(gy, x, want_bias=True, dw_out=o_w, db_out=o_b)
         return dx, dw, db, None, None
 
 

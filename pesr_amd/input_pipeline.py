@@ -45,6 +45,16 @@ class GpuPatchSampler:
             picks.append((i, rng.randint(0, h - patch), rng.randint(0, w - patch), rng.randint(0, 7) if augment else 0))
         return picks
 
+    def draw_for(self, images: Sequence[int], patch: int, rng: Optional[random.Random] = None, augment: bool = True):
+        """As draw(), for a GIVEN list of image indices (an epoch permutation dealt out by the caller): only the crop origin
+        and the augmentation are random."""
+        rng = rng or random
+        picks = []
+        for i in images:
+            h, w, _ = self.lr_shapes[i]
+            picks.append((i, rng.randint(0, h - patch), rng.randint(0, w - patch), rng.randint(0, 7) if augment else 0))
+        return picks
+
     def assemble(self, picks: List[tuple], patch: int, nhwc: bool = False):
         """-> (lr [B,3,P,P], hr [B,3,4P,4P]) fp32 on the device (logical NCHW; channels_last memory when nhwc)."""
         B = len(picks)

@@ -441,14 +441,20 @@ def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param
 # ------------------------------------------------------------------------------------------------
 # Linear
 # ------------------------------------------------------------------------------------------------
+LIN_MAXM = 32     # rows per kernel call (pesr_hip.h); larger batches are walked in chunks
+
+
 def linear_fwd(x, w, b, act=ACT_NONE, slope=0.0):
     _chk(x, "linear_fwd.x")
     M, K = x.shape
     Nf = w.shape[0]
     L = _lib.lib()
-    ws = workspace(L.pesr_linear_workspace_bytes(M, Nf, K), x.device)
     y = torch.empty((M, Nf), dtype=torch.float32, device=x.device)
-    _lib.check(L.pesr_linear_fwd(_p(x), _p(w), _p(b), _p(y), M, Nf, K, act, slope, _p(ws), ws.numel(), _stream()), "pesr_linear_fwd")
+    for m0 in range(0, M, LIN_MAXM):
+        m = min(LIN_MAXM, M - m0)
+        ws = workspace(L.pesr_linear_workspace_bytes(m, Nf, K), x.device)
+        _lib.check(L.pesr_linear_fwd(_p(x[m0:m0 + m]), _p(w), _p(b), _p(y[m0:m0 + m]), m, Nf, K, act, slope, _p(ws), ws.numel(), _stream()),
+                   "pesr_linear_fwd")
     return y
 
 
@@ -457,19 +463,26 @@ def linear_dgrad(dy, w):
     M, Nf = dy.shape
     K = w.shape[1]
     L = _lib.lib()
-    ws = workspace(L.pesr_linear_workspace_bytes(M, Nf, K), dy.device)
     dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-    _lib.check(L.pesr_linear_dgrad(_p(dy), _p(w), _p(dx), M, Nf, K, _p(ws), ws.numel(), _stream()), "pesr_linear_dgrad")
+    for m0 in range(0, M, LIN_MAXM):
+        m = min(LIN_MAXM, M - m0)
+        ws = workspace(L.pesr_linear_workspace_bytes(m, Nf, K), dy.device)
+        _lib.check(L.pesr_linear_dgrad(_p(dy[m0:m0 + m]), _p(w), _p(dx[m0:m0 + m]), m, Nf, K, _p(ws), ws.numel(), _stream()), "pesr_linear_dgrad")
     return dx
 
 
-def linear_wgrad(dy, x, want_bias=True, dw_out=None, db_out=None):
+def linear_wgrad(dy, x, want_bias=True, dw_out=None, db_out=None, accumulate=False):
+    """accumulate: add to dw_out / db_out (which then must be given) instead of overwriting them."""
     _chk(dy, "linear_wgrad.dy")
     M, Nf = dy.shape
     K = x.shape[1]
+    assert not accumulate or (dw_out is not None and (db_out is not None or not want_bias))
     dw = _out(dw_out, (Nf, K), dy.device)
     db = _out(db_out, (Nf,), dy.device) if want_bias else None
-    _lib.check(_lib.lib().pesr_linear_wgrad(_p(dy), _p(x), _p(dw), _p(db), M, Nf, K, _stream()), "pesr_linear_wgrad")
+    for m0 in range(0, M, LIN_MAXM):
+        m = min(LIN_MAXM, M - m0)
+        _lib.check(_lib.lib().pesr_linear_wgrad(_p(dy[m0:m0 + m]), _p(x[m0:m0 + m]), _p(dw), _p(db), m, Nf, K, int(accumulate or m0 > 0), _stream()),
+                   "pesr_linear_wgrad")
     return dw, db
 
 

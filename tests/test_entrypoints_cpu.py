@@ -156,3 +156,40 @@ def test_lr_schedule_order_matches_reference_under_its_pinned_torch():
 def pytest_approx(v):
     import pytest
     return pytest.approx(v, rel=1e-12)
+
+
+def test_gpu_loader_epoch_composition_matches_the_reference():
+    """train.py GpuLoader: every image num_repeats times per epoch (reference data.py:60-77 + shuffle=True, drop_last=True), dealt
+    to the ranks without overlap; a new permutation each epoch."""
+    Tm = _load("train")
+
+    class _NoSampler:          # only the index plan is under test here (the device part needs a GPU)
+        pass
+    n, rep, batch, world = 7, 4, 3, 2
+    loaders = [Tm.GpuLoader(_NoSampler(), batch, 24, n, rep, r, world) for r in range(world)]
+    per_rank = [l.epoch_indices() for l in loaders]
+    iters = (n * rep) // (batch * world)
+    assert len(loaders[0]) == iters and all(len(p) == iters * batch for p in per_rank)
+    used = sorted(per_rank[0] + per_rank[1])
+    full = sorted(list(range(n)) * rep)
+    assert len(used) == iters * batch * world and all(used.count(i) <= rep for i in range(n))
+    assert sum((full.count(i) - used.count(i)) for i in range(n)) == n * rep - len(used)      # only the drop_last tail is missing
+    e0 = list(per_rank[0])
+    for l in loaders:
+        l.set_epoch(1)
+    assert loaders[0].epoch_indices() != e0                                                   # reshuffled per epoch
+    assert loaders[0].epoch_indices() == Tm.GpuLoader(_NoSampler(), batch, 24, n, rep, 0, world).__class__.epoch_indices(loaders[0])
+
+
+def test_train_refuses_a_gan_run_without_pretrained_vgg():
+    """`python train.py` must not silently train the perceptual loss against random VGG19 features."""
+    import pytest
+    Tm = _load("train")
+    args = Tm.build_parser().parse_args([])
+    assert args.vgg_weights == "" and args.allow_random_vgg is False and args.synthetic == 0
+    with pytest.raises(SystemExit, match="pretrained vgg19"):
+        Tm.build_vgg(args, torch.device("cpu"), 0, 1)
+    with pytest.raises(SystemExit, match="multiple of"):
+        Tm.check_limits(Tm.build_parser().parse_args(["--batch_size", "10"]), 4)
+    with pytest.raises(SystemExit, match="patch_size"):
+        Tm.check_limits(Tm.build_parser().parse_args(["--patch_size", "22"]), 1)

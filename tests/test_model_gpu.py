@@ -255,3 +255,35 @@ def test_gan_step_other_branches_vs_oracle(gan_type, focal):
         assert float(log[k]) == pytest.approx(ref[k], rel=5e-5, abs=1e-7), k
     for k, v in G.state_dict().items():
         adam_close(v, st.g[k], 5e-5, 1, "G." + k)
+
+
+def test_test_entrypoint_end_to_end(tmp_path, monkeypatch):
+    """test.py main() (reference test.py:76-116) on a folder of PNGs: perceptual model + x8-ensembled PSNR model blended
+    in image space, written as PNG - against the CPU oracle's plumbing run on the same files (at most one grey level apart:
+    the blend is rounded to uint8)."""
+    import importlib.util, os
+    from PIL import Image
+    from oracle import image as OI
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("entry_test_e2e", os.path.join(root, "test.py"))
+    T = importlib.util.module_from_spec(spec); spec.loader.exec_module(T)
+    monkeypatch.chdir(tmp_path)
+    lr_dir = tmp_path / "data" / "origin" / "test" / "Toy" / "LR"
+    lr_dir.mkdir(parents=True)
+    imgs = {}
+    for name, (h, w), seed in (("a.png", (21, 30), 1), ("b.png", (16, 16), 2)):
+        arr = detrand.image_batch((h, w, 3), 900 + seed).numpy().astype(np.uint8)
+        Image.fromarray(arr).save(lr_dir / name)
+        imgs[name] = arr
+    sd_perc, sd_psnr = gen_sd(64, 2, seed=3), gen_sd(64, 2, seed=4)
+    torch.save(sd_perc, tmp_path / "perc.pt"); torch.save(sd_psnr, tmp_path / "psnr.pt")
+    T.main(["--dataset", "Toy", "--perceptual_model", str(tmp_path / "perc.pt"), "--psnr_model", str(tmp_path / "psnr.pt"),
+            "--num_channels", "64", "--num_blocks", "2", "--alpha", "0.6", "--save_path", str(tmp_path / "out")])
+    for name, arr in imgs.items():
+        got = np.asarray(Image.open(tmp_path / "out" / "Toy" / name).convert("RGB")).astype(np.int32)
+        x = torch.from_numpy(arr.transpose(2, 0, 1)[None].astype(np.float32))
+        with torch.no_grad():
+            ref = 0.6 * OM.generator_forward(sd_perc, x, 2, 0.1) + 0.4 * OI.x8_forward(x, lambda t: OM.generator_forward(sd_psnr, t, 2, 0.1))
+        want = OI.tensor_to_img(ref).astype(np.int32)
+        assert got.shape == want.shape == (4 * arr.shape[0], 4 * arr.shape[1], 3)
+        assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01, (np.abs(got - want).max(), (got != want).mean())

@@ -131,8 +131,9 @@ def test_bn_lrelu(N, C, H, W, nchw):
     _close(_nchw(dx), xr.grad, 5e-5, "bn dx"); _close(dg.cpu(), gr.grad, 5e-5, "dgamma"); _close(db.cpu(), br.grad, 5e-5, "dbeta")
 
 
-@pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (3, 70, 1000), (16, 1024, 73728)])
+@pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (3, 70, 1000), (16, 1024, 73728), (70, 96, 2048)])
 def test_linear(M, N, K):
+    """(70 rows: more than one 32-row kernel call - a per-GPU batch of 64 must not abort in D's classifier.)"""
     from pesr_amd import ops
     x = _rand(M, K, seed=1); w = _rand(N, K, seed=2, lo=-0.01, hi=0.01); b = _rand(N, seed=3)
     ref = F.leaky_relu(F.linear(x, w, b), 0.2)
@@ -143,6 +144,10 @@ def test_linear(M, N, K):
     _close(dx.cpu(), dy @ w, 2e-5, "linear dgrad")
     dw, db = ops.linear_wgrad(dy.cuda(), x.cuda())
     _close(dw.cpu(), dy.t() @ x, 2e-5, "linear wgrad"); _close(db.cpu(), dy.sum(0), 1e-5, "linear bgrad")
+    # accumulate mode: a second contribution lands in the same buffers (the layer used twice in one backward pass)
+    dy2 = _rand(M, N, seed=5); x2 = _rand(M, K, seed=6)
+    ops.linear_wgrad(dy2.cuda(), x2.cuda(), dw_out=dw, db_out=db, accumulate=True)
+    _close(dw.cpu(), dy.t() @ x + dy2.t() @ x2, 2e-5, "linear wgrad accumulate"); _close(db.cpu(), dy.sum(0) + dy2.sum(0), 1e-5, "bgrad accumulate")
 
 
 def test_losses_and_adam():

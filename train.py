@@ -52,39 +52,69 @@ def build_parser():
     p.add_argument("--alpha_l1", type=float, default=0)
     # additions
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic samples per epoch instead of a dataset folder")
-    p.add_argument("--vgg_weights", type=str, default="", help="state_dict file of torchvision vgg19 (offline pretrained weights)")
+    p.add_argument("--vgg_weights", type=str, default="",
+                   help="state_dict file of torchvision's pretrained vgg19 (torch.save(torchvision.models.vgg19(pretrained=True)"
+                        ".state_dict(), path)); REQUIRED for the GAN phase unless torchvision itself is importable")
+    p.add_argument("--allow_random_vgg", type=str2bool, default=False,
+                   help="GAN phase without pretrained VGG19 weights: seeded random features (benchmarks / smoke runs only - the "
+                        "perceptual loss is then NOT the reference's)")
     p.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (smoke runs)")
     p.add_argument("--gpu_pipeline", type=str2bool, default=False,
                    help="keep the uint8 training images in HBM and crop/augment on the GPU (pesr_amd.input_pipeline)")
     return p
 
 
-def make_loaders(args, rank, world):
+def make_loaders(args, rank, world, need_train=True):
     from data import FolderSRDataset, SyntheticSRDataset
+    train_set = None
     if args.synthetic:
         train_set = SyntheticSRDataset(args.synthetic, args.patch_size)
         val_set = SyntheticSRDataset(min(args.num_valids, 2), args.patch_size, seed=99)
     else:
-        train_set = FolderSRDataset(os.path.join("data/origin/train", args.train_dataset), args.patch_size, args.num_repeats, True)
+        if need_train:      # (the GPU input pipeline replaces the host training loader altogether)
+            train_set = FolderSRDataset(os.path.join("data/origin/train", args.train_dataset), args.patch_size, args.num_repeats, True)
         val_set = FolderSRDataset(os.path.join("data/origin/valid", args.valid_dataset), None, 1, False, fixed_length=10)
-    sampler = DistributedSampler(train_set, world, rank, shuffle=True, drop_last=True) if world > 1 else None
-    train_loader = DataLoader(train_set, batch_size=args.batch_size // world, shuffle=sampler is None, sampler=sampler,
-                              num_workers=4, pin_memory=True, drop_last=True)
+    sampler = train_loader = None
+    if train_set is not None:
+        sampler = DistributedSampler(train_set, world, rank, shuffle=True, drop_last=True) if world > 1 else None
+        train_loader = DataLoader(train_set, batch_size=args.batch_size // world, shuffle=sampler is None, sampler=sampler,
+                                  num_workers=4, pin_memory=True, drop_last=True)
     val_loader = DataLoader(val_set, batch_size=1, shuffle=False, num_workers=1, pin_memory=True)
     return train_loader, val_loader, sampler
 
 
 class GpuLoader:
-    """Iterable with the DataLoader's contract (yields (lr, hr) batches) on top of GpuPatchSampler."""
+    """Iterable with the DataLoader's contract (yields (lr, hr) batches) on top of GpuPatchSampler, with the reference's epoch
+    composition (reference data.py:60-77 + DataLoader(shuffle=True, drop_last=True), train.py:96-97): every image appears
+    exactly num_repeats times per epoch in a fresh random order; under torch.distributed the epoch's permutation (seeded by
+    the epoch, identical on all ranks) is dealt round-robin to the ranks like DistributedSampler does, so no image is drawn
+    twice into one global batch position and every sample is seen by exactly one rank."""
 
-    def __init__(self, sampler, batch, patch, iters, seed):
+    def __init__(self, sampler, batch, patch, n_images, num_repeats, rank, world, seed=1):
         import random
-        self.sampler, self.batch, self.patch, self.iters = sampler, batch, patch, iters
-        self.rng = random.Random(seed)
+        self.sampler, self.batch, self.patch = sampler, batch, patch
+        self.n, self.rep, self.rank, self.world, self.seed = n_images, num_repeats, rank, world, seed
+        self.epoch = 0
+        self.rng = random.Random(seed * 7919 + rank)          # crop origins / augmentation: per-rank stream
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return (self.n * self.rep) // (self.batch * self.world)
+
+    def epoch_indices(self):
+        import random
+        order = list(range(self.n)) * self.rep
+        random.Random(self.seed * 1000003 + self.epoch).shuffle(order)
+        usable = len(self) * self.batch * self.world            # drop_last
+        return order[self.rank:usable:self.world]
 
     def __iter__(self):
-        for _ in range(self.iters):
-            yield self.sampler.sample(self.batch, self.patch, self.rng, augment=True, nhwc=True)
+        idx = self.epoch_indices()
+        for b in range(len(self)):
+            picks = self.sampler.draw_for(idx[b * self.batch:(b + 1) * self.batch], self.patch, self.rng, augment=True)
+            yield self.sampler.assemble(picks, self.patch, nhwc=True)
 
 
 def make_gpu_loader(args, rank, world, device):
@@ -95,8 +125,52 @@ def make_gpu_loader(args, rank, world, device):
     lr_paths = sorted(glob.glob(os.path.join(root, "LR", "*.png")))
     lrs = [np.asarray(Image.open(p).convert("RGB")) for p in lr_paths]
     hrs = [np.asarray(Image.open(os.path.join(root, "HR", os.path.basename(p))).convert("RGB")) for p in lr_paths]
-    iters = len(lrs) * args.num_repeats // args.batch_size
-    return GpuLoader(GpuPatchSampler(lrs, hrs, device), args.batch_size // world, args.patch_size, iters, seed=1 + rank)
+    return GpuLoader(GpuPatchSampler(lrs, hrs, device), args.batch_size // world, args.patch_size, len(lrs), args.num_repeats,
+                     rank, world)
+
+
+def build_vgg(args, device, rank, world):
+    """The reference's perceptual loss uses torchvision's PRETRAINED vgg19 (reference model/vgg.py:8); training against anything
+    else silently produces a different model.  Order of preference: --vgg_weights file; torchvision's own pretrained weights if
+    that package is importable; else refuse, unless --synthetic / --allow_random_vgg ask for seeded random features - which are
+    then made identical on every rank (seeded construction + broadcast from rank 0), so all replicas optimise the same loss."""
+    import warnings
+    from model import VGG
+    if args.vgg_weights:
+        return VGG(args.vgg_weights).to(device)
+    try:
+        import torchvision
+        sd = torchvision.models.vgg19(pretrained=True).state_dict()
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            torch.save(sd, f.name)
+            return VGG(f.name).to(device)
+    except Exception as e:      # torchvision missing, or no network for its model zoo
+        if not (args.synthetic or args.allow_random_vgg):
+            raise SystemExit("train.py: the GAN phase needs torchvision's pretrained vgg19 weights (reference model/vgg.py:8): pass "
+                             "--vgg_weights <state_dict file>, or --allow_random_vgg true for a run whose perceptual loss is NOT the "
+                             f"reference's (torchvision unavailable: {type(e).__name__})")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        state = torch.random.get_rng_state()
+        torch.manual_seed(20180917)
+        vgg = VGG().to(device)
+        torch.random.set_rng_state(state)
+    if world > 1:
+        for p in vgg.parameters():
+            dist.broadcast(p.data, 0)
+    if rank == 0:
+        print("WARNING: VGG19 features are RANDOM (seeded): the perceptual loss of this run is not the reference's")
+    return vgg
+
+
+def check_limits(args, world):
+    """Shape limits of the HIP path, checked up front with a clear message instead of a PESR_EINVAL deep inside a step."""
+    if args.batch_size % world:
+        raise SystemExit(f"train.py: --batch_size {args.batch_size} must be a multiple of the {world} ranks")
+    if args.phase != "pretrain" and args.patch_size % 4:
+        raise SystemExit("train.py: the GAN phase needs --patch_size % 4 == 0 (HR patches must survive four stride-2 stages and "
+                         "VGG's four 2x2 max-pools, which this implementation does for even sizes only)")
 
 
 def main(argv=None):
@@ -110,6 +184,7 @@ def main(argv=None):
     device = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+    check_limits(args, world)
     if rank == 0:
         print("_____________YOUR SETTINGS_____________")
         for k, v in vars(args).items():
@@ -120,9 +195,10 @@ def main(argv=None):
     from pesr_amd.step import Trainer
     from utils import compute_PSNR
 
-    train_loader, val_loader, sampler = make_loaders(args, rank, world)
-    if args.gpu_pipeline and not args.synthetic:
-        train_loader, sampler = make_gpu_loader(args, rank, world, device), None
+    gpu_pipe = args.gpu_pipeline and not args.synthetic
+    train_loader, val_loader, sampler = make_loaders(args, rank, world, need_train=not gpu_pipe)
+    if gpu_pipe:
+        train_loader = sampler = make_gpu_loader(args, rank, world, device)      # (it has set_epoch like a DistributedSampler)
     opt = {"patch_size": args.patch_size, "num_channels": args.num_channels, "depth": args.num_blocks,
            "res_scale": args.res_scale, "spectral_norm": args.spectral_norm}
     G = Generator(opt)
@@ -131,7 +207,7 @@ def main(argv=None):
     G = G.to(device)
     gan = args.phase != "pretrain"
     D = Discriminator(opt).to(device) if gan else None
-    vgg = VGG(args.vgg_weights or None).to(device) if gan else None
+    vgg = build_vgg(args, device, rank, world) if gan else None
 
     optim_G = FlatAdam([p for p in G.parameters() if p.requires_grad], lr=args.learning_rate, betas=(0.9, 0.999))
     optim_D = FlatAdam(D.parameters(), lr=args.learning_rate, betas=(0.9, 0.999)) if gan else None
