@@ -287,3 +287,18 @@ def test_test_entrypoint_end_to_end(tmp_path, monkeypatch):
         want = OI.tensor_to_img(ref).astype(np.int32)
         assert got.shape == want.shape == (4 * arr.shape[0], 4 * arr.shape[1], 3)
         assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01, (np.abs(got - want).max(), (got != want).mean())
+
+
+def test_config5_crop_vs_oracle():
+    """BASELINE config 5 against the CPU oracle (not only against itself): the full 256 ch x 32 block generator on a 160x160 LR
+    image (one 640x640 output; every layer takes the large-image tiling: several tiles per row and per column, the F(4,3)
+    kernels' 96-px-wide tiles, ragged last tiles) - G-forward tolerance of SURVEY 8c."""
+    sd = gen_sd(256, 32)
+    G = _G(256, 32, sd)
+    x = detrand.image_batch((1, 3, 160, 160), 55)
+    with torch.no_grad():
+        y = G(x.cuda())
+        torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+        ref = OM.generator_forward(sd, x, 32, 0.1)
+    assert y.shape == ref.shape == (1, 3, 640, 640)
+    close(y, ref, 1e-5, 2e-3, "config-5-style crop vs oracle")
