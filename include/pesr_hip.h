@@ -157,6 +157,16 @@ int pesr_bn_lrelu_bwd(const float* x, const float* dy, const float* gamma, const
                       float* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw,
                       void* workspace, size_t ws_bytes, void* stream);
 
+/* Eval-mode BatchNorm2d (+ activation): the statistics are GIVEN - mean_invstd [2][C] = {running_mean, 1/sqrt(running_var + eps)}
+ * (nn.BatchNorm2d in .eval(), a constructor branch of reference model/basic.py:29 the reference's own scripts never take).
+ * slope: 0.2 LeakyReLU, 0 ReLU, 1 no activation (also accepted by the training-mode entry points above).
+ * bwd: dx = gamma * invstd * dz, dgamma = sum dz * xhat, dbeta = sum dz with dz = dy * act'(z); workspace as pesr_bn_workspace_bytes. */
+int pesr_bn_lrelu_eval_fwd(const float* x, const float* gamma, const float* beta, const float* mean_invstd, float* y, int N, int H,
+                           int W, int C, float slope, int y_nchw, void* stream);
+int pesr_bn_lrelu_eval_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd, float* dx,
+                           float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw, void* workspace,
+                           size_t ws_bytes, void* stream);
+
 /* ---- skinny-batch Linear (reference model/pesr.py:69-74; ATen addmm/mm), M <= 32 per call ------- */
 /* (the Python binding walks larger batches in chunks of 32 rows: pesr_amd/ops.py linear_*).
  * pesr_linear_wgrad: accumulate = 1 adds to dw / db instead of overwriting them (the second use of a layer inside one

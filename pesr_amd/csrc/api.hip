@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 3; }
+PESR_API int pesr_abi_version(void) { return 4; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -104,6 +104,17 @@ PESR_API int pesr_bn_lrelu_bwd(const float* x, const float* dy, const float* gam
                                void* workspace, size_t ws_bytes, void* stream) {
     return pesr_bn_lrelu_bwd_launch(x, dy, gamma, beta, mean_invstd, dx, dgamma, dbeta, (long)N * H * W, C, (long)H * W, slope,
                                     dy_nchw, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+PESR_API int pesr_bn_lrelu_eval_fwd(const float* x, const float* gamma, const float* beta, const float* mean_invstd, float* y, int N,
+                                    int H, int W, int C, float slope, int y_nchw, void* stream) {
+    return pesr_bn_lrelu_apply_launch(x, gamma, beta, mean_invstd, y, (long)N * H * W, C, (long)H * W, slope, y_nchw, (hipStream_t)stream);
+}
+PESR_API int pesr_bn_lrelu_eval_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
+                                    float* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw,
+                                    void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_bn_lrelu_bwd_eval_launch(x, dy, gamma, beta, mean_invstd, dx, dgamma, dbeta, (long)N * H * W, C, (long)H * W, slope,
+                                         dy_nchw, workspace, ws_bytes, (hipStream_t)stream);
 }
 
 PESR_API size_t pesr_linear_workspace_bytes(int M, int N, long K) { return pesr_linear_ws_bytes(M, N, K); }

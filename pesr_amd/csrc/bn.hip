@@ -210,3 +210,48 @@ int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma
                        (f32x4*)dx, M, C, slope, HW, sn, sc, sp);
     return pesr_launch_status();
 }
+
+// ---- eval-mode BatchNorm (running statistics; nn.BatchNorm2d in .eval(), a constructor branch of reference model/basic.py:29) ----
+// mean_invstd [2][C] is GIVEN (mean = running_mean, invstd = 1/sqrt(running_var + eps), computed by the caller).
+int pesr_bn_lrelu_apply_launch(const float* x, const float* gamma, const float* beta, const float* mean_invstd, float* y, long M,
+                               int C, long HW, float slope, int y_nchw, hipStream_t stream) {
+    if (C % 4) return PESR_EINVAL;
+    const long total = M * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    long ysn = HW * C, ysc = 1, ysp = C;
+    if (y_nchw) { ysn = HW * C; ysc = HW; ysp = 1; }
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, mean_invstd, gamma, beta, y, M, C, slope, HW,
+                       ysn, ysc, ysp);
+    return pesr_launch_status();
+}
+
+// backward with fixed statistics: dx = gamma * invstd * dz, dgamma = sum dz * xhat, dbeta = sum dz  (dz = dy * lrelu'(z));
+// the batch-statistics terms of the training-mode formula vanish, i.e. bn_bwd_apply_kernel with zero sums.
+int pesr_bn_lrelu_bwd_eval_launch(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
+                                  float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, void* ws,
+                                  size_t ws_bytes, hipStream_t stream) {
+    if (C % 4) return PESR_EINVAL;
+    long nb, rpb; bn_grid(M, &nb, &rpb);
+    const size_t part_bytes = (size_t)nb * 2 * C * sizeof(float);
+    const size_t dsum_bytes = ((size_t)2 * C * sizeof(double) + 255) / 256 * 256;
+    if (!ws || ws_bytes < dsum_bytes + part_bytes + 2 * (size_t)C * sizeof(float)) return PESR_EWORKSPACE;
+    double* dsum = (double*)ws;
+    float* part = (float*)((char*)ws + dsum_bytes);
+    float* sums = (float*)((char*)ws + dsum_bytes + part_bytes);
+    long sn = HW * C, sc = 1, sp = C;
+    if (dy_nchw) { sn = HW * C; sc = HW; sp = 1; }
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb,
+                           slope, sn, sc, sp, HW);
+        int rc0 = pesr_reduce_rows_launch(part, dsum, (int)nb, 2 * C, stream);
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const double*)dsum, C, sums, dbeta, dgamma);
+    }
+    hipError_t e = hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    const long total = M * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, dy, mean_invstd, gamma, beta, (const float*)sums,
+                       (f32x4*)dx, M, C, slope, HW, sn, sc, sp);
+    return pesr_launch_status();
+}

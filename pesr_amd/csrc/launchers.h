@@ -40,6 +40,12 @@ int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma
                              float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, void* ws,
                              size_t ws_bytes, hipStream_t stream);
 
+int pesr_bn_lrelu_apply_launch(const float* x, const float* gamma, const float* beta, const float* mean_invstd, float* y, long M,
+                               int C, long HW, float slope, int y_nchw, hipStream_t stream);
+int pesr_bn_lrelu_bwd_eval_launch(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
+                                  float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, void* ws,
+                                  size_t ws_bytes, hipStream_t stream);
+
 size_t pesr_linear_ws_bytes(int M, int N, long K);
 int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float* y, int M, int N, long K, int act, float slope,
                            void* ws, size_t ws_bytes, hipStream_t stream);

@@ -383,6 +383,36 @@ class Conv3x3Fn(Function):
         return dx, dw, db, None, None, None, None, None
 
 
+class ConvLReluFn(Function):
+    """y = leaky_relu(conv(x, w) + b, slope): BasicBlock(bn=False, act=LeakyReLU) / ResBlock(act=LeakyReLU) - constructor
+    branches of reference model/basic.py the reference's own scripts never take."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache, stride, slope):
+        x = _c(x)
+        y = ops.conv3x3_fwd(x, lambda: cache.for_fwd(weight, x.shape, stride), cache.bias(bias), weight.shape[0], stride,
+                            act=ops.ACT_LRELU, slope=slope, ps_out=cache.ps, w_oihw=weight.detach())
+        ctx.cache, ctx.stride, ctx.slope, ctx.bias_ref = cache, stride, slope, bias
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gz = ops.relu_mask(_c(gy), y, slope=ctx.slope)          # sign(y) == sign(z) for a positive slope
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            want_b = ctx.bias_ref is not None and ctx.needs_input_grad[2]
+            if x.shape[3] == 3:
+                dw, db = ops.conv3x3_wgrad_rgb(gz, x, 0, want_bias=want_b, dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref) if want_b else None)
+            else:
+                dw, db = ops.conv3x3_wgrad(x, gz, ctx.stride, want_bias=want_b, ps_in=ctx.cache.ps, dw_out=grad_out(weight),
+                                           db_out=grad_out(ctx.bias_ref) if want_b else None)
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3x3_dgrad(gz, ctx.cache.for_dgrad(weight, x.shape, ctx.stride), tuple(x.shape), ctx.stride, ps_in=ctx.cache.ps)
+        return dx, dw, db, None, None, None
+
+
 def conv3x3(x, weight, bias, cache, stride=1, act=ops.ACT_NONE, relu_in=False, relu_grad_by_consumer=False):
     return Conv3x3Fn.apply(x, weight, bias, cache, stride, act, relu_in, relu_grad_by_consumer)
 
@@ -485,14 +515,24 @@ class MeanShiftFn(Function):
 # Discriminator BasicBlock: conv(no bias) -> BatchNorm2d(train) -> LeakyReLU(0.2)   reference model/basic.py:19-31
 # ------------------------------------------------------------------------------------------------
 class ConvBnLReluFn(Function):
+    """conv (bias optional) -> BatchNorm2d -> activation given by its negative slope (0.2 LeakyReLU, 0 ReLU, 1 none).
+    training = True: batch statistics (and the running-stat update) - the Discriminator's only use; training = False: the
+    running statistics (nn.BatchNorm2d in .eval(): a constructor branch of reference model/basic.py:26-30 the reference's own
+    scripts never take)."""
+
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, num_batches, cache, stride, eps, momentum,
-                slope, y_nchw):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches, cache, stride, eps, momentum,
+                slope, y_nchw, training):
         x = _c(x)
-        z = ops.conv3x3_fwd(x, lambda: cache.for_fwd(weight, x.shape, stride), None, weight.shape[0], stride, w_oihw=weight.detach())
-        y, stats = ops.bn_lrelu_fwd(z, gamma.detach(), beta.detach(), running_mean, running_var, num_batches, eps,
-                                    momentum, slope, y_nchw)
-        ctx.cache, ctx.stride, ctx.slope, ctx.y_nchw = cache, stride, slope, y_nchw
+        z = ops.conv3x3_fwd(x, lambda: cache.for_fwd(weight, x.shape, stride), None if bias is None else bias.detach(), weight.shape[0],
+                            stride, w_oihw=weight.detach())
+        if training:
+            y, stats = ops.bn_lrelu_fwd(z, gamma.detach(), beta.detach(), running_mean, running_var, num_batches, eps,
+                                        momentum, slope, y_nchw)
+        else:
+            stats = ops.bn_eval_stats(running_mean, running_var, eps)
+            y = ops.bn_lrelu_eval_fwd(z, gamma.detach(), beta.detach(), stats, slope, y_nchw)
+        ctx.cache, ctx.stride, ctx.slope, ctx.y_nchw, ctx.training, ctx.bias_ref = cache, stride, slope, y_nchw, training, bias
         ctx.save_for_backward(x, z, weight, gamma, beta, stats)
         return y
 
@@ -500,21 +540,39 @@ class ConvBnLReluFn(Function):
     def backward(ctx, gy):
         x, z, weight, gamma, beta, stats = ctx.saved_tensors
         gy = _c(gy)
-        need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
-        dz, dgamma, dbeta = ops.bn_lrelu_bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p,
-                                             dgamma_out=grad_out(gamma) if need_p else None, dbeta_out=grad_out(beta) if need_p else None)
-        dx = dw = None
+        need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        bwd = ops.bn_lrelu_bwd if ctx.training else ops.bn_lrelu_eval_bwd
+        dz, dgamma, dbeta = bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p,
+                                dgamma_out=grad_out(gamma) if need_p else None, dbeta_out=grad_out(beta) if need_p else None)
+        dx = dw = db = None
         wpd = ctx.cache.for_dgrad(weight, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
         if ctx.needs_input_grad[1]:
+            want_b = ctx.bias_ref is not None and ctx.needs_input_grad[2]
             o_w = grad_out(weight)
-            with _OnSide(dz.device, x, dz, fast=o_w is not None, where="d"):
+            o_b = grad_out(ctx.bias_ref) if want_b else None
+            with _OnSide(dz.device, x, dz, fast=o_w is not None and (o_b is not None or not want_b), where="d"):
                 if x.shape[3] == 3:
-                    dw, _ = ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=False, dw_out=o_w)
+                    dw, db = ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=want_b, dw_out=o_w, db_out=o_b)
                 else:
-                    dw, _ = ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=False, dw_out=o_w)
+                    dw, db = ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=want_b, dw_out=o_w, db_out=o_b)
         if ctx.needs_input_grad[0]:
             dx = ops.conv3x3_dgrad(dz, wpd, tuple(x.shape), ctx.stride)
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+
+
+class ScaleAddFn(Function):
+    """y = alpha * a + b (`res = body(x).mul(res_scale); res += x`, reference model/basic.py:49-50) - only the un-fused
+    ResBlock variants need it; the default ResBlock has it in its second conv's epilogue."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ctx.alpha = alpha
+        return ops.relu_mask(_c(a), None, _c(b), alpha=alpha)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = _c(gy)
+        return ops.relu_mask(gy, None, None, alpha=ctx.alpha), gy, None
 
 
 # ------------------------------------------------------------------------------------------------

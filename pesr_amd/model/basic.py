@@ -95,9 +95,37 @@ class _PixelShuffleFn(torch.autograd.Function):
         return ops.pixel_shuffle_bwd(gy.contiguous())
 
 
+def _act_slope(act):
+    """negative slope that stands for an activation module in the fused BN / conv epilogues (None: identity)."""
+    if act is None:
+        return 1.0
+    if isinstance(act, nn.LeakyReLU):
+        return float(act.negative_slope)
+    if isinstance(act, nn.ReLU):
+        return 0.0
+    raise NotImplementedError(f"activation {type(act).__name__}: the HIP epilogues implement ReLU, LeakyReLU and none")
+
+
+def _conv_act(conv, x_nhwc, act):
+    """conv (+bias) followed by an activation module (or None), un-fused with whatever comes next."""
+    slope = _act_slope(act)
+    if slope == 1.0:
+        return PF.conv3x3(x_nhwc, conv.weight, conv.bias, conv.packed, conv.stride)
+    if slope == 0.0:
+        return PF.conv3x3(x_nhwc, conv.weight, conv.bias, conv.packed, conv.stride, act=ops.ACT_RELU)
+    return PF.ConvLReluFn.apply(x_nhwc, conv.weight, conv.bias, conv.packed, conv.stride, slope)
+
+
+def _conv_bn_act(conv, bn, x_nhwc, act, y_nchw=False):
+    return PF.ConvBnLReluFn.apply(x_nhwc, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked, conv.packed, conv.stride, bn.eps, bn.momentum, _act_slope(act), y_nchw,
+                                  bn.training or bn.running_mean is None)
+
+
 class BasicBlock(nn.Sequential):
-    """conv (no bias) -> BatchNorm2d -> act (reference model/basic.py:19-31); the Discriminator's unit.
-    Fused path: bn=True with LeakyReLU; BatchNorm always uses batch statistics in training mode."""
+    """conv -> [BatchNorm2d] -> [act] (reference model/basic.py:19-31); the Discriminator's unit (no bias, BN in training mode,
+    LeakyReLU(0.2)).  Every combination the constructor accepts runs on the HIP kernels: conv bias, bn on / off, BatchNorm in
+    training or eval mode, act = ReLU / LeakyReLU / None."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, bias=False, bn=True, act=nn.ReLU(True),
                  sn=True):
@@ -111,40 +139,57 @@ class BasicBlock(nn.Sequential):
         if act is not None:
             m.append(act)
         super().__init__(*m)
-        self._fused = bn and isinstance(act, nn.LeakyReLU) and not bias
+        self._has_bn, self._has_act = bn, act is not None
         self.flatten_output = False  # set by Discriminator on its last block: emit NCHW-contiguous for .view(B, -1)
 
     def forward(self, x):
-        if not self._fused:
-            raise NotImplementedError("BasicBlock: only conv(no bias)+BatchNorm2d+LeakyReLU is implemented (the Discriminator's use)")
-        conv, bn, act = self[0], self[1], self[2]
-        if not bn.training:
-            raise NotImplementedError("BasicBlock: eval-mode BatchNorm is never used by the reference (D stays in train mode)")
-        y = PF.ConvBnLReluFn.apply(nhwc(x), conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                   bn.num_batches_tracked, conv.packed, conv.stride, bn.eps, bn.momentum,
-                                   act.negative_slope, self.flatten_output)
-        return y if self.flatten_output else nchw(y)
+        conv = self[0]
+        bn = self[1] if self._has_bn else None
+        act = self[-1] if self._has_act else None
+        if bn is not None:
+            y = _conv_bn_act(conv, bn, nhwc(x), act, self.flatten_output)
+            return y if self.flatten_output else nchw(y)
+        y = _conv_act(conv, nhwc(x), act)
+        if self.flatten_output:
+            return nchw(y).contiguous()
+        return nchw(y)
 
 
 class ResBlock(nn.Module):
-    """x + res_scale * conv(relu(conv(x))) (reference model/basic.py:33-52), one fused autograd node."""
+    """x + res_scale * conv(act(conv(x))) (reference model/basic.py:33-52).  The reference's only configuration (bias, no BN,
+    ReLU) is one fused autograd node; the other constructor branches (bn=True, bias=False, LeakyReLU) run un-fused on the
+    same kernels."""
 
     def __init__(self, n_feats, kernel_size, bias=True, bn=False, act=nn.ReLU(True), res_scale=1):
         super().__init__()
-        if bn or not bias or not isinstance(act, nn.ReLU):
-            raise NotImplementedError("ResBlock: the reference only uses bias=True, bn=False, act=ReLU")
+        _act_slope(act)       # rejects activations the epilogues do not implement
         modules_body = []
         for i in range(2):
             modules_body.append(Conv(n_feats, n_feats, kernel_size, bias=bias))
+            if bn:
+                modules_body.append(nn.BatchNorm2d(n_feats))
             if i == 0:
                 modules_body.append(act)
         self.body = nn.Sequential(*modules_body)
         self.res_scale = res_scale
+        self._bn = bn
+        self._fused = bias and not bn and isinstance(act, nn.ReLU) and not isinstance(act, nn.LeakyReLU)
 
     def forward(self, x):
-        c1, c2 = self.body[0], self.body[2]
-        return nchw(PF.ResBlockFn.apply(nhwc(x), c1.weight, c1.bias, c2.weight, c2.bias, c1.packed, c2.packed,
-                                        float(self.res_scale)))
+        if self._fused:
+            c1, c2 = self.body[0], self.body[2]
+            return nchw(PF.ResBlockFn.apply(nhwc(x), c1.weight, c1.bias, c2.weight, c2.bias, c1.packed, c2.packed,
+                                            float(self.res_scale)))
+        h = nhwc(x)
+        if self._bn:
+            c1, b1, act, c2, b2 = self.body
+            r = _conv_bn_act(c1, b1, h, act)
+            r = _conv_bn_act(c2, b2, r, None)
+        else:
+            c1, act, c2 = self.body
+            r = _conv_act(c1, h, act)
+            r = _conv_act(c2, r, None)
+        return nchw(PF.ScaleAddFn.apply(r, h, float(self.res_scale)))
 
 
 class Upsampler(nn.Sequential):

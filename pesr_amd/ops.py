@@ -438,6 +438,34 @@ def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param
     return dx, dgamma, dbeta
 
 
+def bn_eval_stats(running_mean, running_var, eps=1e-5):
+    """[2, C] {mean, invstd} of an eval-mode BatchNorm2d from its running statistics (C-sized torch glue)."""
+    return torch.stack([running_mean.float(), torch.rsqrt(running_var.float() + eps)]).contiguous()
+
+
+def bn_lrelu_eval_fwd(x, gamma, beta, stats, slope=0.2, y_nchw=False):
+    _chk(x, "bn_lrelu_eval_fwd.x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, C, H, W) if y_nchw else (N, H, W, C), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().pesr_bn_lrelu_eval_fwd(_p(x), _p(gamma), _p(beta), _p(stats), _p(y), N, H, W, C, slope, int(y_nchw), _stream())
+    _lib.check(rc, "pesr_bn_lrelu_eval_fwd")
+    return y
+
+
+def bn_lrelu_eval_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param_grads=True, dgamma_out=None, dbeta_out=None):
+    _chk(dy, "bn_lrelu_eval_bwd.dy")
+    N, H, W, C = x.shape
+    L = _lib.lib()
+    ws = workspace(L.pesr_bn_workspace_bytes(N * H * W, C), x.device)
+    dx = torch.empty_like(x)
+    dgamma = _out(dgamma_out, (C,), x.device) if need_param_grads else None
+    dbeta = _out(dbeta_out, (C,), x.device) if need_param_grads else None
+    rc = L.pesr_bn_lrelu_eval_bwd(_p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), N, H, W, C, slope,
+                                  int(dy_nchw), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "pesr_bn_lrelu_eval_bwd")
+    return dx, dgamma, dbeta
+
+
 # ------------------------------------------------------------------------------------------------
 # Linear
 # ------------------------------------------------------------------------------------------------

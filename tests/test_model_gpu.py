@@ -302,3 +302,80 @@ def test_config5_crop_vs_oracle():
         ref = OM.generator_forward(sd, x, 32, 0.1)
     assert y.shape == ref.shape == (1, 3, 640, 640)
     close(y, ref, 1e-5, 2e-3, "config-5-style crop vs oracle")
+
+
+def _ref_basic_block(cin, cout, stride, bias, bn, act):
+    import torch.nn as nn
+    m = [nn.Conv2d(cin, cout, 3, padding=1, stride=stride, bias=bias)]
+    if bn:
+        m.append(nn.BatchNorm2d(cout))
+    if act is not None:
+        m.append(act)
+    return nn.Sequential(*m)
+
+
+@pytest.mark.parametrize("bias,bn,act,train", [(True, True, "relu", True), (False, True, "lrelu", False), (True, False, "lrelu", True),
+                                               (False, True, None, True), (True, True, "lrelu", False), (False, False, "relu", True)])
+def test_basic_block_constructor_branches(bias, bn, act, train):
+    """Every BasicBlock the reference's constructor accepts (model/basic.py:19-31): conv bias, BatchNorm on / off and in eval
+    mode, ReLU / LeakyReLU / no activation - against the same nn.Sequential built from torch modules on the CPU."""
+    import copy
+    import torch.nn as nn
+    from model import BasicBlock
+    mk = lambda: {"relu": nn.ReLU(True), "lrelu": nn.LeakyReLU(0.2, True), None: None}[act]
+    torch.manual_seed(3)
+    blk = BasicBlock(32, 64, 3, stride=1, bias=bias, bn=bn, act=mk(), sn=False)
+    ref = _ref_basic_block(32, 64, 1, bias, bn, mk())
+    ref.load_state_dict(blk.state_dict())
+    if bn:
+        with torch.no_grad():
+            for m in (blk[1], ref[1]):
+                m.running_mean.copy_(detrand.uniform((64,), 5, -0.2, 0.2)); m.running_var.copy_(detrand.uniform((64,), 6, 0.5, 1.5))
+                m.weight.copy_(detrand.uniform((64,), 7, 0.5, 1.5)); m.bias.copy_(detrand.uniform((64,), 8, -0.1, 0.1))
+    blk.train(train); ref.train(train)
+    blk = blk.cuda()
+    x = detrand.uniform((2, 32, 12, 16), 11)
+    xr = x.clone().requires_grad_(True); xg = x.cuda().requires_grad_(True)
+    gy = detrand.uniform((2, 64, 12, 16), 12)
+    yr = ref(xr); yr.backward(gy)
+    yg = blk(xg); yg.backward(gy.cuda())
+    close(yg, yr.detach(), 2e-5, what="forward")
+    close(xg.grad, xr.grad, 1e-4, what="grad input")
+    for (k, pg), (_, pr) in zip(blk.named_parameters(), ref.named_parameters()):
+        if bn and train and k == "0.bias":      # a bias in front of training-mode BN has an exactly-zero gradient: compare absolutely
+            assert float(pg.grad.abs().max()) <= 1e-4 * float(gy.abs().sum()) and float(pr.grad.abs().max()) <= 1e-4 * float(gy.abs().sum())
+        else:
+            close(pg.grad, pr.grad, 1e-4, what="grad " + k)
+    if bn:
+        close(blk[1].running_mean, ref[1].running_mean, 1e-5, what="running_mean"); close(blk[1].running_var, ref[1].running_var, 1e-5, what="running_var")
+
+
+@pytest.mark.parametrize("bias,bn,act", [(True, True, "relu"), (False, False, "relu"), (True, False, "lrelu")])
+def test_res_block_constructor_branches(bias, bn, act):
+    """ResBlock variants of reference model/basic.py:33-52 beyond the one the Generator uses (bn=True, bias=False, LeakyReLU)."""
+    import torch.nn as nn
+    from model import ResBlock
+    mk = lambda: nn.ReLU(True) if act == "relu" else nn.LeakyReLU(0.1, True)
+    torch.manual_seed(4)
+    blk = ResBlock(64, 3, bias=bias, bn=bn, act=mk(), res_scale=0.3)
+    body = []
+    for i in range(2):
+        body.append(nn.Conv2d(64, 64, 3, padding=1, bias=bias))
+        if bn:
+            body.append(nn.BatchNorm2d(64))
+        if i == 0:
+            body.append(mk())
+    ref = nn.Sequential(*body)
+    ref.load_state_dict(blk.body.state_dict())
+    blk = blk.cuda()
+    x = detrand.uniform((2, 64, 10, 12), 21)
+    xr = x.clone().requires_grad_(True); xg = x.cuda().requires_grad_(True)
+    gy = detrand.uniform((2, 64, 10, 12), 22)
+    yr = ref(xr).mul(0.3) + xr; yr.backward(gy)
+    yg = blk(xg); yg.backward(gy.cuda())
+    close(yg, yr.detach(), 2e-5, what="forward")
+    close(xg.grad, xr.grad, 1e-4, what="grad input")
+    for (k, pg), (_, pr) in zip(blk.body.named_parameters(), ref.named_parameters()):
+        if bn and k.endswith("bias") and k[0] in "03" and pr.dim() == 1 and pr.shape[0] == 64 and "0.bias" == k or (bn and k == "3.bias"):
+            continue                               # conv biases in front of training-mode BN: exactly-zero gradients
+        close(pg.grad, pr.grad, 1e-4, what="grad " + k)
