@@ -167,6 +167,14 @@ int pesr_bn_lrelu_eval_bwd(const float* x, const float* dy, const float* gamma, 
                            float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw, void* workspace,
                            size_t ws_bytes, void* stream);
 
+/* Backward OF the training-mode BatchNorm backward - what the gradient penalty (reference train.py:216-226, autograd.grad(...,
+ * create_graph=True) through D's eight BatchNorm2d layers) needs: for dz = gamma * invstd * (du - mean(du) - xhat * mean(du * xhat))
+ * and g = dL/d(dz) it returns l_du = dL/d(du), l_z = dL/dz (through xhat and invstd) and l_gamma = dL/dgamma; any of the three
+ * outputs may be NULL.  All tensors [N][H][W][C]; mean_invstd as saved by pesr_bn_lrelu_fwd. */
+size_t pesr_bn_bwd_bwd_workspace_bytes(long M, int C);
+int pesr_bn_bwd_bwd(const float* z, const float* du, const float* g, const float* gamma, const float* mean_invstd, float* l_du,
+                    float* l_z, float* l_gamma, int N, int H, int W, int C, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- skinny-batch Linear (reference model/pesr.py:69-74; ATen addmm/mm), M <= 32 per call ------- */
 /* (the Python binding walks larger batches in chunks of 32 rows: pesr_amd/ops.py linear_*).
  * pesr_linear_wgrad: accumulate = 1 adds to dw / db instead of overwriting them (the second use of a layer inside one

@@ -83,8 +83,20 @@ def pretrain_step(st: TrainState, lr, hr):
     return {"l1": loss.item()}
 
 
-def gan_step(st: TrainState, lr, hr):
-    """train.py:194-259 with the defaults' branches kept selectable (gan_type, focal_loss); GP is off."""
+def gradient_penalty(D, hr, sr, u):
+    """train.py:216-226: 10 * mean((||dD(x_both)/dx_both||_2 - 1)^2) at x_both = hr*u + sr*(1-u), one u per sample; x_both is a
+    NEW leaf (the reference wraps it in a fresh Variable), so nothing flows back into G.  `u` ([B,1,1,1], uniform in [0,1) in the
+    reference) is an argument here so that runs can be reproduced.  The extra D forward updates the BatchNorm running stats."""
+    x_both = (hr * u + sr.detach() * (1 - u)).detach().requires_grad_(True)
+    out = D(x_both)
+    grad = torch.autograd.grad(outputs=out, inputs=x_both, grad_outputs=torch.ones_like(out), retain_graph=True, create_graph=True,
+                               only_inputs=True)[0]
+    return 10 * ((grad.norm(2, 1).norm(2, 1).norm(2, 1) - 1) ** 2).mean()
+
+
+def gan_step(st: TrainState, lr, hr, gp_u=None):
+    """train.py:194-259 with the defaults' branches kept selectable (gan_type, focal_loss, GP).  cfg["GP"] = True adds the
+    gradient penalty (train.py:216-226) with the interpolation weights gp_u."""
     c = st.cfg
     B = lr.size(0)
     target_real = torch.ones(B, 1)
@@ -103,6 +115,10 @@ def gan_step(st: TrainState, lr, hr):
             F.binary_cross_entropy_with_logits(pred_fake, target_fake)
     else:
         d_loss = F.binary_cross_entropy_with_logits(pred_real - pred_fake, target_real)
+    gp = None
+    if c.get("GP", False):
+        gp = gradient_penalty(st.D, hr, sr, gp_u)
+        d_loss = d_loss + gp
     d_loss.backward()
     st.optim_d.step()
 
@@ -127,7 +143,10 @@ def gan_step(st: TrainState, lr, hr):
     total = l1 + vgg + g_loss + tv
     total.backward()
     st.optim_g.step()
-    return {"l1": l1.item(), "vgg": vgg.item(), "g": g_loss.item(), "tv": tv.item(), "d": d_loss.item()}
+    out = {"l1": l1.item(), "vgg": vgg.item(), "g": g_loss.item(), "tv": tv.item(), "d": d_loss.item()}
+    if gp is not None:
+        out["gp"] = gp.item()
+    return out
 
 
 def step_lr(base_lr, epoch, lr_step, gamma=0.5):

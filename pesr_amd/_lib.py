@@ -57,6 +57,8 @@ SIGNATURES.update({
                                   _P]),
     "pesr_bn_lrelu_eval_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "pesr_bn_lrelu_eval_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_size_t, _P]),
+    "pesr_bn_bwd_bwd_workspace_bytes": (c_size_t, [c_long, c_int]),
+    "pesr_bn_bwd_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "pesr_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_long]),
     "pesr_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_long, c_int, c_float, _P, c_size_t, _P]),
     "pesr_linear_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_long, _P, c_size_t, _P]),

@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 4; }
+PESR_API int pesr_abi_version(void) { return 5; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -115,6 +115,13 @@ PESR_API int pesr_bn_lrelu_eval_bwd(const float* x, const float* dy, const float
                                     void* workspace, size_t ws_bytes, void* stream) {
     return pesr_bn_lrelu_bwd_eval_launch(x, dy, gamma, beta, mean_invstd, dx, dgamma, dbeta, (long)N * H * W, C, (long)H * W, slope,
                                          dy_nchw, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+PESR_API size_t pesr_bn_bwd_bwd_workspace_bytes(long M, int C) { return pesr_bn_bwd_bwd_ws_bytes(M, C); }
+PESR_API int pesr_bn_bwd_bwd(const float* z, const float* du, const float* g, const float* gamma, const float* mean_invstd, float* l_du,
+                             float* l_z, float* l_gamma, int N, int H, int W, int C, void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_bn_bwd_bwd_launch(z, du, g, gamma, mean_invstd, l_du, l_z, l_gamma, (long)N * H * W, C, workspace, ws_bytes,
+                                  (hipStream_t)stream);
 }
 
 PESR_API size_t pesr_linear_workspace_bytes(int M, int N, long K) { return pesr_linear_ws_bytes(M, N, K); }

@@ -255,3 +255,104 @@ int pesr_bn_lrelu_bwd_eval_launch(const float* x, const float* dy, const float* 
                        (f32x4*)dx, M, C, slope, HW, sn, sc, sp);
     return pesr_launch_status();
 }
+
+// ---- backward OF the training-mode BatchNorm backward (gradient penalty, reference train.py:216-226: the penalty is a function
+// of dD/dx, so its gradient needs d(dz)/d(du, z, gamma) of  dz = gamma * s * (du - mean(du) - xhat * mean(du * xhat)) ) -------------
+// With g = dL/d(dz) and the channel means m1 = mean(du), m2 = mean(du xhat), G1 = mean(g), Gx = mean(g xhat),
+// Ga = mean(g (du - m1)) (derivation checked against autograd in fp64, tests/test_entrypoints_cpu.py):
+//     L_du    = gamma s (g - G1 - xhat Gx)                      (the map du -> dz is self-adjoint)
+//     L_z     = -gamma s^2 [ xhat (Ga - 3 m2 Gx) + m2 (g - G1) + Gx (du - m1) ]
+//     L_gamma = s (sum(g du) - m1 sum(g) - m2 sum(g xhat))
+// pass 1: five per-channel sums {du, du xhat, g, g xhat, g du}, double accumulators, per-block partials; pass 2: elementwise.
+__global__ __launch_bounds__(256) void bn_bwd2_reduce_kernel(const float* __restrict__ z, const float* __restrict__ du,
+                                                             const float* __restrict__ g, const float* __restrict__ mean_invstd,
+                                                             float* __restrict__ part, long M, int C, long rows_per_block) {
+    const int C4 = C >> 2;
+    const int cw = C4 < 256 ? C4 : 256;
+    const int rl = 256 / cw;
+    const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    __shared__ f64x4 red[256];
+    for (int c0 = 0; c0 < C4; c0 += cw) {
+        f64x4 s[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s[k] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        const int c4 = c0 + tc;
+        if (tr < rl && c4 < C4) {
+            const f32x4 mu = ((const f32x4*)mean_invstd)[c4], is = ((const f32x4*)(mean_invstd + C))[c4];
+            for (long rr = r0 + tr; rr < r1; rr += rl) {
+                const f32x4 zv = ((const f32x4*)z)[rr * C4 + c4], dv = ((const f32x4*)du)[rr * C4 + c4], gv = ((const f32x4*)g)[rr * C4 + c4];
+                const f64x4 xh = __builtin_convertvector((zv - mu) * is, f64x4);
+                const f64x4 dd = __builtin_convertvector(dv, f64x4), gd = __builtin_convertvector(gv, f64x4);
+                s[0] += dd; s[1] += dd * xh; s[2] += gd; s[3] += gd * xh; s[4] += gd * dd;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {      // one LDS round per quantity keeps the buffer at 8 KiB
+            red[threadIdx.x] = s[k];
+            __syncthreads();
+            if (tr == 0 && c4 < C4) {
+                f64x4 t = s[k];
+                for (int q = 1; q < rl; ++q) t += red[q * cw + tc];
+                ((f32x4*)part)[((size_t)blockIdx.x * 5 + k) * C4 + c4] = __builtin_convertvector(t, f32x4);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void bn_bwd2_apply_kernel(const f32x4* __restrict__ z, const f32x4* __restrict__ du, const f32x4* __restrict__ g,
+                                     const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                     const double* __restrict__ dsum, f32x4* __restrict__ l_du, f32x4* __restrict__ l_z,
+                                     float* __restrict__ l_gamma, long M, int C) {
+    const int C4 = C >> 2;
+    const long total = M * C4;
+    const double invM = 1.0 / (double)M;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        const f32x4 mu = ((const f32x4*)mean_invstd)[c4], is = ((const f32x4*)(mean_invstd + C))[c4], ga = ((const f32x4*)gamma)[c4];
+        f32x4 m1, m2, G1, Gx, Ga;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c4 * 4 + k;
+            const double a = dsum[c] * invM, b = dsum[C + c] * invM, cc = dsum[2 * C + c] * invM, d = dsum[3 * C + c] * invM;
+            m1[k] = (float)a; m2[k] = (float)b; G1[k] = (float)cc; Gx[k] = (float)d;
+            Ga[k] = (float)(dsum[4 * C + c] * invM - cc * a);
+        }
+        const f32x4 xh = (z[e] - mu) * is, dv = du[e], gv = g[e];
+        if (l_du) l_du[e] = ga * is * (gv - G1 - xh * Gx);
+        if (l_z) l_z[e] = (0.f - ga) * is * is * (xh * (Ga - 3.0f * m2 * Gx) + m2 * (gv - G1) + Gx * (dv - m1));
+        if (l_gamma && e < C4) {      // the first C4 threads also emit L_gamma for their channels
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c4 * 4 + k;
+                const double a = dsum[c] * invM, b = dsum[C + c] * invM;
+                l_gamma[c] = (float)((double)mean_invstd[C + c] * (dsum[4 * C + c] - a * dsum[2 * C + c] - b * dsum[3 * C + c]));
+            }
+        }
+    }
+}
+
+size_t pesr_bn_bwd_bwd_ws_bytes(long M, int C) {
+    long nb, rpb; bn_grid(M, &nb, &rpb);
+    return (size_t)nb * 5 * C * sizeof(float) + 5 * (size_t)C * sizeof(double) + 512;
+}
+
+int pesr_bn_bwd_bwd_launch(const float* z, const float* du, const float* g, const float* gamma, const float* mean_invstd, float* l_du,
+                           float* l_z, float* l_gamma, long M, int C, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (C % 4) return PESR_EINVAL;
+    long nb, rpb; bn_grid(M, &nb, &rpb);
+    const size_t dsum_bytes = ((size_t)5 * C * sizeof(double) + 255) / 256 * 256;
+    if (!ws || ws_bytes < dsum_bytes + (size_t)nb * 5 * C * sizeof(float)) return PESR_EWORKSPACE;
+    double* dsum = (double*)ws;
+    float* part = (float*)((char*)ws + dsum_bytes);
+    hipLaunchKernelGGL(bn_bwd2_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, z, du, g, mean_invstd, part, M, C, rpb);
+    int rc0 = pesr_reduce_rows_launch(part, dsum, (int)nb, 5 * C, stream);
+    if (rc0) return rc0;
+    const long total = M * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bn_bwd2_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)z, (const f32x4*)du, (const f32x4*)g, mean_invstd,
+                       gamma, (const double*)dsum, (f32x4*)l_du, (f32x4*)l_z, l_gamma, M, C);
+    return pesr_launch_status();
+}

@@ -46,6 +46,10 @@ int pesr_bn_lrelu_bwd_eval_launch(const float* x, const float* dy, const float* 
                                   float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, void* ws,
                                   size_t ws_bytes, hipStream_t stream);
 
+size_t pesr_bn_bwd_bwd_ws_bytes(long M, int C);
+int pesr_bn_bwd_bwd_launch(const float* z, const float* du, const float* g, const float* gamma, const float* mean_invstd, float* l_du,
+                           float* l_z, float* l_gamma, long M, int C, void* ws, size_t ws_bytes, hipStream_t stream);
+
 size_t pesr_linear_ws_bytes(int M, int N, long K);
 int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float* y, int M, int N, long K, int act, float slope,
                            void* ws, size_t ws_bytes, hipStream_t stream);

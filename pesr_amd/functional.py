@@ -576,6 +576,184 @@ class ScaleAddFn(Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# Twice-differentiable building blocks of the Discriminator (gradient penalty, reference train.py:216-226:
+# torch.autograd.grad(D(x_both), x_both, create_graph=True) and then .backward() through that gradient).
+# Every first-order backward here is itself an autograd Function, so the graph of dD/dx exists; the second-order
+# rules are: conv dgrad <-> conv forward / wgrad, Linear likewise, LeakyReLU masks are piecewise constant, and the
+# training-mode BatchNorm backward has its own backward kernel (pesr_bn_bwd_bwd).  Un-fused on purpose: autograd has
+# to see z between conv and BatchNorm.  Used only for the penalty's extra D forward (Discriminator.forward_second_order).
+# ------------------------------------------------------------------------------------------------
+class Conv2Fn(Function):
+    """z = conv(x, w), no bias."""
+
+    @staticmethod
+    def forward(ctx, x, weight, cache, stride):
+        x = _c(x)
+        z = ops.conv3x3_fwd(x, lambda: cache.for_fwd(weight, x.shape, stride), None, weight.shape[0], stride, w_oihw=weight.detach())
+        ctx.cache, ctx.stride = cache, stride
+        ctx.save_for_backward(x, weight)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, weight = ctx.saved_tensors
+        gz = _c(gz)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ConvDgrad2Fn.apply(gz, weight, tuple(x.shape), ctx.cache, ctx.stride)
+        if ctx.needs_input_grad[1]:
+            xd, gd = x.detach(), gz.detach()
+            if x.shape[3] == 3:
+                dw, _ = ops.conv3x3_wgrad_rgb(gd, xd, 0, want_bias=False)
+            else:
+                dw, _ = ops.conv3x3_wgrad(xd, gd, ctx.stride, want_bias=False)
+        return dx, dw, None, None
+
+
+class ConvDgrad2Fn(Function):
+    """dx = conv_transpose(gz, w): the input gradient of Conv2Fn as a differentiable op.  Its backward for g = dL/d(dx):
+    dL/d(gz) = conv(g, w) (the forward conv), dL/dw = wgrad(x := g, dy := gz)."""
+
+    @staticmethod
+    def forward(ctx, gz, weight, x_shape, cache, stride):
+        gz = _c(gz)
+        dx = ops.conv3x3_dgrad(gz, cache.for_dgrad(weight, x_shape, stride), x_shape, stride)
+        ctx.cache, ctx.stride = cache, stride
+        ctx.save_for_backward(gz, weight)
+        return dx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        gz, weight = ctx.saved_tensors
+        g = _c(g)
+        l_gz = l_w = None
+        if ctx.needs_input_grad[0]:
+            l_gz = ops.conv3x3_fwd(g, lambda: ctx.cache.for_fwd(weight, g.shape, ctx.stride), None, weight.shape[0], ctx.stride,
+                                   w_oihw=weight.detach())
+        if ctx.needs_input_grad[1]:
+            if g.shape[3] == 3:
+                l_w, _ = ops.conv3x3_wgrad_rgb(gz, g, 0, want_bias=False)
+            else:
+                l_w, _ = ops.conv3x3_wgrad(g, gz, ctx.stride, want_bias=False)
+        return l_gz, l_w, None, None, None
+
+
+class Bn2Fn(Function):
+    """u = gamma * xhat(z) + beta with batch statistics (nn.BatchNorm2d in training mode, running stats updated)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, num_batches, eps, momentum):
+        z = _c(z)
+        u, stats = ops.bn_lrelu_fwd(z, gamma.detach(), beta.detach(), running_mean, running_var, num_batches, eps, momentum, 1.0, False)
+        ctx.save_for_backward(z, gamma, stats)
+        return u
+
+    @staticmethod
+    def backward(ctx, gu):
+        z, gamma, stats = ctx.saved_tensors
+        gu = _c(gu)
+        dz = dgamma = dbeta = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dz_plain, dgamma, dbeta = ops.bn_lrelu_bwd(z.detach(), gu.detach(), gamma.detach(), gamma.detach(), stats, 1.0, False, True)
+        if ctx.needs_input_grad[0]:
+            dz = BnBwd2Fn.apply(gu, z, gamma, stats)
+        return dz, dgamma, dbeta, None, None, None, None, None
+
+
+class BnBwd2Fn(Function):
+    """dz = gamma * invstd * (du - mean(du) - xhat * mean(du * xhat)): the training-mode BatchNorm backward as a differentiable
+    op (in du, z AND gamma: xhat and invstd depend on z)."""
+
+    @staticmethod
+    def forward(ctx, du, z, gamma, stats):
+        du = _c(du)
+        dz, _, _ = ops.bn_lrelu_bwd(z.detach(), du, gamma.detach(), gamma.detach(), stats, 1.0, False, False)
+        ctx.save_for_backward(du, z, gamma, stats)
+        return dz
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        du, z, gamma, stats = ctx.saved_tensors
+        l_du, l_z, l_ga = ops.bn_bwd_bwd(z, du, _c(g), gamma, stats, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return l_du, l_z, l_ga, None
+
+
+class LRelu2Fn(Function):
+    """y = leaky_relu(u); its backward is the (differentiable) mask multiply."""
+
+    @staticmethod
+    def forward(ctx, u, slope):
+        u = _c(u)
+        y = ops.relu_mask(u, u, slope=slope)
+        ctx.slope = slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return MaskMul2Fn.apply(gy, y, ctx.slope), None
+
+
+class MaskMul2Fn(Function):
+    """out = gy where ref > 0, slope * gy elsewhere: linear in gy, piecewise constant in ref."""
+
+    @staticmethod
+    def forward(ctx, gy, ref, slope):
+        ctx.slope = slope
+        ctx.save_for_backward(ref)
+        return ops.relu_mask(_c(gy), ref, slope=slope)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (ref,) = ctx.saved_tensors
+        return ops.relu_mask(_c(g), ref, slope=ctx.slope), None, None
+
+
+class Linear2Fn(Function):
+    """y = x W^T + b."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _c(x)
+        ctx.save_for_backward(x, weight)
+        return ops.linear_fwd(x, weight.detach(), bias.detach(), ops.ACT_NONE, 0.0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _c(gy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = LinDgrad2Fn.apply(gy, weight)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw, db = ops.linear_wgrad(gy.detach(), x.detach(), want_bias=True)
+        return dx, dw, db
+
+
+class LinDgrad2Fn(Function):
+    """dx = gy W; backward for g = dL/d(dx): dL/d(gy) = g W^T, dL/dW = gy^T g."""
+
+    @staticmethod
+    def forward(ctx, gy, weight):
+        gy = _c(gy)
+        ctx.save_for_backward(gy, weight)
+        return ops.linear_dgrad(gy, weight.detach())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        gy, weight = ctx.saved_tensors
+        g = _c(g)
+        l_gy = ops.linear_fwd(g, weight.detach(), None, ops.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        l_w = ops.linear_wgrad(gy, g, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+        return l_gy, l_w
+
+
+# ------------------------------------------------------------------------------------------------
 # Linear (+LeakyReLU)                                          reference model/pesr.py:69-74
 # ------------------------------------------------------------------------------------------------
 class LinearFn(Function):

@@ -70,3 +70,22 @@ class Discriminator(nn.Module):
         fc1, act, fc2 = self.classifier
         hidden = PF.LinearFn.apply(flat, fc1.weight, fc1.bias, ops.ACT_LRELU, act.negative_slope)
         return PF.LinearFn.apply(hidden, fc2.weight, fc2.bias, ops.ACT_NONE, 0.0)
+
+
+def _forward_second_order(self, x):
+    """D(x) through twice-differentiable, un-fused functions (pesr_amd.functional *2Fn): the extra forward of the gradient
+    penalty (reference train.py:216-226), whose result goes into torch.autograd.grad(..., create_graph=True).  Same values as
+    forward() up to fp32 rounding; BatchNorm runs in training mode and updates its running statistics like any other call."""
+    h = nhwc(x)
+    for blk in self.features:
+        conv, bn, act = blk[0], blk[1], blk[2]
+        z = PF.Conv2Fn.apply(h, conv.weight, conv.packed, conv.stride)
+        u = PF.Bn2Fn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum)
+        h = PF.LRelu2Fn.apply(u, float(act.negative_slope))
+    flat = nchw(h).contiguous().view(h.size(0), -1)          # NCHW flatten (reference model/pesr.py:79)
+    fc1, act, fc2 = self.classifier
+    hidden = PF.LRelu2Fn.apply(PF.Linear2Fn.apply(flat, fc1.weight, fc1.bias), float(act.negative_slope))
+    return PF.Linear2Fn.apply(hidden, fc2.weight, fc2.bias)
+
+
+Discriminator.forward_second_order = _forward_second_order

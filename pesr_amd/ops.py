@@ -438,6 +438,21 @@ def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param
     return dx, dgamma, dbeta
 
 
+def bn_bwd_bwd(z, du, g, gamma, stats, need_du=True, need_z=True, need_gamma=True):
+    """Backward of the training-mode BatchNorm backward (pesr_bn_bwd_bwd): (dL/d(du), dL/dz, dL/dgamma) for g = dL/d(dz)."""
+    for t, n in ((z, "z"), (du, "du"), (g, "g")):
+        _chk(t, "bn_bwd_bwd." + n)
+    N, H, W, C = z.shape
+    L = _lib.lib()
+    ws = workspace(L.pesr_bn_bwd_bwd_workspace_bytes(N * H * W, C), z.device)
+    l_du = torch.empty_like(z) if need_du else None
+    l_z = torch.empty_like(z) if need_z else None
+    l_ga = torch.empty((C,), dtype=torch.float32, device=z.device) if need_gamma else None
+    rc = L.pesr_bn_bwd_bwd(_p(z), _p(du), _p(g), _p(gamma), _p(stats), _p(l_du), _p(l_z), _p(l_ga), N, H, W, C, _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "pesr_bn_bwd_bwd")
+    return l_du, l_z, l_ga
+
+
 def bn_eval_stats(running_mean, running_var, eps=1e-5):
     """[2, C] {mean, invstd} of an eval-mode BatchNorm2d from its running statistics (C-sized torch glue)."""
     return torch.stack([running_mean.float(), torch.rsqrt(running_var.float() + eps)]).contiguous()

@@ -26,13 +26,14 @@ def _img(x: torch.Tensor) -> torch.Tensor:
 
 class Trainer:
     def __init__(self, G, D=None, vgg=None, optim_G=None, optim_D=None, *, gan_type="RSGAN", focal_loss=True, fl_gamma=1.0,
-                 alpha_vgg=50.0, alpha_gan=1.0, alpha_tv=1e-6, alpha_l1=0.0, world_size=1):
+                 alpha_vgg=50.0, alpha_gan=1.0, alpha_tv=1e-6, alpha_l1=0.0, world_size=1, gradient_penalty=False):
         self.G, self.D, self.vgg = G, D, vgg
         self.optim_G, self.optim_D = optim_G, optim_D
         self.gan_type, self.use_focal = gan_type, focal_loss
         self.f_loss_fn = FocalLoss(fl_gamma)
         self.alpha_vgg, self.alpha_gan, self.alpha_tv, self.alpha_l1 = alpha_vgg, alpha_gan, alpha_tv, alpha_l1
         self.world_size = world_size
+        self.gradient_penalty = gradient_penalty       # reference --GP (train.py:216-226), default off
         self._targets = {}
 
     def _target(self, batch, value, device):
@@ -51,7 +52,20 @@ class Trainer:
         return {"l1": loss.detach()}
 
     # ---- reference train.py:194-259 -----------------------------------------------------------------
-    def gan_step(self, lr, hr):
+    def _gradient_penalty(self, hr_cl, sr, u):
+        """10 * mean((||dD(x_both)/dx_both||_2 - 1)^2), x_both = hr*u + sr*(1-u) a NEW leaf (reference train.py:216-226).  The
+        interpolation, the three norms and the square are torch ops on [B,3,H,W] / [B] tensors; everything inside D and its
+        first- and second-order backward runs on the HIP kernels (Discriminator.forward_second_order)."""
+        B = hr_cl.size(0)
+        if u is None:
+            u = torch.rand(B, 1, 1, 1, device=hr_cl.device)
+        x_both = (hr_cl * u + sr.detach() * (1 - u)).detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        out = self.D.forward_second_order(x_both)
+        grad = torch.autograd.grad(outputs=out, inputs=x_both, grad_outputs=torch.ones_like(out), retain_graph=True,
+                                   create_graph=True, only_inputs=True)[0]
+        return 10 * ((grad.norm(2, 1).norm(2, 1).norm(2, 1) - 1) ** 2).mean()
+
+    def gan_step(self, lr, hr, gp_u=None):
         G, D = self.G, self.D
         B, dev = lr.size(0), lr.device
         target_real, target_fake = self._target(B, 1.0, dev), self._target(B, 0.0, dev)
@@ -71,6 +85,10 @@ class Trainer:
             total_D_loss = F.binary_cross_entropy_with_logits(pred_real - pred_fake, target_real)
         else:
             raise ValueError(f"unknown gan_type {self.gan_type}")
+        gp = None
+        if self.gradient_penalty:
+            gp = self._gradient_penalty(hr_cl, sr, gp_u)
+            total_D_loss = total_D_loss + gp
         total_D_loss.backward()
 
         # The generator-phase terms that need neither the updated D nor its gradients (reference train.py:238-242) run
@@ -99,5 +117,8 @@ class Trainer:
         total_G_loss = l1_loss + vgg_loss + G_loss + tv_local * float(self.world_size)
         total_G_loss.backward()
         self.optim_G.step()
-        return {"l1": l1_loss.detach(), "vgg": vgg_loss.detach(), "g": G_loss.detach(), "tv": tv_local.detach(),
+        logs = {"l1": l1_loss.detach(), "vgg": vgg_loss.detach(), "g": G_loss.detach(), "tv": tv_local.detach(),
                 "d": total_D_loss.detach()}
+        if gp is not None:
+            logs["gp"] = gp.detach()
+        return logs

@@ -218,6 +218,39 @@ def main():
         arrs["D.val." + k] = v[gi]
     save("gv8_gan_steps_small", **arrs)
 
+    # ---- GV11: one GAN step WITH gradient penalty (train.py:216-226) at the small config, reference modules ----------
+    opt = {"patch_size": 8, "num_channels": 16, "depth": 2, "res_scale": 0.1, "spectral_norm": False}
+    G = load_det(R.Generator(opt), seed=0)
+    D = load_det(R.Discriminator(opt), seed=1)
+    oD = torch.optim.Adam(D.parameters(), betas=(0.9, 0.999), lr=5e-5)
+    lr = detrand.image_batch((4, 3, 8, 8), 100)
+    hr = detrand.image_batch((4, 3, 32, 32), 200)
+    u = detrand.uniform((4, 1, 1, 1), 77, 0.0, 1.0)
+    ones = torch.ones(4, 1)
+    oD.zero_grad()
+    pr = D(hr)
+    sr = G(lr)
+    pf = D(sr.detach())
+    dl = F.binary_cross_entropy_with_logits(pr - pf, ones)
+    x_both = (hr * u + sr * (1 - u)).detach().requires_grad_(True)          # Variable(x_both, requires_grad=True): a new leaf
+    grad = torch.autograd.grad(outputs=D(x_both), inputs=x_both, grad_outputs=torch.ones(4, 1), retain_graph=True,
+                               create_graph=True, only_inputs=True)[0]
+    gp = 10 * ((grad.norm(2, 1).norm(2, 1).norm(2, 1) - 1) ** 2).mean()
+    tot = dl + gp
+    tot.backward()
+    gi = sample_idx(grad.numel(), 2048, 9)
+    arrs = {"d_loss": dl, "gp": gp, "total": tot, "gx_idx": gi, "gx_val": grad.detach().reshape(-1)[gi], "gx_max": grad.abs().max()}
+    for k, p in D.named_parameters():
+        g_ = p.grad.reshape(-1)
+        gi = sample_idx(g_.numel(), 1024, 5)
+        arrs["gidx." + k], arrs["gval." + k], arrs["gmax." + k] = gi, g_[gi], g_.abs().max()
+    oD.step()
+    for k, v in D.state_dict().items():
+        v = v.reshape(-1).float()
+        gi = sample_idx(v.numel(), 256, 3)
+        arrs["pidx." + k], arrs["pval." + k] = gi, v[gi]
+    save("gv11_gradient_penalty_small", **arrs)
+
     # ---- GV9: utils known answers ------------------------------------------------------------------------
     a = detrand.image_batch((1, 3, 16, 20), 41)
     b = (a + detrand.uniform((1, 3, 16, 20), 42, -20, 20))

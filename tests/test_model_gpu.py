@@ -379,3 +379,57 @@ def test_res_block_constructor_branches(bias, bn, act):
         if bn and k.endswith("bias") and k[0] in "03" and pr.dim() == 1 and pr.shape[0] == 64 and "0.bias" == k or (bn and k == "3.bias"):
             continue                               # conv biases in front of training-mode BN: exactly-zero gradients
         close(pg.grad, pr.grad, 1e-4, what="grad " + k)
+
+
+def test_discriminator_second_order_forward_equals_forward():
+    """Discriminator.forward_second_order (un-fused, twice differentiable) computes the same D(x) and the same first-order
+    gradients as the fused forward."""
+    from model import Discriminator
+    sd = dis_sd(8)
+    outs = []
+    for second in (False, True):
+        D = Discriminator({"patch_size": 8, "spectral_norm": False}); D.load_state_dict(sd); D = D.cuda()
+        x = detrand.image_batch((4, 3, 32, 32), 21).cuda().requires_grad_(True)
+        o = D.forward_second_order(x) if second else D(x)
+        o.sum().backward()
+        outs.append((o.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in D.named_parameters()}))
+    close(outs[1][0], outs[0][0], 1e-5, what="D(x)")
+    close(outs[1][1], outs[0][1], 2e-4, what="dD/dx")
+    for k in outs[0][2]:
+        if k != "classifier.2.bias":
+            close(outs[1][2][k], outs[0][2][k], 2e-4, what="grad " + k)
+
+
+def test_gv11_gradient_penalty_step_vs_reference():
+    """--GP true (reference train.py:216-226): one D-phase with the gradient penalty - torch.autograd.grad(D(x_both), x_both,
+    create_graph=True) and the backward THROUGH that gradient, all inside D on the HIP kernels - against the run made with the
+    reference's own modules: total D loss, the penalty, dD/dx, D's gradients, post-Adam parameters."""
+    g = load_golden("gv11_gradient_penalty_small")
+    tr, G, D = _trainer(16, 2, 8)
+    tr.gradient_penalty = True
+    lr = detrand.image_batch((4, 3, 8, 8), 100).cuda()
+    hr = detrand.image_batch((4, 3, 32, 32), 200).cuda()
+    u = detrand.uniform((4, 1, 1, 1), 77, 0.0, 1.0).cuda()
+    # dD/dx at the interpolate, on its own
+    sr = G(lr).detach()
+    hr_cl = hr.contiguous(memory_format=torch.channels_last)
+    x_both = (hr_cl * u + sr * (1 - u)).detach().requires_grad_(True)
+    import copy
+    D2 = copy.deepcopy(D)
+    gx = torch.autograd.grad(D2.forward_second_order(x_both).sum(), x_both)[0]
+    close(gx.contiguous().reshape(-1)[torch.from_numpy(g["gx_idx"]).cuda()], g["gx_val"], 0.0, 5e-4 * float(g["gx_max"]), "dD/dx_both")
+    log = tr.gan_step(lr, hr, gp_u=u)
+    close(log["gp"], g["gp"], 2e-3, what="gradient penalty")
+    close(log["d"], g["total"], 2e-3, what="total D loss")
+    worst = 0.0
+    for k, p in D.named_parameters():
+        got = p.grad.reshape(-1)[torch.from_numpy(g["gidx." + k]).cuda()].double().cpu().numpy()
+        err = np.abs(got - g["gval." + k]).max() / (float(g["gmax." + k]) + 1e-30)
+        worst = max(worst, err)
+        assert err <= 2e-2, f"grad {k}: {err:.2e} of the maximum"
+    print(f"worst D gradient error with the penalty: {worst:.2e} of a tensor's maximum")
+    for k, v in D.state_dict().items():
+        if "num_batches" in k:
+            assert int(v) == 5
+        elif "running" not in k:
+            adam_close(v.reshape(-1)[torch.from_numpy(g["pidx." + k]).cuda()], g["pval." + k], 5e-5, 1, "D." + k)

@@ -207,3 +207,24 @@ def test_psnr_on_device_bit_identical():
     assert U.compute_PSNR(a.cuda(), b.cuda()) == ref                                                       # NCHW-contiguous
     assert U.compute_PSNR(a.cuda().contiguous(memory_format=torch.channels_last), b.cuda()) == ref         # mixed layouts
     assert abs(U.compute_PSNR(a, b) - ref) < 1e-12                                                         # host path
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 8, 5, 7), (4, 64, 12, 12), (3, 512, 2, 2)])
+def test_bn_backward_of_backward(N, C, H, W):
+    """pesr_bn_bwd_bwd (the gradient penalty's BatchNorm second-order rule) against autograd through the training-mode
+    BatchNorm backward formula in float64 on the CPU."""
+    from pesr_amd import ops
+    z = _rand(N, C, H, W, seed=1, lo=-2, hi=2); du = _rand(N, C, H, W, seed=2); g = _rand(N, C, H, W, seed=3)
+    gamma = _rand(C, seed=4, lo=0.5, hi=1.5)
+    zd, dud, gd, gad = (t.double() for t in (z, du, g, gamma))
+    zd.requires_grad_(True); dud.requires_grad_(True); gad.requires_grad_(True)
+    mu = zd.mean((0, 2, 3), keepdim=True); var = zd.var((0, 2, 3), unbiased=False, keepdim=True)
+    s = (var + 1e-5).rsqrt(); xh = (zd - mu) * s
+    dz = gad.view(1, C, 1, 1) * s * (dud - dud.mean((0, 2, 3), keepdim=True) - xh * (dud * xh).mean((0, 2, 3), keepdim=True))
+    l_du, l_z, l_ga = torch.autograd.grad((dz * gd).sum(), [dud, zd, gad])
+    # the GPU side gets the statistics the forward kernel saved
+    y, stats = ops.bn_lrelu_fwd(_nhwc(z), gamma.cuda(), torch.zeros(C).cuda(), None, None, None, 1e-5, 0.1, 1.0)
+    dz_gpu, _, _ = ops.bn_lrelu_bwd(_nhwc(z), _nhwc(du), gamma.cuda(), gamma.cuda(), stats, 1.0, False, False)
+    _close(_nchw(dz_gpu), dz.detach().float(), 2e-5, "dz (first-order backward, slope 1)")
+    a, b, c = ops.bn_bwd_bwd(_nhwc(z), _nhwc(du), _nhwc(g), gamma.cuda(), stats)
+    _close(_nchw(a), l_du.float(), 2e-5, "dL/d(du)"); _close(_nchw(b), l_z.float(), 5e-5, "dL/dz"); _close(c.cpu(), l_ga.float(), 5e-5, "dL/dgamma")

@@ -202,3 +202,29 @@ def test_step_lr_schedule(epoch, expect):
     `scheduler.step()` at the start of epoch e (train.py:156,185-186) sets last_epoch = e-1: the first halving is epoch
     lr_step + 1 = 121."""
     assert OS.step_lr(5e-5, epoch, 120) == pytest.approx(expect)
+
+
+def test_gv11_gradient_penalty_step():
+    """The oracle's gradient-penalty branch (reference train.py:216-226, double backward through D) against the reference's own
+    modules: D loss, penalty, dD/dx at the interpolate, D's gradients and post-Adam parameters."""
+    g = load("gv11_gradient_penalty_small")
+    cfg = {"depth": 2, "res_scale": 0.1, "learning_rate": 5e-5, "GP": True}
+    st = OS.TrainState(gen_sd(16, 2), dis_sd(8), vgg_sd(), cfg)
+    lr = detrand.image_batch((4, 3, 8, 8), 100)
+    hr = detrand.image_batch((4, 3, 32, 32), 200)
+    u = detrand.uniform((4, 1, 1, 1), 77, 0.0, 1.0)
+    log = OS.gan_step(st, lr, hr, gp_u=u)
+    close(log["gp"], g["gp"], 2e-5); close(log["d"], g["total"], 2e-5)
+    n = 0
+    for k, v in st.d.items():
+        if ("gidx." + k) in g.files:
+            close(v.grad.reshape(-1)[g["gidx." + k]], g["gval." + k], 0.0, atol=2e-5 * float(g["gmax." + k]) + 1e-12)
+            n += 1
+    assert n == 28
+    for k, v in st.d.items():
+        if "num_batches" in k:
+            assert int(g["pval." + k][0]) == 3 and int(v) == 5    # hr, sr, x_both in the D phase (golden) + sr, hr in the G phase
+        elif "running" in k:
+            continue                                              # (the golden was taken before the G phase's two D forwards)
+        else:
+            close(v.detach().reshape(-1)[g["pidx." + k]], g["pval." + k], 1e-5)

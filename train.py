@@ -175,8 +175,6 @@ def check_limits(args, world):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if args.GP:
-        raise NotImplementedError("--GP true needs double-backward through the conv kernels (not built; reference default is false)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -219,7 +217,7 @@ def main(argv=None):
     scheduler_D = lr_scheduler.StepLR(optim_D, step_size=args.lr_step, gamma=0.5) if gan else None
     trainer = Trainer(G, D, vgg, optim_G, optim_D, gan_type=args.gan_type, focal_loss=args.focal_loss, fl_gamma=args.fl_gamma,
                       alpha_vgg=args.alpha_vgg, alpha_gan=args.alpha_gan, alpha_tv=args.alpha_tv, alpha_l1=args.alpha_l1,
-                      world_size=world)
+                      world_size=world, gradient_penalty=args.GP)
 
     check_point = os.path.join(args.check_point, args.phase)
     tb = None
