@@ -419,14 +419,14 @@ def test_gv11_gradient_penalty_step_vs_reference():
     gx = torch.autograd.grad(D2.forward_second_order(x_both).sum(), x_both)[0]
     close(gx.contiguous().reshape(-1)[torch.from_numpy(g["gx_idx"]).cuda()], g["gx_val"], 0.0, 5e-4 * float(g["gx_max"]), "dD/dx_both")
     log = tr.gan_step(lr, hr, gp_u=u)
-    close(log["gp"], g["gp"], 2e-3, what="gradient penalty")
-    close(log["d"], g["total"], 2e-3, what="total D loss")
+    close(log["gp"], g["gp"], 5e-5, what="gradient penalty")
+    close(log["d"], g["total"], 5e-5, what="total D loss")
     worst = 0.0
     for k, p in D.named_parameters():
         got = p.grad.reshape(-1)[torch.from_numpy(g["gidx." + k]).cuda()].double().cpu().numpy()
         err = np.abs(got - g["gval." + k]).max() / (float(g["gmax." + k]) + 1e-30)
         worst = max(worst, err)
-        assert err <= 2e-2, f"grad {k}: {err:.2e} of the maximum"
+        assert err <= 1e-4, f"grad {k}: {err:.2e} of the maximum"         # measured: 6e-6
     print(f"worst D gradient error with the penalty: {worst:.2e} of a tensor's maximum")
     for k, v in D.state_dict().items():
         if "num_batches" in k:
