@@ -50,9 +50,15 @@ struct Wino4Args {
     float* slab;
 };
 
-constexpr int W4_NT = 512, W4_BN = 64, W4_MG = 9;
+constexpr int W4_BN = 64, W4_MG = 9;
 
-__global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a) {
+// Wave w owns the 16 channels w & 3 and HALF of the xi planes (w >> 2: xi 0..2 / 3..5): 27 accumulator tiles, 2 waves per SIMD.
+// (A 12-wave variant - a third of the xi planes per wave, 3 waves per SIMD in the 168-VGPR budget - measured 2 % slower.)
+__global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
+    constexpr int NT = 512;                                // threads of the workgroup
+    constexpr int NXL = 3;                                 // xi planes per wave
+    constexpr int NSLAB = 3 * NXL;                         // weight slabs per wave and chunk: (ky, xl)
+    constexpr int NU = 2;                                  // staging items per thread (HT * TXT * 4 <= NU * NT)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int plane = a.TXT * 64;                          // bytes of one xi plane of a V row
     const int v_row = 6 * plane;
@@ -60,7 +66,9 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int cb = wave & 3, xh = wave >> 2;
+    const int cb = wave & 3, xt = wave >> 2;               // channel block, xi group
+    // xi plane of this wave's local index xl
+    auto xi_of = [&](int xl) -> int { return xt * 3 + xl; };
 
     // blockIdx -> (split-K slice, pixel tile, n-tile).  Workgroups b and b + 8 share an XCD (round-robin dispatch): give every
     // XCD a contiguous range of logical tiles, n-tile fastest, so the n_tiles workgroups that read the same pixels share an L2.
@@ -87,114 +95,109 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
         const int trow = m / a.TXT, txt = m - trow * a.TXT;
         a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
     }
-#ifdef W4_ABL_ACONF   // timing-only: every lane reads the same address (broadcast: no bank conflict possible)
-#pragma unroll
-    for (int i = 0; i < W4_MG; ++i) a_off[i] = (a.slope == 12345.f) ? a_off[i] : i * 64;
-#endif
     const int kxor = a.row_key * 16;                       // the key's row term flips with the parity of ky
 
-    // ---- B: this lane's 16 bytes of slab (ky, xi, chunk) ---------------------------------------------------------------------
-    // (wave-uniform slab base in SGPRs + one per-lane 32-bit byte offset: no 64-bit address VGPRs)
+    // ---- B: this lane's 16 bytes of slab (ky, xi, chunk): wave-uniform slab base (SGPRs) + one per-lane 32-bit byte offset ----
     const size_t slab_stride = (size_t)a.Cout * 16;        // floats between consecutive chunks of one (ky, xi)
     const unsigned b_lane = (unsigned)(((n0 + cb * 16 + r) * 16 + g * 4) * 4);
     auto ldb = [&](int ky, int xl, int cc) -> f32x4 {      // cc = absolute chunk
-        const char* const base = (const char*)(a.wp + ((size_t)((ky * 6 + xh * 3 + xl) * C16T + cc)) * slab_stride);
+        const char* const base = (const char*)(a.wp + ((size_t)((ky * 6 + xi_of(xl)) * C16T + cc)) * slab_stride);
         return *(const f32x4*)(base + b_lane);
     };
 
-    // ---- staging items: (halo row, x-tile, 4-channel group); six input columns each; at most 2 items per thread -------------
+    // ---- staging items: (halo row, x-tile, 4-channel group); six input columns each; NU items per thread --------------------
     const float* const x_img = a.x + (size_t)img * a.H * a.W * a.Cin;
     const int n_items = a.HT * a.TXT * 4;
     const int Cq = a.Cin >> 2;
-    unsigned st_off[2][6], st_mask[2];                     // byte offsets inside the image (< 4 GB per image)
-    int st_dst[2];
+    // Out-of-image columns (and whole halo rows) are fetched at offset 2^31, beyond the buffer descriptor's range: the load
+    // returns zeros, no masking afterwards.  (Raw buffer: the range check is on the VGPR offset; images are < 2 GB - w4_plan.)
+    unsigned st_off[NU][6];                                // byte offsets inside the image
+    int st_dst[NU];                                        // < 0: the item does not exist
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int it = tid + u * W4_NT;
+    for (int u = 0; u < NU; ++u) {
+        const int it = tid + u * NT;
         const int q = it & 3, rest = it >> 2;
         const int hrow = rest / a.TXT, txt = rest - hrow * a.TXT;
         const int iy = gy0 - 1 + hrow, ix0 = 4 * (gt0 + txt) - 1;
         const bool item_ok = it < n_items && iy >= 0 && iy < a.H;
-        unsigned mk = 0;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int ix = ix0 + j;
             const bool ok = item_ok && ix >= 0 && ix < a.W;
-            mk |= ok ? (1u << j) : 0u;
             const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
-            st_off[u][j] = (unsigned)((ok ? pix + q * 4 : q * 4) * 4);   // an out-of-image column reads a dummy in-range address, zeroed later
+            st_off[u][j] = ok ? (unsigned)((pix + q * 4) * 4) : 0x80000000u;
         }
-        st_mask[u] = it < n_items ? (mk | 0x100u) : 0u;    // bit 8: the item exists (its V entries must be written, zeros included)
-        st_dst[u] = hrow * v_row + txt * 64 + ((q ^ (txt >> 1) ^ (a.row_key * (hrow & 1))) & 3) * 16;
+        st_dst[u] = it < n_items ? hrow * v_row + txt * 64 + ((q ^ (txt >> 1) ^ (a.row_key * (hrow & 1))) & 3) * 16 : -1;
     }
-    auto chunk_off = [&](int cc) -> int {                  // channel part of an input address (floats), chunk cc (absolute)
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)x_img, 0, (unsigned)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+    auto chunk_off = [&](int cc) -> int {                  // channel part of an input address (bytes), chunk cc (absolute)
         int coff = cc * 16;
         if (a.ps_in) {   // chunk = channels [16cc, 16cc+16) of sub-pixel `sub`: one pixel of the shuffled tensor
             const int sub = coff / Cq, cc0 = coff - sub * Cq;
             coff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * Cq + cc0;
         }
-        return coff;
+        return coff * 4;
     };
-    // The two items go through the SAME six staging registers one after the other (24 VGPRs instead of 48): item 0 is loaded
+    // The two items of a thread go through the SAME six staging registers one after the other: item 0 is loaded
     // at the top of a chunk and stored a third in, item 1 is loaded right there and stored two thirds in.
-    f32x4 sx[6];
+    u32x4 sx[6];
     auto stage_load = [&](int u, int cc) {
-#ifdef W4_ABL_LOADS     // timing-only: no staging loads (the stores transform stale registers)
-        if (a.slope != 12345.f && cc != CB) return;
-#endif
-        const char* const xc = (const char*)(x_img + chunk_off(cc));
+        const int so = __builtin_amdgcn_readfirstlane(chunk_off(cc));
 #pragma unroll
-        for (int j = 0; j < 6; ++j) sx[j] = *(const f32x4*)(xc + st_off[u][j]);
+        for (int j = 0; j < 6; ++j) sx[j] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_off[u][j], so, 0);
     };
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto stage_store = [&](int u, char* vdst) {
-#ifdef W4_ABL_STORES    // timing-only: loads stay (kept alive), no transform / ds_write
-        if (a.slope != 12345.f && vdst != smem) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(sx[j]));
-            return;
-        }
-#endif
-        if (st_mask[u]) {
-            const unsigned mk = st_mask[u];
-            const f32x4 d0 = (mk & 1u) ? sx[0] : zero4, d1 = (mk & 2u) ? sx[1] : zero4, d2 = (mk & 4u) ? sx[2] : zero4,
-                        d3 = (mk & 8u) ? sx[3] : zero4, d4 = (mk & 16u) ? sx[4] : zero4, d5 = (mk & 32u) ? sx[5] : zero4;
-            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
+        if (st_dst[u] >= 0) {
+            const f32x4 d0 = __builtin_bit_cast(f32x4, sx[0]), d1 = __builtin_bit_cast(f32x4, sx[1]),
+                        d2 = __builtin_bit_cast(f32x4, sx[2]), d3 = __builtin_bit_cast(f32x4, sx[3]),
+                        d4 = __builtin_bit_cast(f32x4, sx[4]), d5 = __builtin_bit_cast(f32x4, sx[5]);
             char* p = vdst + st_dst[u];
             *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
+            *(f32x4*)(p + 5 * plane) = 4.0f * d1 + (d5 - 5.0f * d3);
+            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1;
             *(f32x4*)(p + plane) = t1 + t2;
             *(f32x4*)(p + 2 * plane) = t1 - t2;
+            const f32x4 t3 = d4 - d2, t4 = d3 - d1;
             *(f32x4*)(p + 3 * plane) = t3 + 2.0f * t4;
             *(f32x4*)(p + 4 * plane) = t3 - 2.0f * t4;
-            *(f32x4*)(p + 5 * plane) = 4.0f * d1 + (d5 - 5.0f * d3);
         }
     };
 
-    f32x4 acc[3][W4_MG];
+    f32x4 acc[NXL][W4_MG];
 #pragma unroll
-    for (int xl = 0; xl < 3; ++xl)
+    for (int xl = 0; xl < NXL; ++xl)
 #pragma unroll
         for (int i = 0; i < W4_MG; ++i) acc[xl][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 fa[2][3], fb[3];
+    // the xor of the odd-ky reads is redone at every use: hoisted out of the loop it would cost nine more live registers
+    auto opaque = [](int v) -> int { asm volatile("" : "+s"(v)); return v; };
 #define W4_READ_A(FA, VB, KY, XL, GRP)                                                                   \
     {                                                                                                    \
-        const char* const vb_ = (VB) + (KY) * v_row + (xh * 3 + (XL)) * plane;                           \
+        const char* const vb_ = (VB) + (KY) * v_row + xi_of(XL) * plane;                                 \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
-            FA[i] = *(const f32x4*)(vb_ + (a_off[(GRP) * 3 + i] ^ (((KY) & 1) ? kxor : 0)));             \
+            FA[i] = *(const f32x4*)(vb_ + (((KY) & 1) ? (a_off[(GRP) * 3 + i] ^ opaque(kxor)) : a_off[(GRP) * 3 + i])); \
     }
 #define W4_MFMA(FA, FB, XL, GRP)                                                                         \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
-            acc[XL][(GRP) * 3 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[i][kk], FB[kk], acc[XL][(GRP) * 3 + i], 0, 0, 0);
+            acc[XL][(GRP) * 3 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(FB[kk], FA[i][kk], acc[XL][(GRP) * 3 + i], 0, 0, 0);
 
     // ---- prologue: chunk CB staged synchronously, the first two weight slabs -------------------------------------------------
-    stage_load(0, CB);
-    fb[0] = ldb(0, 0, CB);
-    fb[1] = ldb(0, 1, CB);
-    stage_store(0, smem);
-    stage_load(1, CB);
-    stage_store(1, smem);
+    {
+        u32x4 sy[6];                                       // item 1 in registers of its own here: one load latency, not two
+        const int so = __builtin_amdgcn_readfirstlane(chunk_off(CB));
+        stage_load(0, CB);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sy[j] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_off[1][j], so, 0);
+        fb[0] = ldb(0, 0, CB);
+        fb[1] = ldb(0, 1, CB);
+        stage_store(0, smem);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sx[j] = sy[j];
+        stage_store(1, smem);
+    }
     __syncthreads();
 
 #pragma unroll 1
@@ -209,106 +212,79 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
         if (more) stage_load(0, CB + c + 1);               // lands while this chunk computes
         W4_READ_A(fa[0], vcur, 0, 0, 0)
 #pragma unroll
-        for (int s = 0; s < 9; ++s) {                      // slab s = (ky, xl)
-            const int ky = s / 3, xl = s - ky * 3;
+        for (int s = 0; s < NSLAB; ++s) {                  // slab s = (ky, xl)
+            const int ky = s / NXL, xl = s - ky * NXL;
             // weight slab s + 2 (of this chunk, or the first ones of the next)
 #ifdef W4_ABL_B
             if (a.slope == 12345.f)
 #endif
             {
-                if (s + 2 < 9) fb[(s + 2) % 3] = ldb((s + 2) / 3, (s + 2) % 3, CB + c);
-                else if (c + 1 < C16) fb[(s + 2) % 3] = ldb(0, s + 2 - 9, CB + c + 1);
+                if (s + 2 < NSLAB) fb[(s + 2) % 3] = ldb((s + 2) / NXL, (s + 2) % NXL, CB + c);
+                else if (c + 1 < C16) fb[(s + 2) % 3] = ldb(0, s + 2 - NSLAB, CB + c + 1);
             }
 #pragma unroll
             for (int grp = 0; grp < 3; ++grp) {
                 const int t = s * 3 + grp, cur = t & 1;
                 if (grp < 2) W4_READ_A(fa[cur ^ 1], vcur, ky, xl, grp + 1)
-                else if (s < 8) W4_READ_A(fa[cur ^ 1], vcur, (s + 1) / 3, (s + 1) % 3, 0)
+                else if (s + 1 < NSLAB) W4_READ_A(fa[cur ^ 1], vcur, (s + 1) / NXL, (s + 1) % NXL, 0)
                 __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of the MFMA group (hipcc sinks it next to its use)
                 W4_MFMA(fa[cur], fb[s % 3], xl, grp)
                 __builtin_amdgcn_sched_barrier(0);
             }
             // A third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs.
-            // The two waves of a SIMD (w and w + 4: the two xi halves) do this at DIFFERENT slabs, so that one of them keeps
-            // the matrix pipe busy while the other issues its VALU / ds_write burst.
-#ifndef W4_NO_STAGGER
-            if (more && s == (xh ? 4 : 2)) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
-            if (more && s == (xh ? 8 : 6)) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
-#else
             if (s == 2 && more) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
             if (s == 6 && more) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
-#endif
         }
         __syncthreads();                                   // V[next] complete and visible; everyone is done with V[cur]
     }
 #undef W4_READ_A
 #undef W4_MFMA
-
-    // ---- epilogue: partial output transforms of the two xi halves summed through LDS, coalesced stores ------------------------
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------
+    // With the weights as the MFMA's A operand a lane holds, per m-tile i, FOUR CONSECUTIVE CHANNELS (cb*16 + 4g ..) of x-tile
+    // 16 i + r for its three xi planes.  y0 = M0 + (M1+M2) + (M3+M4), y1 = (M1-M2) + 2(M3-M4), y2 = (M1+M2) + 4(M3+M4),
+    // y3 = (M1-M2) + 8(M3-M4) + M5: the xi 0..2 wave finishes y0, y1 and the xi 3..5 wave y2, y3; each passes the other its two
+    // partial terms through LDS (lane-linear 16-byte slots: same lane of the partner wave), adds what it receives and stores
+    // 16 bytes per lane straight to global memory - the four channel-block waves fill a pixel's 256-byte line between them.
 #ifdef W4_ABL_EPI
     if (a.slope != 12345.f) return;
 #endif
-    constexpr int RS = W4_BN * 4 + 16;                     // padded row stride of the staged tile (bytes)
-    constexpr int C4 = W4_BN / 4;
-    char* const ob = smem;
-    const int prow = 4 * a.TXT;                            // output pixels per tile row
-    if (xh == 0) {
+    char* const xb = smem;
+    // slot (sender xh, i, k, cb, lane)
+    auto slot = [&](int sender, int i, int k) -> char* { return xb + ((((sender * W4_MG + i) * 2 + k) * 4 + cb) * 64 + lane) * 16; };
+    f32x4 keep[W4_MG][2];
 #pragma unroll
-        for (int i = 0; i < W4_MG; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int m = i * 16 + g * 4 + jj;
-                const int trow = m / a.TXT, txt = m - trow * a.TXT;
-                const float m0 = acc[0][i][jj], m1 = acc[1][i][jj], m2 = acc[2][i][jj];
-                const float sm = m1 + m2, df = m1 - m2;
-                char* o = ob + (trow * prow + 4 * txt) * RS + (cb * 16 + r) * 4;
-                *(float*)(o) = m0 + sm;
-                *(float*)(o + RS) = df;
-                *(float*)(o + 2 * RS) = sm;
-                *(float*)(o + 3 * RS) = df;
-            }
-    }
-    __syncthreads();
-    if (xh == 1) {
-#pragma unroll
-        for (int i = 0; i < W4_MG; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int m = i * 16 + g * 4 + jj;
-                const int trow = m / a.TXT, txt = m - trow * a.TXT;
-                const float m3 = acc[0][i][jj], m4 = acc[1][i][jj], m5 = acc[2][i][jj];
-                const float sm = m3 + m4, df = m3 - m4;
-                char* o = ob + (trow * prow + 4 * txt) * RS + (cb * 16 + r) * 4;
-                *(float*)(o) += sm;
-                *(float*)(o + RS) += 2.0f * df;
-                *(float*)(o + 2 * RS) += 4.0f * sm;
-                *(float*)(o + 3 * RS) += 8.0f * df + m5;
-            }
+    for (int i = 0; i < W4_MG; ++i) {
+        const f32x4 q0 = acc[0][i], q1 = acc[1][i], q2 = acc[2][i];
+        if (xt == 0) {
+            const f32x4 sm = q1 + q2, df = q1 - q2;
+            keep[i][0] = q0 + sm; keep[i][1] = df;
+            *(f32x4*)slot(0, i, 0) = sm; *(f32x4*)slot(0, i, 1) = df;
+        } else {
+            const f32x4 sm = q0 + q1, df = q0 - q1;
+            keep[i][0] = 4.0f * sm; keep[i][1] = 8.0f * df + q2;
+            *(f32x4*)slot(1, i, 0) = sm; *(f32x4*)slot(1, i, 1) = 2.0f * df;
+        }
     }
     __syncthreads();
     const size_t img_out = (size_t)img * a.H * a.W;
-    // 576 pixels x 16 float4 units = 18 per thread, in batches of W4_EB: all of a batch's LDS reads and skip / mask loads are
-    // issued before the first store (an un-batched loop pays the full load latency 18 times in a row)
-#ifndef W4_EB
-#define W4_EB 6
-#endif
-    static_assert(18 % W4_EB == 0, "epilogue batch");
-#pragma unroll 1
-    for (int ub = 0; ub < 18; ub += W4_EB) {
-        f32x4 v[W4_EB], mkv[W4_EB], skv[W4_EB];
-        size_t idx[W4_EB];
-        bool ok[W4_EB];
-        int cov[W4_EB];
+    const int co = n0 + cb * 16 + g * 4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && a.ksplit == 1) bias4 = *(const f32x4*)(a.bias + co);
+    // batches of three m-tiles x two outputs: a batch's LDS reads and skip / mask loads are issued before its first store
 #pragma unroll
-        for (int e = 0; e < W4_EB; ++e) {
-            const int u = tid + (ub + e) * W4_NT;
-            const int p = u / C4, c4 = u - p * C4;
-            const int co = n0 + c4 * 4;
-            const int py = p / prow, px = p - py * prow;
-            const int oy = gy0 + py, ox = 4 * gt0 + px;
+    for (int ib = 0; ib < W4_MG; ib += 3) {
+        f32x4 v[6], mkv[6], skv[6];
+        size_t idx[6];
+        bool ok[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int i = ib + (e >> 1), k = e & 1;
+            const int m = i * 16 + r;
+            const int trow = m / a.TXT, txt = m - trow * a.TXT;
+            const int oy = gy0 + trow, ox = 4 * (gt0 + txt) + 2 * xt + k;
             ok[e] = oy < a.H && ox < a.W;
-            cov[e] = co;
-            v[e] = *(const f32x4*)(ob + p * RS + c4 * 16);
+            // same order of additions as a sequential y = (xi 0..2 part) + (xi 3..5 part)
+            v[e] = xt == 0 ? keep[i][k] + *(const f32x4*)slot(1, i, k) : *(const f32x4*)slot(0, i, k) + keep[i][k];
             if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
                 const int C = a.Cout >> 2;
                 const int sub = co / C, cc = co - sub * C;
@@ -323,14 +299,14 @@ __global__ __launch_bounds__(W4_NT) void conv3x3_wino4_kernel(const Wino4Args a)
             }
         }
 #pragma unroll
-        for (int e = 0; e < W4_EB; ++e) {
+        for (int e = 0; e < 6; ++e) {
             if (!ok[e]) continue;
             f32x4 o = v[e];
             if (a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
                 *(f32x4*)(a.slab + (size_t)ks * ((size_t)a.N * a.H * a.W * a.Cout) + idx[e]) = o;
                 continue;
             }
-            if (a.bias) o += *(const f32x4*)(a.bias + cov[e]);
+            if (a.bias) o += bias4;
             o *= a.alpha;
             if (a.mask) {
                 const f32x4 mk = mkv[e];
@@ -372,13 +348,14 @@ struct W4Plan { int TR, TXT, tiles_x, tiles_y, n_tiles, ksplit, chunks_per_split
 // slots that lie inside the image, or 0 when the shape is not supported or yields fewer than 192 workgroups.
 static bool w4_plan(int N, int H, int W, int Cin, int Cout, bool allow_split, size_t ws_bytes, W4Plan* p) {
     if (N < 1 || H < 1 || W < 4 || W % 4 || Cin % 16 || Cin < 16 || Cout % W4_BN) return false;
+    if ((size_t)H * W * Cin * 4 >= ((size_t)1 << 31)) return false;   // one image per buffer descriptor, offsets below 2^31
     const int XT = W / 4;
     long best = -1;
     for (int TXT = 1; TXT <= 144; ++TXT) {
         if (144 % TXT) continue;
         const int TR = 144 / TXT, HT = TR + 2;
         const size_t vb = (size_t)2 * HT * 6 * TXT * 64;
-        if (vb > 160 * 1024 || HT * TXT * 4 > 2 * W4_NT) continue;
+        if (vb > 160 * 1024 || HT * TXT * 4 > 2 * 512) continue;  // two staging items per thread
         const long cover = (long)pesr_cdiv(H, TR) * TR * pesr_cdiv(XT, TXT) * TXT;
         // least waste first; then a row length whose fragment reads are bank-conflict free with the kernel's swizzle key
         // (measured with scripts/lds_bank_probe.hip: TXT = 12 with the row term, 8 / 16 / 24 without; a 3-x-tile row costs
@@ -390,7 +367,7 @@ static bool w4_plan(int N, int H, int W, int Cin, int Cout, bool allow_split, si
     if (best < 0) return false;
     p->tiles_y = pesr_cdiv(H, p->TR); p->tiles_x = pesr_cdiv(XT, p->TXT); p->n_tiles = Cout / W4_BN;
     p->tiles = (long)N * p->tiles_y * p->tiles_x * p->n_tiles;
-    const size_t vb = (size_t)2 * (p->TR + 2) * 6 * p->TXT * 64, ob = (size_t)576 * (W4_BN * 4 + 16);
+    const size_t vb = (size_t)2 * (p->TR + 2) * 6 * p->TXT * 64, ob = (size_t)2 * W4_MG * 2 * 4 * 64 * 16;   // the epilogue's exchange slots
     p->lds = vb > ob ? vb : ob;
     const int C16T = Cin / 16;
     p->ksplit = 1; p->chunks_per_split = C16T;
@@ -442,7 +419,7 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)(p.tiles * p.ksplit)), dim3(W4_NT), p.lds, stream, a);
+    hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
     if (p.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, act,
                                               slope, stream);
