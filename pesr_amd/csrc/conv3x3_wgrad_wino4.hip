@@ -45,7 +45,16 @@ constexpr int G4_VPLANE = G4_K4 * 128, G4_VROW = 6 * G4_VPLANE;       // floats:
 constexpr int G4_DPLANE = G4_K4 * 256, G4_DROW = 6 * G4_DPLANE;       // floats: dM row     [6 xi][3 blocks][4 x-tiles x 64 co]
 constexpr int G4_RING = 6;
 
+#ifdef PESR_TIMING
+__device__ unsigned long long g4_timing[4096 * PESR_TIMING_SLOTS];
+PESR_API int pesr_debug_timing_wgrad4(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_timing), (size_t)n * sizeof(unsigned long long));
+}
+#endif
+
 __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Args a) {
+    PESR_STAMP(g4_timing, 0);
+    PESR_STAMP_CLK(g4_timing, 6);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const vring = lds;                             // [6 slots] V rows
     float* const dmbuf = lds + G4_RING * G4_VROW;         // [2 buffers][2 rows] dM rows
@@ -81,9 +90,12 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     const int v_rr = vi / 96, vt = (vi % 96) >> 3, vc4 = vi & 7;          // which of the 2 new rows, x-tile, 4-channel group
     const int di = d_thr ? tid - 128 : 0;
     const int d_rr = di / 192, dt = (di % 192) >> 4, dc4 = di & 15;
-    // position of an item inside a plane: block of 4 x-tiles, 16-float groups interleaved over the 4 x-tiles
-    const int v_pos = (vt >> 2) * 128 + (((vc4 >> 2) * 4 + (vt & 3)) * 16) + (vc4 & 3) * 4;
-    const int d_pos = (dt >> 2) * 256 + (((dc4 >> 2) * 4 + (dt & 3)) * 16) + (dc4 & 3) * 4;
+    // position of an item inside a plane: block of 4 x-tiles, 16-float groups interleaved over the 4 x-tiles.  The x-tile slot
+    // is rotated by the channel tile (V: by 2 per 16-ci tile, dM: by 1 per 16-co tile): the 16 lanes that write one x-tile's
+    // 64 (32) channels then hit 64 different banks instead of the same 16 four (two) times, and a fragment read - one channel
+    // tile, x-tiles g = 0..3 - still covers 64 consecutive floats.
+    const int v_pos = (vt >> 2) * 128 + (((vc4 >> 2) * 4 + ((vt + 2 * (vc4 >> 2)) & 3)) * 16) + (vc4 & 3) * 4;
+    const int d_pos = (dt >> 2) * 256 + (((dc4 >> 2) * 4 + ((dt + (dc4 >> 2)) & 3)) * 16) + (dc4 & 3) * 4;
     const int d_C = a.ps_in ? (a.Cout >> 2) : a.Cout;
     int d_choff;                                          // channel part of a dy address (floats)
     {
@@ -91,41 +103,42 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
         if (a.ps_in) { const int sub = pch / d_C, cc = pch - sub * d_C; d_choff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * d_C + cc; }
         else d_choff = pch;
     }
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // Loads put RAW values into registers (an out-of-range element reads a dummy in-range address); zeroing, transform and
-    // ds_write happen in store_*() behind most of the MFMA block.
-    f32x4 vx[6], dd[4];
-    unsigned vmask = 0, dmask = 0, v_cols = 0, d_cols = 0;
-    int v_off[6], d_off[4];
-    auto set_strip = [&](int xs) {   // per strip, a thread's column offsets (floats from the start of a row) and their validity
-        v_cols = 0; d_cols = 0;
+    // Loads go through a buffer descriptor over ONE tensor row: a column outside the row is fetched at offset 2^31 and a row
+    // outside the image through an empty descriptor - both return zeros, so store_*() transforms what arrived without masking.
+    // Only the waves that own items issue them (V: waves 0..2, dM: waves 2..7).
+    u32x4 vx[6], dd[4];
+    unsigned v_off[6], d_off[4];
+    auto set_strip = [&](int xs) {   // per strip, a thread's column offsets (bytes from the start of a row)
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int ix = xs * 48 + 4 * vt - 1 + j;
             const bool ok = v_thr && ix >= 0 && ix < a.W;
-            v_off[j] = ok ? ix * a.Cin + ci0 + vc4 * 4 : 0;
-            v_cols |= ok ? (1u << j) : 0u;
+            v_off[j] = ok ? (unsigned)((ix * a.Cin + ci0 + vc4 * 4) * 4) : 0x80000000u;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ox = xs * 48 + 4 * dt + j;
             const bool ok = d_thr && ox < a.W;
-            d_off[j] = ok ? (a.ps_in ? 2 * ox * d_C : ox * a.Cout) + d_choff : 0;
-            d_cols |= ok ? (1u << j) : 0u;
+            d_off[j] = ok ? (unsigned)(((a.ps_in ? 2 * ox * d_C : ox * a.Cout) + d_choff) * 4) : 0x80000000u;
         }
     };
+    const unsigned x_row_bytes = (unsigned)a.W * a.Cin * 4;
+    // a dy row of the shuffled tensor spans the two sub-pixel rows 2oy, 2oy+1: 2 * (2W) * (Cout/4) floats = W * Cout as well
+    const unsigned d_row_bytes = (unsigned)a.W * a.Cout * 4;
     auto load_v = [&](int img, int iy) {                   // input row iy (may lie outside the image: zeros)
-        const bool row_ok = iy >= 0 && iy < a.H;
-        const float* const rowp = a.x + ((size_t)img * a.H + (row_ok ? iy : 0)) * a.W * a.Cin;
-        vmask = row_ok ? v_cols : 0u;
+        if (wave < 3) {
+            const bool row_ok = iy >= 0 && iy < a.H;
+            const float* const rowp = a.x + ((size_t)img * a.H + (row_ok ? iy : 0)) * a.W * a.Cin;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rowp, 0, row_ok ? x_row_bytes : 0u, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) vx[j] = *(const f32x4*)(rowp + v_off[j]);
+            for (int j = 0; j < 6; ++j) vx[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, v_off[j], 0, 0);
+        }
     };
     auto store_v = [&](int slot) {
-        if (v_thr) {
-            const f32x4 d0 = (vmask & 1u) ? vx[0] : zero4, d1 = (vmask & 2u) ? vx[1] : zero4, d2 = (vmask & 4u) ? vx[2] : zero4,
-                        d3 = (vmask & 8u) ? vx[3] : zero4, d4 = (vmask & 16u) ? vx[4] : zero4, d5 = (vmask & 32u) ? vx[5] : zero4;
+        if (wave < 3) {
+            const f32x4 d0 = __builtin_bit_cast(f32x4, vx[0]), d1 = __builtin_bit_cast(f32x4, vx[1]), d2 = __builtin_bit_cast(f32x4, vx[2]),
+                        d3 = __builtin_bit_cast(f32x4, vx[3]), d4 = __builtin_bit_cast(f32x4, vx[4]), d5 = __builtin_bit_cast(f32x4, vx[5]);
             const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
             float* p = vring + slot * G4_VROW + v_pos;
             *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
@@ -137,18 +150,20 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
         }
     };
     auto load_d = [&](int img, int oy) {                   // output-gradient row oy (>= H: zeros)
-        const bool row_ok = oy < a.H;
-        const int ry = row_ok ? oy : 0;
-        const float* const rowp = a.ps_in ? a.dy + ((size_t)img * (2 * a.H) + 2 * ry) * (2 * a.W) * d_C
-                                          : a.dy + ((size_t)img * a.H + ry) * a.W * a.Cout;
-        dmask = row_ok ? d_cols : 0u;
+        if (wave >= 2) {
+            const bool row_ok = oy < a.H;
+            const int ry = row_ok ? oy : 0;
+            const float* const rowp = a.ps_in ? a.dy + ((size_t)img * (2 * a.H) + 2 * ry) * (2 * a.W) * d_C
+                                              : a.dy + ((size_t)img * a.H + ry) * a.W * a.Cout;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rowp, 0, row_ok ? d_row_bytes : 0u, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dd[j] = *(const f32x4*)(rowp + d_off[j]);
+            for (int j = 0; j < 4; ++j) dd[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, d_off[j], 0, 0);
+        }
     };
     auto store_d = [&](int buf) {
-        if (d_thr) {
-            const f32x4 g0 = (dmask & 1u) ? dd[0] : zero4, g1 = (dmask & 2u) ? dd[1] : zero4, g2 = (dmask & 4u) ? dd[2] : zero4,
-                        g3 = (dmask & 8u) ? dd[3] : zero4;
+        if (wave >= 2) {
+            const f32x4 g0 = __builtin_bit_cast(f32x4, dd[0]), g1 = __builtin_bit_cast(f32x4, dd[1]), g2 = __builtin_bit_cast(f32x4, dd[2]),
+                        g3 = __builtin_bit_cast(f32x4, dd[3]);
             const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
             float* p = dmbuf + (buf * 2 + d_rr) * G4_DROW + d_pos;
             *(f32x4*)(p) = g0;
@@ -172,8 +187,9 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     };
 
     // ---- fragment addresses (floats): lane (r, g) reads x-tile 4k + g, channel 16*tile + r ------------------------------
-    const int b_lane = (ci_tile * 4 + g) * 16 + r + xh * 3 * G4_VPLANE;
-    const int a_lane = (co_half * 2 * 4 + g) * 16 + r + xh * 3 * G4_DPLANE;     // second m-tile: + 64
+    const int b_lane = (ci_tile * 4 + ((g + 2 * ci_tile) & 3)) * 16 + r + xh * 3 * G4_VPLANE;
+    const int a_lane0 = (co_half * 2 * 4 + ((g + co_half * 2) & 3)) * 16 + r + xh * 3 * G4_DPLANE;        // m-tile 2 co_half
+    const int a_lane1 = ((co_half * 2 + 1) * 4 + ((g + co_half * 2 + 1) & 3)) * 16 + r + xh * 3 * G4_DPLANE;   // m-tile 2 co_half + 1
 
     if (seg_begin >= seg_end) return;                       // (never: the planner hands every workgroup at least one segment)
     int img, xs, row;
@@ -185,6 +201,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     // of segment s they were waited for a third of a segment later - under load an L2 / MALL round trip is longer than that.
     if (seg_begin + 1 < seg_end && row + 2 < a.H) { load_v(img, row + 3 + v_rr); load_d(img, row + 2 + d_rr); }
     __syncthreads();
+    PESR_STAMP(g4_timing, 1);
     int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
 #ifndef G4_STORE_STEP
 #define G4_STORE_STEP 4
@@ -197,7 +214,8 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
         const bool cont = more && row + 2 < a.H;            // the next segment is the next row pair of the same strip
         const bool cont2 = cont && seg + 2 < seg_end && row + 4 < a.H;   // ... and so is the one after it
 
-        const float* const db = dmbuf + (par * 2) * G4_DROW + a_lane;
+        const float* const db = dmbuf + (par * 2) * G4_DROW + a_lane0;
+        const float* const db1 = dmbuf + (par * 2) * G4_DROW + a_lane1;
         const float* vb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -211,7 +229,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             const int rr_ = (STEP) / G4_K4, k4_ = (STEP) % G4_K4;                                         \
             _Pragma("unroll") for (int xl = 0; xl < 3; ++xl) {                                           \
                 AV[xl * 2 + 0] = db[rr_ * G4_DROW + xl * G4_DPLANE + k4_ * 256];                         \
-                AV[xl * 2 + 1] = db[rr_ * G4_DROW + xl * G4_DPLANE + k4_ * 256 + 64];                    \
+                AV[xl * 2 + 1] = db1[rr_ * G4_DROW + xl * G4_DPLANE + k4_ * 256];                        \
                 _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                         \
                     BV[ky * 3 + xl] = vb[rr_ + ky][xl * G4_VPLANE + k4_ * 128];                          \
             }                                                                                            \
@@ -222,6 +240,14 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
                     acc[ky * 3 + xl][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[xl * 2 + i], BV[ky * 3 + xl], acc[ky * 3 + xl][i], 0, 0, 0); \
         if (xh == 0) { _Pragma("unroll") for (int i = 0; i < 2; ++i) bsum[i] += AV[2 + i]; }   /* dM_1 = dy0+dy1+dy2+dy3 */
+#ifdef G4_ABL_READS
+#undef G4_READ
+#define G4_READ(AV, BV, STEP) if (a.ps_in == 12345) { _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) AV[q_] = db[q_ * 64 + (STEP)]; _Pragma("unroll") for (int q_ = 0; q_ < 9; ++q_) BV[q_] = vb[0][q_ * 64 + (STEP)]; }
+#pragma unroll
+        for (int q_ = 0; q_ < 6; ++q_) av0[q_] = av1[q_] = 1.0f;
+#pragma unroll
+        for (int q_ = 0; q_ < 9; ++q_) bv0[q_] = bv1[q_] = 1.0f;
+#endif
         G4_READ(av0, bv0, 0)
 #pragma unroll
         for (int stp = 0; stp < 2 * G4_K4; stp += 2) {
@@ -265,20 +291,26 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
 #undef G4_READ
 #undef G4_MFMA
         if (cont) {                                         // rows +3, +4 went to the slots of rows -1, 0, which the next segment drops
+#ifdef G4_ABL_BARRIER
+            if (a.ps_in == 12345)
+#endif
             __syncthreads();
             base += 2; if (base >= G4_RING) base -= G4_RING;
             row += 2;
         } else if (more) {                                  // new strip / image: its four halo rows are staged from scratch
             __syncthreads();
+            PESR_STAMP(g4_timing, 4);
             seg_coords(seg + 1, img, xs, row);
             set_strip(xs);
             stage_strip_start(img, row, par ^ 1);
             if (seg + 2 < seg_end && row + 2 < a.H) { load_v(img, row + 3 + v_rr); load_d(img, row + 2 + d_rr); }
             __syncthreads();
+            PESR_STAMP(g4_timing, 5);
             base = 0;
         }
     }
     __syncthreads();
+    PESR_STAMP(g4_timing, 2);
 
     if (a.bias_part && cit == 0) {   // combine the 4 k-slot lane groups through LDS (the staging buffers are free now), fixed order
         float* red = lds;
@@ -330,6 +362,8 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
         }
         if (ph == 0) __syncthreads();
     }
+    PESR_STAMP(g4_timing, 3);
+    PESR_STAMP_CLK(g4_timing, 7);
 }
 
 namespace {

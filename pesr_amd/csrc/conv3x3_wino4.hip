@@ -54,7 +54,16 @@ constexpr int W4_BN = 64, W4_MG = 9;
 
 // Wave w owns the 16 channels w & 3 and HALF of the xi planes (w >> 2: xi 0..2 / 3..5): 27 accumulator tiles, 2 waves per SIMD.
 // (A 12-wave variant - a third of the xi planes per wave, 3 waves per SIMD in the 168-VGPR budget - measured 2 % slower.)
+#ifdef PESR_TIMING
+__device__ unsigned long long w4_timing[4096 * PESR_TIMING_SLOTS];
+PESR_API int pesr_debug_timing_wino4(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(w4_timing), (size_t)n * sizeof(unsigned long long));
+}
+#endif
+
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
+    PESR_STAMP(w4_timing, 0);
+    PESR_STAMP_CLK(w4_timing, 6);
     constexpr int NT = 512;                                // threads of the workgroup
     constexpr int NXL = 3;                                 // xi planes per wave
     constexpr int NSLAB = 3 * NXL;                         // weight slabs per wave and chunk: (ky, xl)
@@ -199,6 +208,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         stage_store(1, smem);
     }
     __syncthreads();
+    PESR_STAMP(w4_timing, 1);
 
 #pragma unroll 1
     for (int c = 0; c < C16; ++c) {
@@ -210,6 +220,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         const bool more = c + 1 < C16;
 #endif
         if (more) stage_load(0, CB + c + 1);               // lands while this chunk computes
+#ifdef W4_ABL_READS
+#undef W4_READ_A
+#define W4_READ_A(FA, VB, KY, XL, GRP) if (a.slope == 12345.f) { _Pragma("unroll") for (int i = 0; i < 3; ++i) FA[i] = *(const f32x4*)((VB) + a_off[(GRP) * 3 + i] + (KY) * 64 + (XL) * 16); }
+        if (c == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { fa[0][i] = (f32x4){1.f, 2.f, 3.f, 4.f}; fa[1][i] = (f32x4){1.f, 2.f, 3.f, 4.f}; }
+        }
+#endif
         W4_READ_A(fa[0], vcur, 0, 0, 0)
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {                  // slab s = (ky, xl)
@@ -235,10 +253,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             if (s == 2 && more) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
             if (s == 6 && more) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
         }
+#ifdef W4_ABL_BARRIER
+        if (a.slope == 12345.f)
+#endif
         __syncthreads();                                   // V[next] complete and visible; everyone is done with V[cur]
     }
 #undef W4_READ_A
 #undef W4_MFMA
+    PESR_STAMP(w4_timing, 2);
     // ---- epilogue ------------------------------------------------------------------------------------------------------------
     // With the weights as the MFMA's A operand a lane holds, per m-tile i, FOUR CONSECUTIVE CHANNELS (cb*16 + 4g ..) of x-tile
     // 16 i + r for its three xi planes.  y0 = M0 + (M1+M2) + (M3+M4), y1 = (M1-M2) + 2(M3-M4), y2 = (M1+M2) + 4(M3+M4),
@@ -266,6 +288,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         }
     }
     __syncthreads();
+    PESR_STAMP(w4_timing, 3);
     const size_t img_out = (size_t)img * a.H * a.W;
     const int co = n0 + cb * 16 + g * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -322,6 +345,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             *(f32x4*)(a.y + idx[e]) = o;
         }
     }
+    PESR_STAMP(w4_timing, 4);
+    PESR_STAMP_CLK(w4_timing, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
