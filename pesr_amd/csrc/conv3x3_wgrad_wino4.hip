@@ -139,14 +139,22 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
         if (wave < 3) {
             const f32x4 d0 = __builtin_bit_cast(f32x4, vx[0]), d1 = __builtin_bit_cast(f32x4, vx[1]), d2 = __builtin_bit_cast(f32x4, vx[2]),
                         d3 = __builtin_bit_cast(f32x4, vx[3]), d4 = __builtin_bit_cast(f32x4, vx[4]), d5 = __builtin_bit_cast(f32x4, vx[5]);
-            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
             float* p = vring + slot * G4_VROW + v_pos;
+#if defined(G4_ABL_XFORM)      // timing-only: raw values, no transform arithmetic
+            *(f32x4*)(p) = d0; *(f32x4*)(p + G4_VPLANE) = d1; *(f32x4*)(p + 2 * G4_VPLANE) = d2;
+            *(f32x4*)(p + 3 * G4_VPLANE) = d3; *(f32x4*)(p + 4 * G4_VPLANE) = d4; *(f32x4*)(p + 5 * G4_VPLANE) = d5;
+#elif defined(G4_ABL_LDSW)     // timing-only: the arithmetic, one ds_write instead of six
+            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
+            *(f32x4*)(p) = ((4.0f * d0 + (d4 - 5.0f * d2)) * (t1 + t2)) * ((t1 - t2) * (t3 + 2.0f * t4)) * ((t3 - 2.0f * t4) * (4.0f * d1 + (d5 - 5.0f * d3)));
+#else
+            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
             *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
             *(f32x4*)(p + G4_VPLANE) = t1 + t2;
             *(f32x4*)(p + 2 * G4_VPLANE) = t1 - t2;
             *(f32x4*)(p + 3 * G4_VPLANE) = t3 + 2.0f * t4;
             *(f32x4*)(p + 4 * G4_VPLANE) = t3 - 2.0f * t4;
             *(f32x4*)(p + 5 * G4_VPLANE) = 4.0f * d1 + (d5 - 5.0f * d3);
+#endif
         }
     };
     auto load_d = [&](int img, int oy) {                   // output-gradient row oy (>= H: zeros)
@@ -164,14 +172,22 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
         if (wave >= 2) {
             const f32x4 g0 = __builtin_bit_cast(f32x4, dd[0]), g1 = __builtin_bit_cast(f32x4, dd[1]), g2 = __builtin_bit_cast(f32x4, dd[2]),
                         g3 = __builtin_bit_cast(f32x4, dd[3]);
-            const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
             float* p = dmbuf + (buf * 2 + d_rr) * G4_DROW + d_pos;
+#if defined(G4_ABL_XFORM)
+            *(f32x4*)(p) = g0; *(f32x4*)(p + G4_DPLANE) = g1; *(f32x4*)(p + 2 * G4_DPLANE) = g2;
+            *(f32x4*)(p + 3 * G4_DPLANE) = g3; *(f32x4*)(p + 4 * G4_DPLANE) = g0; *(f32x4*)(p + 5 * G4_DPLANE) = g3;
+#elif defined(G4_ABL_LDSW)
+            const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
+            *(f32x4*)(p) = (g0 * (e02 + e13)) * ((e02 - e13) * (f02 + 2.0f * f13)) * ((f02 - 2.0f * f13) * g3);
+#else
+            const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
             *(f32x4*)(p) = g0;
             *(f32x4*)(p + G4_DPLANE) = e02 + e13;
             *(f32x4*)(p + 2 * G4_DPLANE) = e02 - e13;
             *(f32x4*)(p + 3 * G4_DPLANE) = f02 + 2.0f * f13;
             *(f32x4*)(p + 4 * G4_DPLANE) = f02 - 2.0f * f13;
             *(f32x4*)(p + 5 * G4_DPLANE) = g3;
+#endif
         }
     };
     auto seg_coords = [&](int seg, int& img, int& xs, int& row) {
@@ -203,8 +219,9 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     __syncthreads();
     PESR_STAMP(g4_timing, 1);
     int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
-    // One common store point for all waves, two thirds into the segment.  (Giving the two waves of a SIMD different store points
-    // - so that one keeps the matrix pipe busy while the other transforms and writes - measured 1.4 % slower.)
+    // One common store point for all waves, two thirds into the segment, with the next loads issued right behind it.  Measured
+    // alternatives: different store points for the two waves of a SIMD 1.4 % slower; the loads spread over three k-steps instead
+    // of one burst 12 % slower (those issued two k-steps before the store have not landed - a loaded L2 round trip is > 1 us).
 #ifndef G4_STORE_STEP
 #define G4_STORE_STEP 4
 #endif
