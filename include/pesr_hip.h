@@ -110,6 +110,12 @@ int pesr_conv3x3_wino4(const float* x, const float* w_packed, const float* bias,
 int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
                          float slope, void* stream);
 
+/* Forward 3x3 conv to 3 output channels, stride 1 (the Generator's last conv, reference model/pesr.py:38 `Conv(num_channels, 3)`
+ * via model/basic.py:4-7): x [N][H][W][C] (C a multiple of 64, <= 512), w OIHW [3][C][3][3] (NOT packed), bias [3] or null,
+ * y [N][H][W][3].  HBM-bound: every input row is read once per band of 12 output rows. */
+int pesr_conv3x3_rgb_out_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
+                             float slope, void* stream);
+
 /* Input gradient of a C -> 3 conv (stride 1): reference Upsampler's last conv (model/basic.py:60), i.e. ATen
  * convolution_backward(input) for it.  dy [N][H][W][3], w OIHW [3][C][3][3] (NOT packed), dx [N][H][W][C]. */
 int pesr_conv3x3_rgb_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, void* stream);

@@ -95,6 +95,8 @@ int pesr_conv_splitk_finish_launch(const float* slab, const float* bias, const f
                                    int C, int ksplit, float alpha, int act, float slope, hipStream_t stream);
 int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
                             float slope, hipStream_t stream);
+int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
+                                 float slope, hipStream_t stream);
 int pesr_conv_rgb_out_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream);
 
 int pesr_crop_augment_launch(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, hipStream_t stream);

@@ -64,6 +64,89 @@ __global__ __launch_bounds__(64) void corr_rgb_kernel(const float* __restrict__ 
     for (int i = 0; i < 27; ++i) o[i] = acc[i];
 }
 
+// MFMA form of the same correlation for C a multiple of 256: dw^T[c][n] = sum_p A[p][c] * b27[p][n] with n = oy*9 + ox*3 + k
+// (27 of 32 columns) and K = pixels.  The point is the load pattern, not the flops: a lane reads 16 bytes = FOUR CONSECUTIVE
+// CHANNELS of one pixel and hands component t to MFMA tile t, whose row i stands for channel 4i + t - so the 16 lanes of a
+// k-slot cover 256 contiguous bytes and the four waves of a workgroup a pixel's whole 1-KiB channel vector (the VALU kernel
+// above issues one 4-byte load per 27 FMAs and is bound by them).  The B operand - the 27 neighbourhood values of the pixel -
+// is gathered from three zero-padded B3 rows staged in LDS.  One workgroup = 256 channels x rows_per_split image rows; wave w
+// owns channels 64 w .. 64 w + 63 (4 M tiles x 2 N tiles); loads run CR_D - 1 k-steps (4 pixels each) ahead.
+constexpr int CR_D = 8;
+__global__ __launch_bounds__(256) void corr_rgb_mfma_kernel(const float* __restrict__ A, const float* __restrict__ b3p,
+                                                            float* __restrict__ part, int NH, int H, int W, int C,
+                                                            int rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][3][(W + 2) * 3] padded B3 rows, double buffered
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int ncol = C >> 8;
+    const int cc = blockIdx.x % ncol, sp = blockIdx.x / ncol;
+    const int c0 = cc * 256 + wave * 64;
+    const int r0 = sp * rows_per_split;
+    int r1 = r0 + rows_per_split; if (r1 > NH) r1 = NH;
+    const int WP3 = (W + 2) * 3;
+    const int ksteps = (W + 3) >> 2;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // B gather offsets of this lane inside a staged row triple: column n = i (N tile 0) and 16 + i (N tile 1, n < 27 only)
+    const int n1 = 16 + i;
+    const int boff0 = (i / 9) * WP3 + (i % 9);
+    const int boff1 = n1 < 27 ? (n1 / 9) * WP3 + (n1 % 9) : -1;
+    const unsigned row_bytes = (unsigned)W * C * 4;
+    const unsigned a_lane = (unsigned)((c0 + 4 * i) * 4);                 // + pixel * C * 4
+    auto stage_b = [&](int row, int buf) {                                 // padded rows y .. y+2 of image n (= neighbours y-1 .. y+1)
+        const int n = row / H, y = row - n * H;
+        const float* src = b3p + ((size_t)n * (H + 2) + y) * WP3;
+        float* dst = lds + buf * 3 * WP3;
+        for (int e = tid; e < 3 * WP3; e += 256) dst[e] = src[e];
+    };
+    if (r0 < r1) stage_b(r0, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int row = r0; row < r1; ++row) {
+        const int buf = (row - r0) & 1;
+        if (row + 1 < r1) stage_b(row + 1, buf ^ 1);                       // visible after the barrier at the end of this row
+        const float* const bl = lds + buf * 3 * WP3;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)row * W * C), 0, row_bytes, 0x00020000);
+        auto a_load = [&](int s) -> u32x4 {                                // k-step s: pixel 4 s + g (beyond the row: zeros)
+            const int px = 4 * s + g;
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, px < W ? a_lane + (unsigned)px * C * 4 : 0x80000000u, 0, 0);
+        };
+        u32x4 fa[CR_D];
+#pragma unroll
+        for (int d = 0; d < CR_D - 1; ++d) fa[d] = a_load(d);              // s >= ksteps: all lanes out of range, harmless
+#pragma unroll 1
+        for (int s0 = 0; s0 < ksteps; s0 += CR_D)
+#pragma unroll
+        for (int u = 0; u < CR_D; ++u) {
+            const int s = s0 + u;
+            if (s < ksteps) {
+                fa[(u + CR_D - 1) % CR_D] = a_load(s + CR_D - 1);
+                int px = 4 * s + g; if (px > W - 1) px = W - 1;            // a pixel past the row multiplies zeros: any finite B value
+                const float b0 = bl[px * 3 + boff0];
+                const float b1 = boff1 >= 0 ? bl[px * 3 + boff1] : 0.f;
+                const f32x4 av = __builtin_bit_cast(f32x4, fa[u]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b1, acc[t][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D tile (t, h): row m = 4 g + jj is channel c0 + 4 m + t, column i is n = 16 h + i
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int n = 16 * h + i, c = c0 + 4 * (4 * g + jj) + t;
+                if (n < 27) part[((size_t)sp * C + c) * 27 + n] = acc[t][h][jj];
+            }
+}
+
 __global__ void corr_rgb_final_kernel(const double* __restrict__ dsum, float* __restrict__ dw, int C, int mode, float alpha) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // e = c*27 + oy*9 + ox*3 + k
     if (e >= C * 27) return;
@@ -95,11 +178,13 @@ __global__ void colsum3_final_kernel(const double* __restrict__ dsum, float* __r
 }
 
 namespace {
-struct RgbPlan { int nsplit, rows_per_split; size_t pad_bytes, part_bytes, dsum_bytes, bias_bytes, total; };
+struct RgbPlan { int nsplit, rows_per_split, mfma; size_t pad_bytes, part_bytes, dsum_bytes, bias_bytes, total; };
 static bool rgb_plan(int N, int H, int W, int C, RgbPlan* p) {
     if (C < 1) return false;
     const int NH = N * H;
-    int want = 4096 / ((C + 63) / 64);
+    // MFMA kernel (C % 256 == 0): one 4-wave workgroup per 256 channels and row range, two resident per CU -> ~512 workgroups
+    p->mfma = C % 256 == 0 && (size_t)W * C * 4 < ((size_t)1 << 31) && (size_t)2 * 3 * (W + 2) * 3 * sizeof(float) <= 64 * 1024;
+    int want = p->mfma ? 512 / (C / 256) : 4096 / ((C + 63) / 64);
     if (want > NH) want = NH;
     if (want < 1) want = 1;
     p->rows_per_split = (NH + want - 1) / want;
@@ -129,7 +214,13 @@ int pesr_conv3x3_wgrad_rgb_launch(const float* A, const float* b3, float* dw, fl
     float* bpart = (float*)((char*)ws + p.pad_bytes + p.part_bytes + p.dsum_bytes);
     const long padn = (long)N * (H + 2) * (W + 2) * 3;
     hipLaunchKernelGGL(pad_rgb_kernel, dim3((unsigned)((padn + 255) / 256 < 2048 ? (padn + 255) / 256 : 2048)), dim3(256), 0, stream, b3, b3p, N, H, W);
-    hipLaunchKernelGGL(corr_rgb_kernel, dim3(((C + 63) / 64) * p.nsplit), dim3(64), 0, stream, A, (const float*)b3p, part, N * H, H, W, C, p.rows_per_split);
+    if (p.mfma) {
+        const size_t lds = (size_t)2 * 3 * (W + 2) * 3 * sizeof(float);
+        hipLaunchKernelGGL(corr_rgb_mfma_kernel, dim3((C / 256) * p.nsplit), dim3(256), lds, stream, A, (const float*)b3p, part, N * H, H, W, C,
+                           p.rows_per_split);
+    } else {
+        hipLaunchKernelGGL(corr_rgb_kernel, dim3(((C + 63) / 64) * p.nsplit), dim3(64), 0, stream, A, (const float*)b3p, part, N * H, H, W, C, p.rows_per_split);
+    }
     int rc = pesr_reduce_rows_launch(part, dsum, p.nsplit, C * 27, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(corr_rgb_final_kernel, dim3((C * 27 + 255) / 256), dim3(256), 0, stream, (const double*)dsum, dw, C, mode, alpha);

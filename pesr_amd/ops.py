@@ -203,6 +203,14 @@ def _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, sl
     _lib.check(rc, f"pesr_conv3x3_wino{'4' if four else ''}[{what} {N}x{H}x{W}x{Cin}->{cout}]")
 
 
+USE_RGB_OUT = True   # tests switch it off to compare with the implicit-GEMM kernel
+
+
+def rgb_out_eligible(cin: int, cout: int, stride: int) -> bool:
+    """Shapes of pesr_conv3x3_rgb_out_fwd (C -> 3, stride 1)."""
+    return USE_RGB_OUT and cout == 3 and stride == 1 and cin % 64 == 0 and cin <= 512
+
+
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], cout: int, stride: int = 1,
                 alpha: float = 1.0, act: int = ACT_NONE, slope: float = 0.0, skip: Optional[torch.Tensor] = None,
                 mask: Optional[torch.Tensor] = None, ps_out: bool = False,
@@ -224,6 +232,11 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         # RGB input layer: dedicated HBM-bound direct kernel on the un-packed OIHW weights
         rc = _lib.lib().pesr_conv3x3_rgb_fwd(_p(x), _p(w_oihw), _p(bias), _p(y), N, H, W, cout, act, slope, _stream())
         _lib.check(rc, f"pesr_conv3x3_rgb_fwd[{N}x{H}x{W}x3->{cout}]")
+        return y
+    if rgb_out_eligible(Cin, cout, stride) and skip is None and mask is None and not ps_out and alpha == 1.0 and w_oihw is not None:
+        # -> RGB output layer: dedicated HBM-bound kernel on the un-packed OIHW weights (no pack, no padded MFMAs)
+        rc = _lib.lib().pesr_conv3x3_rgb_out_fwd(_p(x), _p(w_oihw), _p(bias), _p(y), N, H, W, Cin, act, slope, _stream())
+        _lib.check(rc, f"pesr_conv3x3_rgb_out_fwd[{N}x{H}x{W}x{Cin}->3]")
         return y
     if callable(wp):
         wp = wp()

@@ -338,3 +338,33 @@ def test_winograd_random_shape_sweep():
         _, dw_ref, db_ref = O.conv3x3_grads(x, w, dy)
         dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1)
         _close(dw.cpu(), dw_ref, 2e-5); _close(db.cpu(), db_ref, 2e-5)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,bias,act", [
+    (2, 7, 192, 64, True, 0),       # one full-width strip, a band shorter than 12 rows
+    (1, 13, 50, 64, False, 0),      # narrower than a strip: columns >= W read zeros; ragged band (13 = 12 + 1)
+    (1, 9, 400, 64, True, 0),       # three overlapping 190-column strips, the last one ragged
+    (2, 192, 192, 256, True, 0),    # the Generator's last conv at two images of the training shape
+    (1, 30, 16, 128, True, 2),      # LeakyReLU epilogue, three bands
+])
+def test_conv3x3_rgb_out_kernel(N, H, W, Cin, bias, act):
+    """C -> 3 forward (dedicated kernel, x stencil folded into the MFMA N dimension) vs the oracle conv and vs the
+    implicit-GEMM kernel it replaces (reference model/pesr.py:38 via model/basic.py:4-7)."""
+    from pesr_amd import ops
+    x = _rand(N, Cin, H, W, seed=1)
+    w = _rand(3, Cin, 3, 3, seed=2, scale=0.1)
+    b = _rand(3, seed=3) if bias else None
+    ref = O.conv3x3(x, w, b, 1)
+    if act == 2:
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    assert ops.rgb_out_eligible(Cin, 3, 1)
+    xg, wg, bg = _nhwc(x), w.cuda(), (b.cuda() if bias else None)
+    kw = dict(act=ops.ACT_LRELU, slope=0.2) if act == 2 else {}
+    y = ops.conv3x3_fwd(xg, lambda: (_ for _ in ()).throw(AssertionError("the packed weights must not be needed")), bg, 3, w_oihw=wg, **kw)
+    _close(_nchw(y), ref, 2e-6 * (Cin * 9) ** 0.5)
+    ops.USE_RGB_OUT = False
+    try:
+        y2 = ops.conv3x3_fwd(xg, ops.pack_conv3x3(wg, 0), bg, 3, w_oihw=wg, **kw)
+    finally:
+        ops.USE_RGB_OUT = True
+    _close(_nchw(y), _nchw(y2), 2e-6 * (Cin * 9) ** 0.5)

@@ -27,7 +27,7 @@ def _close(a, b, rel, what=""):
     assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e} > {rel})"
 
 
-@pytest.mark.parametrize("N,H,W,C", [(2, 12, 12, 64), (1, 9, 7, 256), (2, 37, 70, 64)])
+@pytest.mark.parametrize("N,H,W,C", [(2, 12, 12, 64), (1, 9, 7, 256), (2, 37, 70, 64), (2, 37, 70, 256), (1, 5, 192, 512)])
 def test_rgb_convs(N, H, W, C):
     """3 -> C and C -> 3 convs (zero-padded onto the MFMA kernel) and their grads."""
     from pesr_amd import ops
