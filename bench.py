@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--cpu_steps", type=int, default=3, help="timed CPU-oracle steps (after one warm-up / parity step)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (cpu_baseline and parity_check)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="N=1 GAN workload: capture the step into a hipGraph after the warm-up and time replays (bit-identical "
+                         "results; the roofline kernel events are then taken from two extra eager steps outside the timed region)")
     args = ap.parse_args()
 
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
@@ -247,8 +250,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if not args.no_kernel_events:
-        ops.KERNEL_EVENTS.enable(shape=(args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels, 1))
+    use_graph = args.hip_graph and world == 1 and args.workload == "gan" and args.warmup >= 1
+    watch = (args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels, 1)
+    if use_graph:
+        step = trainer.capture_gan_step(lr, hr)
+        step(lr, hr)                                # first replay outside the timed region (graph upload)
+        torch.cuda.synchronize()
+    elif not args.no_kernel_events:
+        ops.KERNEL_EVENTS.enable(shape=watch)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         logs = step(lr, hr)
@@ -258,6 +267,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if use_graph and not args.no_kernel_events:     # events cannot be read back from inside a graph: two eager steps for them
+        ops.KERNEL_EVENTS.enable(shape=watch)
+        for _ in range(2):
+            trainer.gan_step(lr, hr)
     kern = ops.KERNEL_EVENTS.drain()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -283,6 +296,7 @@ def main():
         "step_tflops_per_gpu": round(value / world * flop_patch / 1e12, 2),
         "step_frac_of_mfma_peak": round(value / world * flop_patch / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         "losses": {k: float(v) for k, v in logs.items()},
+        "hip_graph": bool(use_graph),
     }
     if kern:
         out.update(roofline_objects(args, kern))

@@ -218,6 +218,13 @@ int pesr_psnr_y(const float* a, const float* b, double* out2, int H, int W, int 
 int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    int step, float grad_scale, void* stream);
 
+/* The same Adam step with its step-dependent scalars in DEVICE memory, for hipGraph replay (a captured launch replays its kernel
+ * arguments): state = 6 floats {lr, unused, lr/bc1, sqrt(bc2), step count low 32 bits, high 32 bits (bit patterns)}.  The call
+ * first advances the step count and recomputes state[2..3] in double (reference train.py:124-125 / torch.optim.Adam's
+ * bias_correction1/2), then applies the update.  The host writes state[0] (StepLR, reference train.py:127-128) between replays. */
+int pesr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* state, float beta1, float beta2, float eps,
+                       float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ SIGNATURES.update({
     "pesr_crop_augment": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "pesr_psnr_y": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "pesr_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
+    "pesr_adam_step_dev": (c_int, [_P, _P, _P, _P, c_long, _P, c_float, c_float, c_float, c_float, _P]),
 })
 
 _lib = None

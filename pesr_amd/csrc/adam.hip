@@ -34,3 +34,47 @@ int pesr_adam_launch(float* p, const float* g, float* m, float* v, long n, float
                        1.0f - b2, step_size, bc2_sqrt, eps, gscale);
     return pesr_launch_status();
 }
+
+// ---- the same update with its step-dependent scalars read from device memory ------------------------------------------------
+// For hipGraph replay (Trainer.capture_gan_step): a captured launch replays its kernel arguments, so the step count and the
+// learning rate must not be among them.  state[0] = learning rate (written by the host between replays), state[1] = step count
+// (as a float-exact integer < 2^24 would overflow in long runs: kept as two 32-bit halves in state[4..5]), state[2] = lr / bc1,
+// state[3] = sqrt(bc2).  adam_tick_kernel advances the count and refreshes state[2..3] in double, like the host path.
+__global__ void adam_tick_kernel(float* __restrict__ state, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long t = ((unsigned long long)__float_as_uint(state[5]) << 32) | __float_as_uint(state[4]);
+    t += 1;
+    state[4] = __uint_as_float((unsigned)(t & 0xffffffffu));
+    state[5] = __uint_as_float((unsigned)(t >> 32));
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    state[2] = (float)((double)state[0] / bc1);
+    state[3] = (float)sqrt(bc2);
+}
+__global__ void adam_dev_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v, long n4,
+                                float one_minus_b1, float b2, float one_minus_b2, const float* __restrict__ state, float eps, float gscale) {
+    const float step_size = state[2], bc2_sqrt = state[3];
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        const f32x4 gg = g[e] * gscale;
+        f32x4 mm = m[e], vv = v[e], pp = p[e];
+        mm = mm + (gg - mm) * one_minus_b1;
+        vv = vv * b2 + gg * gg * one_minus_b2;
+        f32x4 den;
+        den.x = sqrtf(vv.x) / bc2_sqrt + eps; den.y = sqrtf(vv.y) / bc2_sqrt + eps;
+        den.z = sqrtf(vv.z) / bc2_sqrt + eps; den.w = sqrtf(vv.w) / bc2_sqrt + eps;
+        pp.x -= step_size * (mm.x / den.x); pp.y -= step_size * (mm.y / den.y);
+        pp.z -= step_size * (mm.z / den.z); pp.w -= step_size * (mm.w / den.w);
+        p[e] = pp; m[e] = mm; v[e] = vv;
+    }
+}
+
+int pesr_adam_dev_launch(float* p, const float* g, float* m, float* v, long n, float* state, float b1, float b2, float eps, float gscale,
+                         hipStream_t stream) {
+    if (n % 4 || !state) return PESR_EINVAL;
+    const long n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, state, b1, b2);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, stream, (f32x4*)p, (const f32x4*)g, (f32x4*)m, (f32x4*)v, n4, 1.0f - b1, b2,
+                       1.0f - b2, (const float*)state, eps, gscale);
+    return pesr_launch_status();
+}

@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 6; }
+PESR_API int pesr_abi_version(void) { return 7; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -149,6 +149,11 @@ PESR_API int pesr_mse_fwd_bwd(const float* a, const float* b, float* grad, float
 PESR_API int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                             int step, float grad_scale, void* stream) {
     return pesr_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
+}
+
+PESR_API int pesr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* state, float beta1, float beta2, float eps,
+                                float grad_scale, void* stream) {
+    return pesr_adam_dev_launch(p, g, m, v, n, state, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
 }
 
 PESR_API int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout,

@@ -576,6 +576,16 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     _lib.check(rc, "pesr_adam_step")
 
 
+def adam_step_dev(p, g, m, v, state, beta1, beta2, eps, grad_scale=1.0):
+    """Adam step whose learning rate and step count live in the 6-float device tensor `state` (include/pesr_hip.h): safe to
+    capture in a hipGraph - nothing that changes from step to step is a kernel argument."""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (state, "state")):
+        _chk(t, f"adam_step_dev.{n}")
+    assert state.numel() == 6
+    rc = _lib.lib().pesr_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(state), beta1, beta2, eps, grad_scale, _stream())
+    _lib.check(rc, "pesr_adam_step_dev")
+
+
 def psnr_y(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """Y-channel PSNR of two [1, 3, H, W] image tensors (NCHW-contiguous or channels_last) -> device double [mse, psnr]."""
     outs = []

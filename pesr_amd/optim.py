@@ -174,12 +174,35 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_p)
         self.buckets = GradBuckets(self.flat, process_group, bucket_bytes)
         self.steps = 0
+        self.dev_state = None        # use_device_state(): lr and step count in device memory (hipGraph replay)
+        self._dev_lr = None
         self.last_scale = 1.0        # the 1/world factor of the latest step (flat_g holds the SUM over ranks)
         PF.bump_weight_epoch(self.flat.params)
 
     def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: ARG002 (kept for API compatibility)
         self.flat.zero_grad()
         self.buckets.reset()
+
+    def use_device_state(self) -> torch.Tensor:
+        """Move the step-dependent Adam scalars to device memory (include/pesr_hip.h pesr_adam_step_dev): from now on step()
+        launches nothing whose kernel arguments change from step to step, so a captured step can be replayed.  The host keeps
+        counting in self.steps (state_dict, logging); a replay that runs without step() must add to it itself."""
+        if self.dev_state is None:
+            st = torch.zeros(6, dtype=torch.float32, device=self.flat.flat_p.device)
+            st.view(torch.int32)[4] = self.steps & 0x7fffffff
+            st.view(torch.int32)[5] = self.steps >> 31
+            assert self.steps < (1 << 31)
+            self.dev_state = st
+            self.sync_lr_to_device()
+        return self.dev_state
+
+    def sync_lr_to_device(self) -> None:
+        """Write param_groups[0]['lr'] (StepLR) into the device state; a no-op while it is unchanged.  NOT capturable - call it
+        between replays."""
+        lr = float(self.param_groups[0]["lr"])
+        if self.dev_state is not None and lr != self._dev_lr:
+            self.dev_state[0:1].fill_(lr)
+            self._dev_lr = lr
 
     @torch.no_grad()
     def step(self, closure: Optional[Callable] = None):
@@ -191,7 +214,13 @@ class FlatAdam(torch.optim.Optimizer):
         scale = self.last_scale = self.buckets.finish()
         g = self.param_groups[0]
         self.steps += 1
-        ops.adam_step(self.flat.flat_p, self.flat.flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],
-                      g["betas"][1], g["eps"], self.steps, scale)
+        if self.dev_state is not None:
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_lr_to_device()
+            ops.adam_step_dev(self.flat.flat_p, self.flat.flat_g, self.exp_avg, self.exp_avg_sq, self.dev_state, g["betas"][0],
+                              g["betas"][1], g["eps"], scale)
+        else:
+            ops.adam_step(self.flat.flat_p, self.flat.flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],
+                          g["betas"][1], g["eps"], self.steps, scale)
         PF.bump_weight_epoch(self.flat.params)   # this optimizer's packed conv weights are now stale ...
         PF.repack_all(self.flat.params)          # ... and are refreshed here in one batched launch

@@ -35,6 +35,7 @@ class Trainer:
         self.world_size = world_size
         self.gradient_penalty = gradient_penalty       # reference --GP (train.py:216-226), default off
         self._targets = {}
+        self._graph = None
 
     def _target(self, batch, value, device):
         key = (batch, value, device)
@@ -122,3 +123,45 @@ class Trainer:
         if gp is not None:
             logs["gp"] = gp.detach()
         return logs
+
+    # ---- the GAN step as ONE hipGraph ------------------------------------------------------------------------------------
+    def capture_gan_step(self, lr, hr):
+        """Capture gan_step(lr, hr) - ~1000 kernel launches - into a hipGraph (torch.cuda.CUDAGraph on ROCm) and return
+        gan_step_graphed.  Call it after at least one eager gan_step at the same shapes (first-use work - weight packing,
+        workspace growth, descriptor tables - must not happen under capture).  The capture itself executes nothing.
+
+        What makes the step replayable: every kernel is launched on torch's current stream through the C ABI; the losses stay
+        on the device; the two Adam steps read the learning rate and step count from device memory
+        (FlatAdam.use_device_state); the packed conv weights are refreshed by launches that are part of the captured sequence.
+        Single-process only: the bucketed RCCL all-reduce of the data-parallel path runs on its own stream from autograd hooks
+        and is left to eager mode."""
+        from . import ops
+        assert self.world_size == 1, "graph capture covers the single-GPU step"
+        assert not self.gradient_penalty, "the gradient-penalty step draws torch.rand inside the step: eager only"
+        for o in (self.optim_D, self.optim_G):
+            o.use_device_state()
+        self._g_lr, self._g_hr = lr.clone(), hr.clone()
+        steps = (self.optim_D.steps, self.optim_G.steps)
+        watched, ops.KERNEL_EVENTS.shape = ops.KERNEL_EVENTS.shape, None       # no timing events inside a graph
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+                self._g_logs = self.gan_step(self._g_lr, self._g_hr)
+        finally:
+            ops.KERNEL_EVENTS.shape = watched
+            self.optim_D.steps, self.optim_G.steps = steps                      # nothing ran: the host count must not move
+        return self.gan_step_graphed
+
+    def gan_step_graphed(self, lr, hr):
+        """Replay the captured step on a new batch (same shapes).  Returns the same dict of device scalars as gan_step; they are
+        overwritten by the next replay."""
+        assert self._graph is not None, "capture_gan_step first"
+        for o in (self.optim_D, self.optim_G):
+            o.sync_lr_to_device()
+        self._g_lr.copy_(lr, non_blocking=True)
+        self._g_hr.copy_(hr, non_blocking=True)
+        self._graph.replay()
+        self.optim_D.steps += 1
+        self.optim_G.steps += 1
+        return self._g_logs

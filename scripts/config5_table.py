@@ -5,7 +5,7 @@ src, out = sys.argv[1], sys.argv[2]
 B = 4
 algo = {   # kernel-name substring -> (layer, algorithmic bytes per launch)
     "conv_rgb_in_kernel": ("embed 3->256 @512x512 (reads 3 ch, writes 256 ch)", B * 512 * 512 * (3 + 256) * 4),
-    "conv3x3_mfma_kernel<4, 1, 4": ("upsample.4 256->3 @2048x2048 (reads 256 ch, writes 3 ch)", B * 2048 * 2048 * (256 + 3) * 4),
+    "conv_rgb_out_kernel": ("upsample.4 256->3 @2048x2048 (reads 256 ch, writes 3 ch)", B * 2048 * 2048 * (256 + 3) * 4),
     "meanshift_fwd_kernel": None,
 }
 rows = list(csv.DictReader(open(src)))

@@ -433,3 +433,29 @@ def test_gv11_gradient_penalty_step_vs_reference():
             assert int(v) == 5
         elif "running" not in k:
             adam_close(v.reshape(-1)[torch.from_numpy(g["pidx." + k]).cuda()], g["pval." + k], 5e-5, 1, "D." + k)
+
+
+def test_gan_step_hipgraph_replay_is_bit_identical_to_eager():
+    """Trainer.capture_gan_step: three replayed GAN steps (new batch each) leave the same losses and the same G / D parameters,
+    bit for bit, as three eager steps from the same state - the two Adam steps read lr and the step count from device memory,
+    so nothing step-dependent is baked into the captured launches.  Includes an lr change between replays (StepLR)."""
+    tra, Ga, Da = _trainer(16, 2, 8)
+    trb, Gb, Db = _trainer(16, 2, 8)
+    data = [(detrand.image_batch((4, 3, 8, 8), 50 + i).cuda(), detrand.image_batch((4, 3, 32, 32), 60 + i).cuda()) for i in range(5)]
+    for lr, hr in data[:2]:
+        tra.gan_step(lr, hr); trb.gan_step(lr, hr)
+    step = trb.capture_gan_step(*data[0])
+    assert trb.optim_G.steps == tra.optim_G.steps == 2          # the capture itself executes nothing
+    for i, (lr, hr) in enumerate(data[2:]):
+        if i == 2:
+            for t in (tra, trb):
+                t.optim_G.param_groups[0]["lr"] *= 0.5; t.optim_D.param_groups[0]["lr"] *= 0.5
+        la, lb = tra.gan_step(lr, hr), step(lr, hr)
+        for k in la:
+            assert la[k].item() == lb[k].item(), (i, k, la[k].item(), lb[k].item())
+    assert trb.optim_G.steps == tra.optim_G.steps == 5
+    for pa, pb in zip(list(Ga.parameters()) + list(Da.parameters()), list(Gb.parameters()) + list(Db.parameters())):
+        assert torch.equal(pa, pb)
+    # eager steps keep working after the capture (device-state Adam) and stay in lock-step
+    la, lb = tra.gan_step(*data[0]), trb.gan_step(*data[0])
+    assert la["d"].item() == lb["d"].item() and torch.equal(next(Ga.parameters()), next(Gb.parameters()))
