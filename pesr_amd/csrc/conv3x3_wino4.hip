@@ -48,6 +48,9 @@ struct Wino4Args {
     int ksplit;         // > 1: the Cin chunks are split over ksplit workgroups per tile; raw partial sums go to slab[ks][...]
     int chunks_per_split;
     float* slab;
+    int stack;          // 0, or H + 1: the N images are tiled as ONE image of N * (H + 1) - 1 rows, a zero row between neighbours
+    int stack_n;        //   (that row is the bottom halo of one image and the top halo of the next); N above is then 1
+    int v_row;          // bytes of one V row: 6 * TXT * 64, plus the pad of the dense layout
 };
 
 constexpr int W4_BN = 64, W4_MG = 9;
@@ -61,6 +64,12 @@ PESR_API int pesr_debug_timing_wino4(unsigned long long* host, int n) {
 }
 #endif
 
+// DENSE = false: the swizzle key of the rows of 8 / 12 / 16 / 24 x-tiles (the layers that matter), a_off ^ kxor for odd ky.
+// DENSE = true: any row length.  A V row is padded so that the 64-byte entries of consecutive x-tiles m = row * TXT + txt of one
+// xi plane fall into 64-byte slots m mod 4 of the 256-byte bank window, and the 16-byte sub-slot is rotated by (m >> 2) & 3:
+// the 16 lanes of a fragment read (16 consecutive m) then touch every bank once.  The key of the row ky below is a different
+// function of the lane, so its XOR with the ky = 0 key comes from two packed per-lane tables (2 bits per m-tile and ky).
+template <bool DENSE>
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     PESR_STAMP(w4_timing, 0);
     PESR_STAMP_CLK(w4_timing, 6);
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     constexpr int NU = 2;                                  // staging items per thread (HT * TXT * 4 <= NU * NT)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int plane = a.TXT * 64;                          // bytes of one xi plane of a V row
-    const int v_row = 6 * plane;
+    const int v_row = a.v_row;
     const int v_bytes = a.HT * v_row;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,11 +107,19 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
 
     // ---- A fragment offsets: lane (r, g) reads k-group g of x-tile m = 16 i + r (for an even ky; odd ky: ^ kxor) -------------
     int a_off[W4_MG];
+    unsigned ktab1 = 0, ktab2 = 0;                         // DENSE: (key(ky) ^ key(0)) << 4 for m-tile i at bits [2i + 4, 2i + 6)
 #pragma unroll
     for (int i = 0; i < W4_MG; ++i) {
         const int m = i * 16 + r;
         const int trow = m / a.TXT, txt = m - trow * a.TXT;
-        a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
+        if (DENSE) {
+            const int k0 = (m >> 2) & 3;
+            a_off[i] = trow * v_row + txt * 64 + ((g ^ k0) & 3) * 16;
+            ktab1 |= (unsigned)((((m + a.TXT) >> 2) & 3) ^ k0) << (2 * i + 4);
+            ktab2 |= (unsigned)((((m + 2 * a.TXT) >> 2) & 3) ^ k0) << (2 * i + 4);
+        } else {
+            a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
+        }
     }
     const int kxor = a.row_key * 16;                       // the key's row term flips with the parity of ky
 
@@ -115,7 +132,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     };
 
     // ---- staging items: (halo row, x-tile, 4-channel group); six input columns each; NU items per thread --------------------
-    const float* const x_img = a.x + (size_t)img * a.H * a.W * a.Cin;
+    const float* const x_img = a.x + (size_t)img * a.H * a.W * a.Cin;    // stacked: img == 0, rows run over all images
     const int n_items = a.HT * a.TXT * 4;
     const int Cq = a.Cin >> 2;
     // Out-of-image columns (and whole halo rows) are fetched at offset 2^31, beyond the buffer descriptor's range: the load
@@ -127,8 +144,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         const int it = tid + u * NT;
         const int q = it & 3, rest = it >> 2;
         const int hrow = rest / a.TXT, txt = rest - hrow * a.TXT;
-        const int iy = gy0 - 1 + hrow, ix0 = 4 * (gt0 + txt) - 1;
-        const bool item_ok = it < n_items && iy >= 0 && iy < a.H;
+        int iy = gy0 - 1 + hrow;
+        const int ix0 = 4 * (gt0 + txt) - 1;
+        bool item_ok = it < n_items && iy >= 0 && iy < a.H;
+        if (a.stack) {                                      // virtual row -> (image, row); the separator rows read zeros
+            const int im = iy / a.stack, yy = iy - im * a.stack;
+            item_ok = it < n_items && iy >= 0 && im < a.stack_n && yy < a.H;
+            iy = im * a.H + yy;
+        }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int ix = ix0 + j;
@@ -136,10 +159,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
             st_off[u][j] = ok ? (unsigned)((pix + q * 4) * 4) : 0x80000000u;
         }
-        st_dst[u] = it < n_items ? hrow * v_row + txt * 64 + ((q ^ (txt >> 1) ^ (a.row_key * (hrow & 1))) & 3) * 16 : -1;
+        const int skey = DENSE ? ((hrow * a.TXT + txt) >> 2) : ((txt >> 1) ^ (a.row_key * (hrow & 1)));
+        st_dst[u] = it < n_items ? hrow * v_row + txt * 64 + ((q ^ skey) & 3) * 16 : -1;
     }
     const __amdgpu_buffer_rsrc_t x_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)x_img, 0, (unsigned)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)x_img, 0, (unsigned)((size_t)(a.stack ? a.stack_n : 1) * a.H * a.W * a.Cin * 4), 0x00020000);
     auto chunk_off = [&](int cc) -> int {                  // channel part of an input address (bytes), chunk cc (absolute)
         int coff = cc * 16;
         if (a.ps_in) {   // chunk = channels [16cc, 16cc+16) of sub-pixel `sub`: one pixel of the shuffled tensor
@@ -182,11 +206,19 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     f32x4 fa[2][3], fb[3];
     // the xor of the odd-ky reads is redone at every use: hoisted out of the loop it would cost nine more live registers
     auto opaque = [](int v) -> int { asm volatile("" : "+s"(v)); return v; };
+    auto a_key = [&](const int i, const int ky) -> int {   // fragment offset of m-tile i for the V row ky below the tile row
+        if (DENSE) {
+            if (ky == 0) return a_off[i];
+            const unsigned tab = ky == 1 ? ktab1 : ktab2;
+            return a_off[i] ^ (int)((tab >> (2 * i)) & 0x30u);
+        }
+        return (ky & 1) ? (a_off[i] ^ opaque(kxor)) : a_off[i];
+    };
 #define W4_READ_A(FA, VB, KY, XL, GRP)                                                                   \
     {                                                                                                    \
         const char* const vb_ = (VB) + (KY) * v_row + xi_of(XL) * plane;                                 \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
-            FA[i] = *(const f32x4*)(vb_ + (((KY) & 1) ? (a_off[(GRP) * 3 + i] ^ opaque(kxor)) : a_off[(GRP) * 3 + i])); \
+            FA[i] = *(const f32x4*)(vb_ + a_key((GRP) * 3 + i, KY));                                      \
     }
 #define W4_MFMA(FA, FB, XL, GRP)                                                                         \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
@@ -304,8 +336,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             const int i = ib + (e >> 1), k = e & 1;
             const int m = i * 16 + r;
             const int trow = m / a.TXT, txt = m - trow * a.TXT;
-            const int oy = gy0 + trow, ox = 4 * (gt0 + txt) + 2 * xt + k;
+            int oy = gy0 + trow;
+            const int ox = 4 * (gt0 + txt) + 2 * xt + k;
             ok[e] = oy < a.H && ox < a.W;
+            if (a.stack) {                                  // virtual row -> row of the [N * H] row space; separator rows are dropped
+                const int im = oy / a.stack, yy = oy - im * a.stack;
+                ok[e] = im < a.stack_n && yy < a.H && ox < a.W;
+                oy = im * a.H + yy;
+            }
             // same order of additions as a sequential y = (xi 0..2 part) + (xi 3..5 part)
             v[e] = xt == 0 ? keep[i][k] + *(const f32x4*)slot(1, i, k) : *(const f32x4*)slot(0, i, k) + keep[i][k];
             if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
@@ -326,7 +364,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             if (!ok[e]) continue;
             f32x4 o = v[e];
             if (a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
-                *(f32x4*)(a.slab + (size_t)ks * ((size_t)a.N * a.H * a.W * a.Cout) + idx[e]) = o;
+                *(f32x4*)(a.slab + (size_t)ks * ((size_t)(a.stack ? a.stack_n : a.N) * a.H * a.W * a.Cout) + idx[e]) = o;
                 continue;
             }
             if (a.bias) o += bias4;
@@ -366,52 +404,77 @@ int pesr_pack_conv3x3_wino4_launch(const float* w, float* out, int O, int I, int
 }
 
 namespace {
-struct W4Plan { int TR, TXT, tiles_x, tiles_y, n_tiles, ksplit, chunks_per_split; long tiles; size_t lds; int score; };
+struct W4Plan { int TR, TXT, tiles_x, tiles_y, n_tiles, ksplit, chunks_per_split; long tiles; size_t lds; int score; int stack, dense, v_row; };
+
+static bool w4_clean(int TXT) { return TXT == 12 || TXT == 8 || TXT == 16 || TXT == 24; }   // rows the non-dense swizzle key serves
+static int w4_v_row(int TXT) {   // bytes of a V row; other row lengths use the dense layout, padded to TXT * 64 (mod 256)
+    const int raw = 6 * TXT * 64;
+    return w4_clean(TXT) ? raw : raw + (256 - (5 * TXT * 64) % 256) % 256;
+}
 
 // Tile shape TR x TXT == 144 x-tiles with the least out-of-image area that fits LDS (two V buffers) and the 2 staging items per
-// thread; split-K over the Cin chunks when the tiles alone cannot fill the 256 CUs.  score = per-mille of the tiles' x-tile
-// slots that lie inside the image, or 0 when the shape is not supported or yields fewer than 192 workgroups.
-static bool w4_plan(int N, int H, int W, int Cin, int Cout, bool allow_split, size_t ws_bytes, W4Plan* p) {
-    if (N < 1 || H < 1 || W < 4 || W % 4 || Cin % 16 || Cin < 16 || Cout % W4_BN) return false;
-    if ((size_t)H * W * Cin * 4 >= ((size_t)1 << 31)) return false;   // one image per buffer descriptor, offsets below 2^31
+// thread, for NI images of HI rows (stacked: one image of all rows, `real_rows` of them real); split-K over the Cin chunks when
+// the tiles alone cannot fill the 256 CUs.  score = per-mille of the tiles' x-tile slots that hold real pixels, or 0 when the
+// shape yields fewer than 192 workgroups.
+static bool w4_plan_one(int NI, int HI, long real_rows, int W, int Cin, int Cout, bool allow_split, size_t ws_bytes, size_t out_bytes,
+                        W4Plan* p) {
     const int XT = W / 4;
     long best = -1;
     for (int TXT = 1; TXT <= 144; ++TXT) {
         if (144 % TXT) continue;
         const int TR = 144 / TXT, HT = TR + 2;
-        const size_t vb = (size_t)2 * HT * 6 * TXT * 64;
+        const size_t vb = (size_t)2 * HT * w4_v_row(TXT);
         if (vb > 160 * 1024 || HT * TXT * 4 > 2 * 512) continue;  // two staging items per thread
-        const long cover = (long)pesr_cdiv(H, TR) * TR * pesr_cdiv(XT, TXT) * TXT;
-        // least waste first; then a row length whose fragment reads are bank-conflict free with the kernel's swizzle key
-        // (measured with scripts/lds_bank_probe.hip: TXT = 12 with the row term, 8 / 16 / 24 without; a 3-x-tile row costs
-        // 14 LDS cycles per ds_read_b128 instead of 4); then the smallest halo
-        const bool clean = TXT == 12 || TXT == 8 || TXT == 16 || TXT == 24;
-        const long score = cover * 8192 + (clean ? 0 : 4096) + (long)HT * TXT;
+        const long cover = (long)pesr_cdiv(HI, TR) * TR * pesr_cdiv(XT, TXT) * TXT;
+        // least waste first; then a row length served by the cheaper non-dense key (conflict-free for 12 with the row term and
+        // for 8 / 16 / 24 without, scripts/lds_bank_probe.hip); then the smallest halo
+        const long score = cover * 8192 + (w4_clean(TXT) ? 0 : 4096) + (long)HT * TXT;
         if (best < 0 || score < best) { best = score; p->TR = TR; p->TXT = TXT; }
     }
     if (best < 0) return false;
-    p->tiles_y = pesr_cdiv(H, p->TR); p->tiles_x = pesr_cdiv(XT, p->TXT); p->n_tiles = Cout / W4_BN;
-    p->tiles = (long)N * p->tiles_y * p->tiles_x * p->n_tiles;
-    const size_t vb = (size_t)2 * (p->TR + 2) * 6 * p->TXT * 64, ob = (size_t)2 * W4_MG * 2 * 4 * 64 * 16;   // the epilogue's exchange slots
+    p->dense = !w4_clean(p->TXT);
+    p->v_row = w4_v_row(p->TXT);
+    p->tiles_y = pesr_cdiv(HI, p->TR); p->tiles_x = pesr_cdiv(XT, p->TXT); p->n_tiles = Cout / W4_BN;
+    p->tiles = (long)NI * p->tiles_y * p->tiles_x * p->n_tiles;
+    const size_t vb = (size_t)2 * (p->TR + 2) * p->v_row, ob = (size_t)2 * W4_MG * 2 * 4 * 64 * 16;   // the epilogue's exchange slots
     p->lds = vb > ob ? vb : ob;
     const int C16T = Cin / 16;
     p->ksplit = 1; p->chunks_per_split = C16T;
-    const size_t out_bytes = (size_t)N * H * W * Cout * sizeof(float);
     if (allow_split && p->tiles < 160 && C16T >= 8) {
-        int want = (int)((256 + p->tiles - 1) / p->tiles);
-        if (want > 8) want = 8;
-        if (want > C16T / 4) want = C16T / 4;
-        while (want > 1 && (size_t)want * out_bytes > ws_bytes) --want;
-        if (want > 1) {
-            p->chunks_per_split = (C16T + want - 1) / want;
-            p->ksplit = (C16T + p->chunks_per_split - 1) / p->chunks_per_split;
+        // the split that minimises (rounds of 256 workgroups) x (chunks per workgroup), each workgroup's prologue + epilogue
+        // counted as one more chunk; at least 4 chunks per slice
+        long best_cost = -1;
+        for (int want = 1; want <= 8 && want <= C16T / 4; ++want) {
+            if (want > 1 && (size_t)want * out_bytes > ws_bytes) break;
+            const int cps = (C16T + want - 1) / want, ks = (C16T + cps - 1) / cps;
+            const long cost = ((p->tiles * ks + 255) / 256) * (cps + 1);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; p->chunks_per_split = cps; p->ksplit = ks; }
         }
     }
     // The F(2,3) kernel's tiles (288 pixels x 128 channels) give the same workgroup count, so chip fill does not separate the
     // two; below ~3/4 of a round neither beats the direct kernel's smaller tiles.
     const long wgs = p->tiles * p->ksplit;
-    const double cover_eff = (double)((long)H * XT) / ((double)p->tiles_y * p->TR * p->tiles_x * p->TXT);
+    const double cover_eff = (double)(real_rows * XT) / ((double)NI * p->tiles_y * p->TR * p->tiles_x * p->TXT);
     p->score = wgs >= 192 ? (int)(1000.0 * cover_eff) : 0;
+    return true;
+}
+
+// Images shorter than a tile waste most of its rows (a 12 x 12 image fills a quarter of a 48-row x 3-x-tile tile).  When it pays,
+// the N images are laid out as ONE image of N * (H + 1) - 1 rows with a zero row between neighbours - the bottom halo of one
+// image and the top halo of the next - and tiled together (allow_stack: not with a fused PixelShuffle on either side).
+static bool w4_plan(int N, int H, int W, int Cin, int Cout, bool allow_split, size_t ws_bytes, bool allow_stack, W4Plan* p) {
+    if (N < 1 || H < 1 || W < 4 || W % 4 || Cin % 16 || Cin < 16 || Cout % W4_BN) return false;
+    if ((size_t)H * W * Cin * 4 >= ((size_t)1 << 31)) return false;   // one image per buffer descriptor, offsets below 2^31
+    const size_t out_bytes = (size_t)N * H * W * Cout * sizeof(float);
+    if (!w4_plan_one(N, H, (long)N * H, W, Cin, Cout, allow_split, ws_bytes, out_bytes, p)) return false;
+    p->stack = 0;
+    if (allow_stack && N > 1 && (size_t)N * H * W * Cin * 4 < ((size_t)1 << 31)) {
+        W4Plan q;
+        if (w4_plan_one(1, N * (H + 1) - 1, (long)N * H, W, Cin, Cout, allow_split, ws_bytes, out_bytes, &q) && q.score > p->score + 50) {
+            *p = q;
+            p->stack = H + 1;
+        }
+    }
     return true;
 }
 }  // namespace
@@ -420,7 +483,7 @@ static bool w4_plan(int N, int H, int W, int Cin, int Cout, bool allow_split, si
 // passes the split-K workspace.
 int pesr_conv3x3_wino4_score_impl(int N, int H, int W, int Cin, int Cout, int allow_split) {
     W4Plan p;
-    if (!w4_plan(N, H, W, Cin, Cout, allow_split != 0, (size_t)-1, &p)) return 0;
+    if (!w4_plan(N, H, W, Cin, Cout, allow_split != 0, (size_t)-1, true, &p)) return 0;
     return p.score;
 }
 
@@ -428,7 +491,7 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
                               int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
                               void* ws, size_t ws_bytes, hipStream_t stream) {
     W4Plan p;
-    if (!w4_plan(N, H, W, Cin, Cout, ws != nullptr && !ps, ws_bytes, &p)) return PESR_EINVAL;
+    if (!w4_plan(N, H, W, Cin, Cout, ws != nullptr && !ps, ws_bytes, !ps && !ps_in, &p)) return PESR_EINVAL;
     if (ps && (Cout % 256 || skip || mask)) return PESR_EINVAL;    // a 64-channel n-tile must stay inside one sub-pixel plane
     if (ps_in && Cin % 64) return PESR_EINVAL;
     Wino4Args a{};
@@ -439,12 +502,16 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
     a.row_key = (p.TXT % 8 == 4) ? 2 : 0;
     a.ksplit = p.ksplit; a.chunks_per_split = p.chunks_per_split; a.slab = (float*)ws;
+    a.stack = p.stack; a.stack_n = N; a.v_row = p.v_row;
+    if (p.stack) a.N = 1;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
+    if (p.dense) hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
+    else hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
     if (p.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, act,
                                               slope, stream);

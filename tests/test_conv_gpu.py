@@ -209,6 +209,11 @@ WINO4_CASES = [
     (1, 9, 196, 16, 64),      # wider than one tile
     (16, 24, 24, 512, 512),   # few tiles: split-K over the Cin chunks + finish kernel
     (1, 30, 20, 48, 192),     # 5 x-tiles per row, Cin not a multiple of 64
+    (16, 12, 12, 512, 512),   # VGG conv5_x: 16 images stacked into one 207-row image (zero separator rows), 3-x-tile rows in
+                              # the dense LDS layout, split-K
+    (3, 12, 12, 128, 64),     # stacked, no split-K, odd image count
+    (5, 6, 8, 64, 64),        # stacked, 2 x-tiles per row
+    (4, 9, 20, 64, 128),      # stacked candidate with 5-x-tile rows (tile rows of 4 / 6 x-tiles: ragged in x as well)
 ]
 
 
@@ -307,7 +312,8 @@ def test_winograd_dispatch_rule():
     assert ops.wino4_eligible(16, 24, 24, 512, 512)             # split-K fills the chip
     assert ops.wino4_eligible(16, 96, 96, 256, 1024, ps_out=True)
     assert not ops.wino4_eligible(16, 48, 50, 256, 256)         # width not a multiple of 4
-    assert not ops.wino4_eligible(16, 12, 12, 512, 512)         # 36 x-tiles per image: tiles would span images
+    assert ops.wino4_eligible(16, 12, 12, 512, 512)             # 36 x-tiles per image: the 16 images are stacked into one (80 % cover)
+    assert not ops.wino4_eligible(2, 12, 12, 512, 512)          # too few workgroups even stacked
     assert not ops.wino4_eligible(1, 48, 48, 256, 256)          # 16 workgroups: the direct kernel's small tiles instead
     assert not ops.wino4_eligible(16, 48, 48, 256, 256, stride=2)
 

@@ -99,10 +99,15 @@ def test_n_rank_gan_steps_vs_full_batch_oracle(nproc, tmp_path):
     cfg = {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5, "dp_replicas": nproc}
     st = OS.TrainState(gen_sd(C, depth), dis_sd(ps), vgg_sd(), cfg)
     # The GAN step's gradients are ill-conditioned in fp32 (LeakyReLU / ReLU kinks, BatchNorm over 4-sample shards): a rounding-
-    # level change anywhere flips masks and moves whole gradient tensors.  The tolerance is therefore MEASURED here, per tensor:
-    # the fp32 oracle is re-run with every weight perturbed by one relative ulp (w * (1 +- 2^-23), three draws), and our
-    # gradient may differ from the oracle's by at most 5 x the spread those one-ulp perturbations produce (and 1e-4 of the
-    # tensor's maximum where the spread is smaller).  The exchange itself is pinned bit-exactly by the test above.
+    # level change anywhere - another summation order in one conv is enough - flips masks and moves whole gradient tensors.
+    # scripts/dp_grad_diag.py measures it for this configuration: over six batches and four kernel dispatches (default, no
+    # C->3 kernel, no F(4,3), direct kernels only) the worst per-tensor distance to the fp32 oracle is 2e-2 .. 6e-2 of the
+    # tensor's maximum for EVERY dispatch, with an occasional 2e-3, while the sr images themselves agree with float64 to
+    # 3..5e-5 (one ulp at 100 is 8e-6).  One-ulp weight perturbations of the oracle (three draws below) move the gradients by
+    # ~1e-3: a lower bound of the noise, not the noise.  The allowance per tensor is therefore the larger of 5 x that spread and
+    # 0.1 of the tensor's maximum - this comparison can only catch what data-parallel bugs produce (a missing 1/N, a wrong
+    # shard, a dropped bucket: errors of order one); the exchange itself is pinned bit-exactly by the test above and the
+    # losses, which are well conditioned, at 5e-5 below.
     def perturbed(sd, seed):
         gen = torch.Generator().manual_seed(seed)
         return {k: (v * (1.0 + (torch.randint(0, 2, v.shape, generator=gen).to(v.dtype) * 2 - 1) * 2.0 ** -23)
