@@ -127,8 +127,9 @@ class Trainer:
     # ---- the GAN step as ONE hipGraph ------------------------------------------------------------------------------------
     def capture_gan_step(self, lr, hr):
         """Capture gan_step(lr, hr) - ~1000 kernel launches - into a hipGraph (torch.cuda.CUDAGraph on ROCm) and return
-        gan_step_graphed.  Call it after at least one eager gan_step at the same shapes (first-use work - weight packing,
-        workspace growth, descriptor tables - must not happen under capture).  The capture itself executes nothing.
+        gan_step_graphed.  Call it after at least TWO eager gan_steps at the same shapes: first-use work - weight packing,
+        workspace growth, the re-pack descriptor tables (the second step's table lists the packings the first step created late,
+        in its backward pass) - must not happen under capture.  The capture itself executes nothing.
 
         What makes the step replayable: every kernel is launched on torch's current stream through the C ABI; the losses stay
         on the device; the two Adam steps read the learning rate and step count from device memory

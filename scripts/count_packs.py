@@ -27,4 +27,4 @@ for k, v in sorted(cnt.items(), key=lambda kv: -kv[1]): print(v, k)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     trainer.gan_step(lr, hr); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=70, max_name_column_width=60))

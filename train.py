@@ -60,7 +60,7 @@ def build_parser():
                         "perceptual loss is then NOT the reference's)")
     p.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (smoke runs)")
     p.add_argument("--hip_graph", type=str2bool, default=False,
-                   help="GAN phase on one GPU: capture the step into a hipGraph after the first eager iteration and replay it "
+                   help="GAN phase on one GPU: capture the step into a hipGraph after two eager iterations and replay it "
                         "(same results bit for bit; the host no longer issues ~1000 launches per step)")
     p.add_argument("--gpu_pipeline", type=str2bool, default=False,
                    help="keep the uint8 training images in HBM and crop/augment on the GPU (pesr_amd.input_pipeline)")
@@ -233,7 +233,7 @@ def main(argv=None):
             pass
     best_psnr = 0.0
     keys = ("l1", "vgg", "g", "tv", "d") if gan else ("l1",)
-    graphed, graph_shapes = None, None
+    graphed, graph_shapes, eager_at_shape = None, None, 0
 
     for epoch in range(1, args.num_epochs + 1):
         # The reference calls scheduler.step() at epoch START (train.py:156,185-186); under its pinned torch 0.4 the
@@ -251,8 +251,13 @@ def main(argv=None):
             else:
                 logs = trainer.gan_step(lr_img, hr_img) if gan else trainer.pretrain_step(lr_img, hr_img)
                 if gan and args.hip_graph and world == 1 and not args.GP and graphed is None and device.type == "cuda":
-                    graph_shapes = (lr_img.shape, hr_img.shape)     # one eager step done at these shapes: capture the next ones
-                    graphed = trainer.capture_gan_step(lr_img, hr_img)
+                    # capture after TWO eager steps at these shapes: the second one has seen every weight packing the first one
+                    # created (some only in its backward pass), so nothing is allocated or uploaded under capture
+                    shapes = (lr_img.shape, hr_img.shape)
+                    eager_at_shape = eager_at_shape + 1 if shapes == graph_shapes else 1
+                    graph_shapes = shapes
+                    if eager_at_shape >= 2:
+                        graphed = trainer.capture_gan_step(lr_img, hr_img)
             running += torch.stack([logs[k].float() for k in keys])
             iters += 1
             if args.max_iters and iters >= args.max_iters:
