@@ -126,13 +126,24 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     const unsigned x_row_bytes = (unsigned)a.W * a.Cin * 4;
     // a dy row of the shuffled tensor spans the two sub-pixel rows 2oy, 2oy+1: 2 * (2W) * (Cout/4) floats = W * Cout as well
     const unsigned d_row_bytes = (unsigned)a.W * a.Cout * 4;
-    auto load_v = [&](int img, int iy) {                   // input row iy (may lie outside the image: zeros)
+    // A wave's descriptor must be wave-uniform - or hipcc wraps every buffer load in a waterfall loop (it did: 62 of them).  The
+    // two new V rows of a segment are spread over threads 0..95 / 96..191, i.e. they MIX inside wave 1: the V descriptor
+    // therefore spans both rows (base = the first one, which may lie outside the image: nothing is fetched through it then) and
+    // a lane adds its row's pitch, or 2^31 when its row is outside the image.  dM rows change at a wave boundary (thread 320).
+    auto uniform_ptr = [](const float* p) -> const float* {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const float*)(((unsigned long long)hi << 32) | lo);
+    };
+    auto load_v = [&](int img, int iy0) {                  // input rows iy0 (threads 0..95) and iy0 + 1 (96..191); outside the image: zeros
         if (wave < 3) {
+            const float* const rowp = a.x + ((long)img * a.H + iy0) * ((long)a.W * a.Cin);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0, 2 * x_row_bytes, 0x00020000);
+            const int iy = iy0 + v_rr;
             const bool row_ok = iy >= 0 && iy < a.H;
-            const float* const rowp = a.x + ((size_t)img * a.H + (row_ok ? iy : 0)) * a.W * a.Cin;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rowp, 0, row_ok ? x_row_bytes : 0u, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) vx[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, v_off[j], 0, 0);
+            for (int j = 0; j < 6; ++j)
+                vx[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? v_off[j] + (unsigned)v_rr * x_row_bytes : 0x80000000u, 0, 0);
         }
     };
     auto store_v = [&](int slot) {
@@ -163,7 +174,8 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             const int ry = row_ok ? oy : 0;
             const float* const rowp = a.ps_in ? a.dy + ((size_t)img * (2 * a.H) + 2 * ry) * (2 * a.W) * d_C
                                               : a.dy + ((size_t)img * a.H + ry) * a.W * a.Cout;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rowp, 0, row_ok ? d_row_bytes : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0,
+                                                                                __builtin_amdgcn_readfirstlane(row_ok ? d_row_bytes : 0u), 0x00020000);
 #pragma unroll
             for (int j = 0; j < 4; ++j) dd[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, d_off[j], 0, 0);
         }
@@ -197,8 +209,8 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
         xs = strip - img * a.segs_x;
     };
     auto stage_strip_start = [&](int img, int row, int buf) {   // halo rows row-1 .. row+2 -> slots 0 .. 3; dM(row, row+1) -> buf
-        load_v(img, row - 1 + v_rr); store_v(v_rr);
-        load_v(img, row + 1 + v_rr); store_v(2 + v_rr);
+        load_v(img, row - 1); store_v(v_rr);
+        load_v(img, row + 1); store_v(2 + v_rr);
         load_d(img, row + d_rr); store_d(buf);
     };
 
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     // Staging runs a full segment ahead of its ds_writes: the loads for segment s+1's new rows are issued at the store point
     // of segment s-1 (or right after a strip start) and land while segment s-1 / s computes; with the loads issued at the top
     // of segment s they were waited for a third of a segment later - under load an L2 / MALL round trip is longer than that.
-    if (seg_begin + 1 < seg_end && row + 2 < a.H) { load_v(img, row + 3 + v_rr); load_d(img, row + 2 + d_rr); }
+    if (seg_begin + 1 < seg_end && row + 2 < a.H) { load_v(img, row + 3); load_d(img, row + 2 + d_rr); }
     __syncthreads();
     PESR_STAMP(g4_timing, 1);
     int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
 #ifdef G4_ABL_LOADS
                     if (a.ps_in == 12345)
 #endif
-                    if (cont2) { load_v(img, row + 5 + v_rr); load_d(img, row + 4 + d_rr); }
+                    if (cont2) { load_v(img, row + 5); load_d(img, row + 4 + d_rr); }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             seg_coords(seg + 1, img, xs, row);
             set_strip(xs);
             stage_strip_start(img, row, par ^ 1);
-            if (seg + 2 < seg_end && row + 2 < a.H) { load_v(img, row + 3 + v_rr); load_d(img, row + 2 + d_rr); }
+            if (seg + 2 < seg_end && row + 2 < a.H) { load_v(img, row + 3); load_d(img, row + 2 + d_rr); }
             __syncthreads();
             PESR_STAMP(g4_timing, 5);
             base = 0;

@@ -80,7 +80,11 @@ __global__ __launch_bounds__(RO_NT) void conv_rgb_out_kernel(const RgbOutArgs a)
     auto row_rsrc = [&](int r) -> __amdgpu_buffer_rsrc_t {  // image row r of this band's image (an invalid row: empty descriptor)
         const bool ok = r >= 0 && r < a.H;
         const float* const rowp = a.x + ((size_t)img * a.H + (ok ? r : 0)) * a.W * a.C;
-        return __builtin_amdgcn_make_buffer_rsrc((void*)rowp, 0, ok ? row_bytes : 0u, 0x00020000);
+        const unsigned long long pv = (unsigned long long)rowp;                              // provably wave-uniform base: no waterfall loops
+        return __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pv >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pv)),     // (unsigned): the builtin returns int - no sign extension
+            0, __builtin_amdgcn_readfirstlane(ok ? row_bytes : 0u), 0x00020000);
     };
     __syncthreads();
 

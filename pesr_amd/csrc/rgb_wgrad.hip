@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256) void corr_rgb_mfma_kernel(const float* __restr
         const int buf = (row - r0) & 1;
         if (row + 1 < r1) stage_b(row + 1, buf ^ 1);                       // visible after the barrier at the end of this row
         const float* const bl = lds + buf * 3 * WP3;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)row * W * C), 0, row_bytes, 0x00020000);
+        const unsigned long long av = (unsigned long long)(A + (size_t)row * W * C);      // provably wave-uniform base: no waterfall loops
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(av >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)av)),     // (unsigned): the builtin returns int - no sign extension
+            0, row_bytes, 0x00020000);
         auto a_load = [&](int s) -> u32x4 {                                // k-step s: pixel 4 s + g (beyond the row: zeros)
             const int px = 4 * s + g;
             return __builtin_amdgcn_raw_buffer_load_b128(rs, px < W ? a_lane + (unsigned)px * C * 4 : 0x80000000u, 0, 0);
