@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--cpu_steps", type=int, default=3, help="timed CPU-oracle steps (after one warm-up / parity step)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (cpu_baseline and parity_check)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="bracket every n-th launch of each watched kernel kind with HIP events (all ~200 per step cost 2 %% of the step)")
     ap.add_argument("--hip-graph", action="store_true",
                     help="N=1 GAN workload: capture the step into a hipGraph after the warm-up and time replays (bit-identical "
                          "results; the roofline kernel events are then taken from two extra eager steps outside the timed region)")
@@ -259,7 +261,7 @@ def main():
         step(lr, hr)                                # first replay outside the timed region (graph upload)
         torch.cuda.synchronize()
     elif not args.no_kernel_events:
-        ops.KERNEL_EVENTS.enable(shape=watch)
+        ops.KERNEL_EVENTS.enable(shape=watch, every=args.event_every)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         logs = step(lr, hr)
@@ -350,7 +352,8 @@ def roofline_objects(args, kern):
              "traffic": traffic,
              "traffic_note": (f"HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in profiles/{src}"
                               if src else "no committed PMC summary found"),
-             "launches_timed": n, "avg_launch_us": round(ms * 1e3, 2)}
+             "launches_timed": n, "avg_launch_us": round(ms * 1e3, 2),
+             "sampling": f"every {getattr(args, 'event_every', 1)}-th launch of this kind inside the timed steps is bracketed by HIP events"}
         if issue_frac < 1.0:
             o["note"] = (f"1-D Winograd {'F(4,3)' if issue_frac == 0.5 else 'F(2,3)'}: the kernel issues "
                          f"{'1/2' if issue_frac == 0.5 else '2/3'} of the direct conv's MFMA flops; frac counts the ISSUED flops "
