@@ -53,3 +53,20 @@ def test_product_does_not_import_oracle():
         if os.path.exists(p) and re.search(r"^\s*(from|import)\s+oracle\b", open(p).read(), flags=re.M):
             bad.append(p)
     assert not bad, bad
+
+
+def test_wino4_planner_scores_on_the_host():
+    """pesr_conv3x3_wino4_score is host-only code (the F(4,3) kernel's tile planner): per-mille of the tiles' x-tile slots that
+    hold real pixels, 0 when the shape is unsupported or yields fewer than 192 workgroups.  It decides the dispatch, so its
+    behaviour on the shapes of the three networks is pinned here, without a GPU."""
+    from pesr_amd import _lib
+    score = _lib.lib().pesr_conv3x3_wino4_score
+    assert score(16, 48, 48, 256, 256, 1) == 1000                 # G body: 12 rows x 12 x-tiles per tile, one round of 256 workgroups
+    assert score(16, 96, 96, 256, 1024, 0) == 1000                # upsampler conv (fused PixelShuffle: no split-K)
+    assert score(16, 24, 24, 512, 512, 1) == 1000                 # VGG conv4_x: 6-x-tile rows (dense LDS layout), split-K
+    s12 = score(16, 12, 12, 512, 512, 1)                          # VGG conv5_x: 16 images stacked into one 207-row image
+    assert 780 <= s12 <= 800, s12
+    assert score(2, 12, 12, 512, 512, 1) == 0                     # too few workgroups even stacked and split
+    assert score(1, 48, 48, 256, 256, 1) == 0                     # one image: 16 workgroups
+    assert score(16, 48, 50, 256, 256, 1) == 0                    # width not a multiple of 4
+    assert score(16, 48, 48, 256, 96, 1) == 0                     # Cout not a multiple of 64
