@@ -252,12 +252,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    use_graph = args.hip_graph and world == 1 and args.workload == "gan"
+    use_graph = args.hip_graph and world == 1 and args.workload in ("gan", "pretrain")
     watch = (args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels, 1)
     if use_graph:
         for _ in range(max(0, 2 - args.warmup)):    # the capture needs two eager steps behind it (Trainer.capture_gan_step)
             step(lr, hr)
-        step = trainer.capture_gan_step(lr, hr)
+        step = trainer.capture_gan_step(lr, hr) if args.workload == "gan" else trainer.capture_pretrain_step(lr, hr)
         step(lr, hr)                                # first replay outside the timed region (graph upload)
         torch.cuda.synchronize()
     elif not args.no_kernel_events:
@@ -274,7 +274,7 @@ def main():
     if use_graph and not args.no_kernel_events:     # events cannot be read back from inside a graph: two eager steps for them
         ops.KERNEL_EVENTS.enable(shape=watch)
         for _ in range(2):
-            trainer.gan_step(lr, hr)
+            (trainer.gan_step if args.workload == "gan" else trainer.pretrain_step)(lr, hr)
     kern = ops.KERNEL_EVENTS.drain()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)

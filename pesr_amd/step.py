@@ -136,33 +136,51 @@ class Trainer:
         (FlatAdam.use_device_state); the packed conv weights are refreshed by launches that are part of the captured sequence.
         Single-process only: the bucketed RCCL all-reduce of the data-parallel path runs on its own stream from autograd hooks
         and is left to eager mode."""
+        assert not self.gradient_penalty, "the gradient-penalty step draws torch.rand inside the step: eager only"
+        return self._capture("gan", self.gan_step, (self.optim_D, self.optim_G), lr, hr)
+
+    def capture_pretrain_step(self, lr, hr):
+        """The same for pretrain_step (reference train.py:164-173): returns pretrain_step_graphed."""
+        return self._capture("pretrain", self.pretrain_step, (self.optim_G,), lr, hr)
+
+    def _capture(self, kind, fn, optims, lr, hr):
         from . import ops
         assert self.world_size == 1, "graph capture covers the single-GPU step"
-        assert not self.gradient_penalty, "the gradient-penalty step draws torch.rand inside the step: eager only"
-        for o in (self.optim_D, self.optim_G):
+        for o in optims:
             o.use_device_state()
-        self._g_lr, self._g_hr = lr.clone(), hr.clone()
-        steps = (self.optim_D.steps, self.optim_G.steps)
+        st = {"lr": lr.clone(), "hr": hr.clone(), "optims": optims}
+        steps = [o.steps for o in optims]
         watched, ops.KERNEL_EVENTS.shape = ops.KERNEL_EVENTS.shape, None       # no timing events inside a graph
         torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
+        st["graph"] = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-                self._g_logs = self.gan_step(self._g_lr, self._g_hr)
+            with torch.cuda.graph(st["graph"], capture_error_mode="thread_local"):
+                st["logs"] = fn(st["lr"], st["hr"])
         finally:
             ops.KERNEL_EVENTS.shape = watched
-            self.optim_D.steps, self.optim_G.steps = steps                      # nothing ran: the host count must not move
-        return self.gan_step_graphed
+            for o, n in zip(optims, steps):
+                o.steps = n                                                     # nothing ran: the host count must not move
+        if self._graph is None:
+            self._graph = {}
+        self._graph[kind] = st
+        return self.gan_step_graphed if kind == "gan" else self.pretrain_step_graphed
+
+    def _replay(self, kind, lr, hr):
+        assert self._graph and kind in self._graph, f"capture_{kind}_step first"
+        st = self._graph[kind]
+        for o in st["optims"]:
+            o.sync_lr_to_device()
+        st["lr"].copy_(lr, non_blocking=True)
+        st["hr"].copy_(hr, non_blocking=True)
+        st["graph"].replay()
+        for o in st["optims"]:
+            o.steps += 1
+        return st["logs"]
 
     def gan_step_graphed(self, lr, hr):
         """Replay the captured step on a new batch (same shapes).  Returns the same dict of device scalars as gan_step; they are
         overwritten by the next replay."""
-        assert self._graph is not None, "capture_gan_step first"
-        for o in (self.optim_D, self.optim_G):
-            o.sync_lr_to_device()
-        self._g_lr.copy_(lr, non_blocking=True)
-        self._g_hr.copy_(hr, non_blocking=True)
-        self._graph.replay()
-        self.optim_D.steps += 1
-        self.optim_G.steps += 1
-        return self._g_logs
+        return self._replay("gan", lr, hr)
+
+    def pretrain_step_graphed(self, lr, hr):
+        return self._replay("pretrain", lr, hr)

@@ -469,3 +469,11 @@ def test_gan_step_hipgraph_replay_is_bit_identical_to_eager():
     # eager steps keep working after the capture (device-state Adam) and stay in lock-step
     la, lb = tra.gan_step(*data[0]), trb.gan_step(*data[0])
     assert la["d"].item() == lb["d"].item() and torch.equal(next(Ga.parameters()), next(Gb.parameters()))
+    # the pretrain step (reference train.py:164-173) captured on the same trainer
+    for lr, hr in data[:2]:
+        tra.pretrain_step(lr, hr); trb.pretrain_step(lr, hr)
+    pstep = trb.capture_pretrain_step(*data[0])
+    for lr, hr in data[2:4]:
+        assert tra.pretrain_step(lr, hr)["l1"].item() == pstep(lr, hr)["l1"].item()
+    for pa, pb in zip(Ga.parameters(), Gb.parameters()):
+        assert torch.equal(pa, pb)
