@@ -265,12 +265,40 @@ class _OnSide:
                 torch.cuda.current_stream(self.device).wait_stream(self.side)
 
 
-_REPACK_TABLES = {}
+_REPACK_TABLES = {}        # key -> device descriptor table, least recently used first (a dict keeps insertion order)
+_REPACK_TABLES_MAX = 8
+# Set (to a list) by Trainer._capture while a step is being captured into a hipGraph: every repack_all launch under capture
+# appends (jobs, table).  The graph holds the table's and the packed buffers' RAW pointers, so the capture state keeps these
+# objects alive (an evicted table, or a packed buffer an eager rebuild replaced, would otherwise go back to the caching
+# allocator and the next replay would read / write reused memory), and Trainer._replay uses the job list to re-stamp exactly
+# the packings the replayed launch refreshed.
+_REPACK_RECORD = None
+
+_SLOT_FIELD = {0: ("fwd", "kf"), 1: ("dgrad", "kd"), 2: ("wfwd", "kwf"), 3: ("wdgrad", "kwd"), 4: ("w4fwd", "k4f"), 5: ("w4dgrad", "k4d")}
+
+
+def _slot_buffer(sl, mode):
+    b = getattr(sl, _SLOT_FIELD[mode][0])
+    return b if (b is None or torch.is_tensor(b)) else b.t
+
+
+def stamp_repacked(jobs) -> None:
+    """Mark the packings of `jobs` (as recorded by repack_all) as built from their weights' CURRENT contents.  A packing whose
+    buffer is no longer the recorded one (an eager rebuild replaced it) is left alone: its key then misses and it is rebuilt
+    on next use."""
+    for sl, wref, mode, ptr in jobs:
+        w = wref()
+        buf = _slot_buffer(sl, mode)
+        if w is None or buf is None or buf.data_ptr() != ptr:
+            continue
+        setattr(sl, _SLOT_FIELD[mode][1], PackedConvWeights._key(w))
 
 
 def repack_all(params) -> None:
     """Refresh, in ONE kernel launch, every packed layout that already exists for the given parameters (called by
     FlatAdam.step right after its Adam kernel, instead of ~2 small pack launches per conv on the next forward/backward)."""
+    import weakref
+
     import numpy as np
     ids = {id(p) for p in params}
     jobs = []
@@ -301,28 +329,20 @@ def repack_all(params) -> None:
     # One descriptor table per (parameter set, pack layout), kept on the device: the H2D copy that builds it SYNCHRONISES the
     # host with the stream, so it must happen once per optimizer - not once per step (with one shared slot, the G and D
     # optimizers of the GAN step evicted each other's table every step and the host could never run ahead of the GPU).
-    table = _REPACK_TABLES.get(key)
+    table = _REPACK_TABLES.pop(key, None)
     if table is None:
-        if len(_REPACK_TABLES) >= 8:
-            _REPACK_TABLES.clear()
-        table = _REPACK_TABLES[key] = torch.from_numpy(np.array([j[3] for j in jobs], dtype=np.int64)).to(dev)
+        while len(_REPACK_TABLES) >= _REPACK_TABLES_MAX:           # least recently used goes first
+            _REPACK_TABLES.pop(next(iter(_REPACK_TABLES)))
+        table = torch.from_numpy(np.array([j[3] for j in jobs], dtype=np.int64)).to(dev)
+    _REPACK_TABLES[key] = table                                    # (re-)inserted as the most recently used
     from . import _lib
     _lib.check(_lib.lib().pesr_pack_conv3x3_batched(table.data_ptr(), len(jobs), torch.cuda.current_stream(dev).cuda_stream),
                "pesr_pack_conv3x3_batched")
-    for sl, w, mode, _ in jobs:
-        k = PackedConvWeights._key(w)
-        if mode == 0:
-            sl.kf = k
-        elif mode == 1:
-            sl.kd = k
-        elif mode == 2:
-            sl.kwf = k
-        elif mode == 3:
-            sl.kwd = k
-        elif mode == 4:
-            sl.k4f = k
-        else:
-            sl.k4d = k
+    rec = [(sl, weakref.ref(w), mode, d[1]) for sl, w, mode, d in jobs]
+    if _REPACK_RECORD is not None:
+        # under capture nothing ran: the record (it also pins the table and the packed buffers) is used at replay time
+        _REPACK_RECORD.append((rec, table, [_slot_buffer(sl, mode) for sl, _, mode, _ in jobs]))
+    stamp_repacked(rec)
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -756,6 +776,14 @@ class LinDgrad2Fn(Function):
 # ------------------------------------------------------------------------------------------------
 # Linear (+LeakyReLU)                                          reference model/pesr.py:69-74
 # ------------------------------------------------------------------------------------------------
+# LinearFn's second use inside one backward pass may accumulate into the flat-gradient slice in place (below).  That is only
+# correct while NOTHING ELSE contributes to the same weight in that pass: a third contribution arriving as an ordinary tensor
+# (the gradient penalty's LinDgrad2Fn, reference train.py:216-226) makes autograd's input buffer a fresh temporary, and an
+# in-place add into the slice would then miss it - whether it does depends on the engine's node order.  Trainer switches the
+# fast path off around every backward pass that runs with the penalty.
+INPLACE_SECOND_USE = True
+
+
 class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, slope):
@@ -778,7 +806,7 @@ class LinearFn(Function):
         dw = db = None
         if ctx.needs_input_grad[1]:
             o_w, o_b = grad_out(weight), grad_out(ctx.bias_ref)
-            if o_w is None and o_b is None and weight.grad is None:
+            if INPLACE_SECOND_USE and o_w is None and o_b is None and weight.grad is None:
                 # second use of this layer in the same backward pass (the Discriminator sees hr and sr in one graph,
                 # reference train.py:205-214): accumulate straight into the flat-gradient slices the first use wrote,
                 # and hand autograd nothing to add - for classifier.0 that add was a 302 MB elementwise kernel

@@ -120,6 +120,9 @@ class GradBuckets:
                 self.bucket_of[i] = b
         self._pending, self._launched, self._works = [], [], []
         self._hooks = []
+        # measure_exposed = True: bracket finish()'s waits with HIP events on the compute stream; exposed_ms() then reports
+        # how long that stream stood still for all-reduces that backward did not cover (bench.py's comm_exposed_ms)
+        self.measure_exposed, self._exposed = False, []
         if self.enabled:
             for i, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -152,10 +155,26 @@ class GradBuckets:
         for b in range(len(self.members)):
             if not self._launched[b]:
                 self._launch(b)
+        timed = self.measure_exposed and self.flat.flat_g.is_cuda and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
-            w.wait()
+            w.wait()        # (RCCL: the compute stream waits for the communication stream; the host does not block)
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._exposed.append((e0, e1))
         self.reset()
         return 1.0 / self.world
+
+    def exposed_ms(self):
+        """-> (mean milliseconds per finish() the compute stream waited for unfinished all-reduces, samples); clears them."""
+        ev, self._exposed = self._exposed, []
+        if not ev:
+            return 0.0, 0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)
 
 
 class FlatAdam(torch.optim.Optimizer):

@@ -90,7 +90,12 @@ class Trainer:
         if self.gradient_penalty:
             gp = self._gradient_penalty(hr_cl, sr, gp_u)
             total_D_loss = total_D_loss + gp
-        total_D_loss.backward()
+        # with the penalty, classifier.{0,2}.weight get a third contribution (functional.INPLACE_SECOND_USE)
+        PF.INPLACE_SECOND_USE = not self.gradient_penalty
+        try:
+            total_D_loss.backward()
+        finally:
+            PF.INPLACE_SECOND_USE = True
 
         # The generator-phase terms that need neither the updated D nor its gradients (reference train.py:238-242) run
         # BEFORE D's optimizer step: on N > 1 GPUs these ~9 ms of VGG kernels cover the all-reduce of D's 321 MB of
@@ -134,29 +139,38 @@ class Trainer:
         What makes the step replayable: every kernel is launched on torch's current stream through the C ABI; the losses stay
         on the device; the two Adam steps read the learning rate and step count from device memory
         (FlatAdam.use_device_state); the packed conv weights are refreshed by launches that are part of the captured sequence.
-        Single-process only: the bucketed RCCL all-reduce of the data-parallel path runs on its own stream from autograd hooks
-        and is left to eager mode."""
-        assert not self.gradient_penalty, "the gradient-penalty step draws torch.rand inside the step: eager only"
+        Data-parallel runs capture too: the bucketed all-reduces that the autograd hooks launch (optim.GradBuckets) go to RCCL's
+        communication stream, which forks from the capturing stream at each launch and joins it again in FlatAdam.step's
+        wait - they become nodes of the same graph, still concurrent with the backward kernels between fork and join.  Every
+        rank must capture (and later replay) the same sequence."""
+        if self.gradient_penalty:
+            # the penalty's interpolation weights (reference train.py:217, one uniform draw per sample) become a graph INPUT:
+            # gan_step_graphed draws them with torch.rand before every replay, or takes the caller's gp_u
+            u = torch.rand(lr.size(0), 1, 1, 1, device=lr.device)
+            return self._capture("gan", lambda a, b: self.gan_step(a, b, gp_u=u), (self.optim_D, self.optim_G), lr, hr, gp_u=u)
         return self._capture("gan", self.gan_step, (self.optim_D, self.optim_G), lr, hr)
 
     def capture_pretrain_step(self, lr, hr):
         """The same for pretrain_step (reference train.py:164-173): returns pretrain_step_graphed."""
         return self._capture("pretrain", self.pretrain_step, (self.optim_G,), lr, hr)
 
-    def _capture(self, kind, fn, optims, lr, hr):
+    def _capture(self, kind, fn, optims, lr, hr, gp_u=None):
         from . import ops
-        assert self.world_size == 1, "graph capture covers the single-GPU step"
         for o in optims:
             o.use_device_state()
-        st = {"lr": lr.clone(), "hr": hr.clone(), "optims": optims}
+        st = {"lr": lr.clone(), "hr": hr.clone(), "optims": optims, "gp_u": gp_u}
         steps = [o.steps for o in optims]
         watched, ops.KERNEL_EVENTS.shape = ops.KERNEL_EVENTS.shape, None       # no timing events inside a graph
         torch.cuda.synchronize()
         st["graph"] = torch.cuda.CUDAGraph()
+        # The captured repack launches hold raw pointers of their descriptor tables and packed buffers: the record keeps those
+        # objects alive for as long as the graph lives, and tells _replay which packings a replay refreshes.
+        PF._REPACK_RECORD = st["repacks"] = []
         try:
             with torch.cuda.graph(st["graph"], capture_error_mode="thread_local"):
                 st["logs"] = fn(st["lr"], st["hr"])
         finally:
+            PF._REPACK_RECORD = None
             ops.KERNEL_EVENTS.shape = watched
             for o, n in zip(optims, steps):
                 o.steps = n                                                     # nothing ran: the host count must not move
@@ -165,22 +179,33 @@ class Trainer:
         self._graph[kind] = st
         return self.gan_step_graphed if kind == "gan" else self.pretrain_step_graphed
 
-    def _replay(self, kind, lr, hr):
+    def _replay(self, kind, lr, hr, gp_u=None):
         assert self._graph and kind in self._graph, f"capture_{kind}_step first"
         st = self._graph[kind]
         for o in st["optims"]:
             o.sync_lr_to_device()
         st["lr"].copy_(lr, non_blocking=True)
         st["hr"].copy_(hr, non_blocking=True)
+        if st["gp_u"] is not None:
+            if gp_u is None:
+                st["gp_u"].uniform_()
+            else:
+                st["gp_u"].copy_(gp_u, non_blocking=True)
         st["graph"].replay()
         for o in st["optims"]:
             o.steps += 1
+            # The replayed Adam kernels rewrote the parameters through raw pointers: every packed layout of these weights is
+            # stale now (the epoch is part of the cache keys) ...
+            PF.bump_weight_epoch(o.flat.params)
+        for jobs, _table, _bufs in st["repacks"]:
+            PF.stamp_repacked(jobs)      # ... except the ones the replayed repack launches have just rebuilt.  A packing made
+            #                              later for another shape (validation on full images) misses its key and is rebuilt.
         return st["logs"]
 
-    def gan_step_graphed(self, lr, hr):
+    def gan_step_graphed(self, lr, hr, gp_u=None):
         """Replay the captured step on a new batch (same shapes).  Returns the same dict of device scalars as gan_step; they are
         overwritten by the next replay."""
-        return self._replay("gan", lr, hr)
+        return self._replay("gan", lr, hr, gp_u)
 
     def pretrain_step_graphed(self, lr, hr):
         return self._replay("pretrain", lr, hr)

@@ -15,7 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
-CONFIGS = {"small": dict(C=64, depth=2, ps=24, B=4, steps=2)}
+# "small": the GAN step as trained; "pretrain": the L1 step (well conditioned: pins 1/N and the shard layout tightly);
+# "tv": a GAN step whose generator gradient is the TV term alone (alpha_tv = 1, everything else 0) - TV is a SUM over the
+# global batch (reference train.py:137-140), so this pins the x world_size of pesr_amd/step.py
+CONFIGS = {"small": dict(C=64, depth=2, ps=24, B=4, steps=2, kind="gan", alphas={}),
+           "pretrain": dict(C=64, depth=2, ps=24, B=4, steps=2, kind="pretrain", alphas={}),
+           "tv": dict(C=64, depth=2, ps=24, B=4, steps=1, kind="gan", alphas=dict(alpha_tv=1.0, alpha_vgg=0.0, alpha_gan=0.0, alpha_l1=0.0))}
 
 
 def main():
@@ -25,9 +30,17 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+    backend = os.environ.get("PESR_DP_BACKEND", "nccl")
+    if os.environ.get("PESR_DP_SHARE_GPU") == "1":
+        local = 0            # N ranks time-share ONE GPU (gloo moves the buckets through host memory): everything of the
+        #                      data-parallel path except RCCL itself, on a box where only one GPU is visible
+        assert backend == "gloo", "RCCL refuses two ranks on one device"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
     warnings.filterwarnings("ignore", message=".*pretrained vgg19.*")
     from helpers import dis_sd, gen_sd, vgg_sd
     from model import Discriminator, Generator, VGG
@@ -41,24 +54,26 @@ def main():
     oG = FlatAdam(G.parameters(), lr=5e-5, bucket_bytes=64 << 10)      # small buckets: several all-reduces per backward
     oD = FlatAdam(D.parameters(), lr=5e-5, bucket_bytes=256 << 10)
     assert oG.buckets.enabled and oD.buckets.enabled and len(oG.buckets.bounds) > 2
-    tr = Trainer(G, D, V, oG, oD, world_size=world)
+    tr = Trainer(G, D, V, oG, oD, world_size=world, **cfg["alphas"])
+    gan = cfg["kind"] == "gan"
     losses = []
     for it in range(cfg["steps"]):
         lr = detrand.image_batch((B * world, 3, ps, ps), 700 + it)
         hr = detrand.image_batch((B * world, 3, 4 * ps, 4 * ps), 800 + it)
         sh = slice(rank * B, (rank + 1) * B)
-        log = tr.gan_step(lr[sh].to(dev), hr[sh].to(dev))
-        keys = ("l1", "vgg", "g", "tv", "d")
+        log = (tr.gan_step if gan else tr.pretrain_step)(lr[sh].to(dev), hr[sh].to(dev))
+        keys = ("l1", "vgg", "g", "tv", "d") if gan else ("l1",)
         t = torch.stack([log[k].float() for k in keys])
         dist.all_reduce(t)                       # as train.py logs them: mean-type terms averaged, the TV sum summed
         t = t / world
-        t[keys.index("tv")] *= world
+        if gan:
+            t[keys.index("tv")] *= world
         losses.append(t.cpu())
         if it == 0:      # gradients of the FIRST step (averaged over ranks = the full-batch ones): the tight comparison
             g0 = {"G": {k: (p.grad * oG.last_scale).cpu() for k, p in G.named_parameters()},
-                  "D": {k: (p.grad * oD.last_scale).cpu() for k, p in D.named_parameters()}}
+                  "D": {k: (p.grad * oD.last_scale).cpu() for k, p in D.named_parameters()} if gan else {}}
     # replicas must hold bit-identical parameters (same all-reduced gradients, same Adam)
-    for opt in (oG, oD):
+    for opt in ((oG, oD) if gan else (oG,)):
         mine = opt.flat.flat_p.clone()
         ref = mine.clone()
         dist.broadcast(ref, 0)

@@ -30,7 +30,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _two_steps(C=64, depth=2, ps=8, B=4):
+def _two_steps(C=64, depth=2, ps=8, B=4, graph=False, steps=2):
     from model import Discriminator, Generator, VGG
     from pesr_amd.optim import FlatAdam
     from pesr_amd.step import Trainer
@@ -41,10 +41,13 @@ def _two_steps(C=64, depth=2, ps=8, B=4):
     oD = FlatAdam(D.parameters(), lr=5e-5, bucket_bytes=256 << 10)
     tr = Trainer(G, D, V, oG, oD)
     logs = []
-    for it in range(2):
+    step = tr.gan_step
+    for it in range(steps):
         lr = detrand.image_batch((B, 3, ps, ps), 700 + it).cuda()
         hr = detrand.image_batch((B, 3, 4 * ps, 4 * ps), 800 + it).cuda()
-        log = tr.gan_step(lr, hr)
+        if graph and it == 2:     # two eager steps, then the data-parallel step (hooks, buckets, RCCL calls) as ONE hipGraph
+            step = tr.capture_gan_step(lr, hr)
+        log = step(lr, hr)
         logs.append(torch.stack([log[k].float() for k in ("l1", "vgg", "g", "tv", "d")]).cpu())
     return torch.stack(logs), oG, oD
 
@@ -75,79 +78,109 @@ def test_single_rank_nccl_forced_dp_is_bit_identical(monkeypatch):
         for a, b in ((oGa, oGb), (oDa, oDb)):
             assert torch.equal(a.flat.flat_p, b.flat.flat_p) and torch.equal(a.flat.flat_g, b.flat.flat_g)
             assert torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+        # the same through the hipGraph path: the forced-DP step CAPTURED (all-reduces included) and replayed twice against
+        # four plain eager steps
+        monkeypatch.setenv("PESR_FORCE_DP", "1")
+        n0 = len(calls)
+        lc, oGc, oDc = _two_steps(graph=True, steps=4)
+        assert oGc.buckets.enabled
+        # two eager steps + ONE capture pass issue all-reduce calls; the two replays issue none from Python
+        assert len(calls) - n0 == 3 * (len(oGc.buckets.bounds) + len(oDc.buckets.bounds)), (len(calls) - n0)
+        monkeypatch.delenv("PESR_FORCE_DP")
+        le, oGe, oDe = _two_steps(steps=4)          # plain twin, four eager steps
+        assert torch.equal(lc, le), (lc, le)
+        for a, b in ((oGc, oGe), (oDc, oDe)):
+            assert torch.equal(a.flat.flat_p, b.flat.flat_p) and torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nproc", [1, 2])
-def test_n_rank_gan_steps_vs_full_batch_oracle(nproc, tmp_path):
-    if torch.cuda.device_count() < nproc:
-        pytest.skip(f"{nproc} GPUs needed, {torch.cuda.device_count()} visible")
-    out = str(tmp_path / "dp.pt")
+def _launch_worker(nproc, config, backend, share_gpu, out):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.pop("PESR_FORCE_DP", None)
+    env["PESR_DP_BACKEND"] = backend
+    env["PESR_DP_SHARE_GPU"] = "1" if share_gpu else "0"
     if nproc == 1:
         env["PESR_FORCE_DP"] = "1"       # a 1-rank group still runs the hooks / buckets / RCCL calls
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_worker.py"), "--out", out]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_worker.py"), "--out", out, "--config", config]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    got = torch.load(out)
+    return torch.load(out)
+
+
+def _oracle_step(config, nproc, dt):
+    """The CPU oracle's FIRST step on the GLOBAL batch in dtype dt (DataParallel's per-replica BatchNorm statistics) ->
+    (state, losses).  The float64 run is the truth the fp32 runs - the oracle's and ours - are measured against."""
+    from dp_worker import CONFIGS
+    cfg = CONFIGS[config]
+    C, depth, ps, B = cfg["C"], cfg["depth"], cfg["ps"], cfg["B"]
+    f = lambda sd: {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+    ocfg = {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5, "dp_replicas": nproc, **cfg["alphas"]}
+    st = OS.TrainState(f(gen_sd(C, depth)), f(dis_sd(ps)), f(vgg_sd()), ocfg)
+    return st, cfg, (lambda it: (detrand.image_batch((B * nproc, 3, ps, ps), 700 + it).to(dt),
+                                 detrand.image_batch((B * nproc, 3, 4 * ps, 4 * ps), 800 + it).to(dt)))
+
+
+# (ranks, backend, all ranks on cuda:0): a 1-rank RCCL group always runs; 2 ranks over RCCL need two GPUs; 2 ranks over gloo
+# time-share one GPU - the whole data-parallel path (shards, per-rank BatchNorm, TV x N, 1/N, buckets, hooks) on the real
+# kernels wherever a single MI355X is visible
+LAUNCHES = [(1, "nccl", False), (2, "nccl", False), (2, "gloo", True)]
+
+
+@pytest.mark.parametrize("config", ["small", "pretrain", "tv"])
+@pytest.mark.parametrize("nproc,backend,share", LAUNCHES, ids=["nccl1", "nccl2", "gloo2-one-gpu"])
+def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_path):
+    """N ranks, each on its shard, against the CPU oracle's step on the GLOBAL batch.  Gradients of the first step are held to
+    the fp64 criterion of helpers.grads_vs_fp64, with the float64 oracle computed here: per tensor, our distance to the fp64
+    truth may be at most 3 x the fp32 oracle's own distance to it, never asked below twice the worst such distance of the
+    network (fp32 noise is a discrete event per tensor) - 1e-5..1e-4 for the L1 ("pretrain") and TV-only ("tv") steps, whose
+    gradients are well conditioned, so a missing 1/N, a missing x N on the TV sum, a wrong shard or a dropped bucket of even a
+    small tensor shows; the full GAN step ("small") is ill-conditioned in fp32 (BatchNorm over 4-sample shards, LeakyReLU
+    kinks) and its allowance follows from the same measurement."""
+    if not share and torch.cuda.device_count() < nproc:
+        pytest.skip(f"{nproc} GPUs needed, {torch.cuda.device_count()} visible")
+    got = _launch_worker(nproc, config, backend, share, str(tmp_path / "dp.pt"))
     assert got["world"] == nproc
-    C, depth, ps, B = 64, 2, 24, 4
-    cfg = {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5, "dp_replicas": nproc}
-    st = OS.TrainState(gen_sd(C, depth), dis_sd(ps), vgg_sd(), cfg)
-    # The GAN step's gradients are ill-conditioned in fp32 (LeakyReLU / ReLU kinks, BatchNorm over 4-sample shards): a rounding-
-    # level change anywhere - another summation order in one conv is enough - flips masks and moves whole gradient tensors.
-    # scripts/dp_grad_diag.py measures it for this configuration: over six batches and four kernel dispatches (default, no
-    # C->3 kernel, no F(4,3), direct kernels only) the worst per-tensor distance to the fp32 oracle is 2e-2 .. 6e-2 of the
-    # tensor's maximum for EVERY dispatch, with an occasional 2e-3, while the sr images themselves agree with float64 to
-    # 3..5e-5 (one ulp at 100 is 8e-6).  One-ulp weight perturbations of the oracle (three draws below) move the gradients by
-    # ~1e-3: a lower bound of the noise, not the noise.  The allowance per tensor is therefore the larger of 5 x that spread and
-    # 0.1 of the tensor's maximum - this comparison can only catch what data-parallel bugs produce (a missing 1/N, a wrong
-    # shard, a dropped bucket: errors of order one); the exchange itself is pinned bit-exactly by the test above and the
-    # losses, which are well conditioned, at 5e-5 below.
-    def perturbed(sd, seed):
-        gen = torch.Generator().manual_seed(seed)
-        return {k: (v * (1.0 + (torch.randint(0, 2, v.shape, generator=gen).to(v.dtype) * 2 - 1) * 2.0 ** -23)
-                    if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
-    lr0 = detrand.image_batch((B * nproc, 3, ps, ps), 700)
-    hr0 = detrand.image_batch((B * nproc, 3, 4 * ps, 4 * ps), 800)
-    spread = {}
-    base_grads = None
-    for draw in range(4):
-        g_sd, d_sd = gen_sd(C, depth), dis_sd(ps)
-        if draw:
-            g_sd, d_sd = perturbed(g_sd, 10 + draw), perturbed(d_sd, 20 + draw)
-        stp = OS.TrainState(g_sd, d_sd, vgg_sd(), cfg)
-        OS.gan_step(stp, lr0, hr0)
-        grads = {("G", k): v.grad.clone() for k, v in stp.g.items()}
-        grads.update({("D", k): v.grad.clone() for k, v in stp.d.items() if v.grad is not None})
-        if draw == 0:
-            base_grads = grads
-        else:
-            for key, gr in grads.items():
-                mx = float(base_grads[key].abs().max())
-                if mx > 0:
-                    spread[key] = max(spread.get(key, 0.0), float((gr - base_grads[key]).abs().max()) / mx)
-    for it in range(2):
-        lr = detrand.image_batch((B * nproc, 3, ps, ps), 700 + it)
-        hr = detrand.image_batch((B * nproc, 3, 4 * ps, 4 * ps), 800 + it)
-        ref = OS.gan_step(st, lr, hr)
-        close(got["losses"][it].numpy(), np.array([ref[k] for k in ("l1", "vgg", "g", "tv", "d")]), 5e-5 if it == 0 else 5e-4,
-              what=f"losses step {it}")
-        if it == 0:     # gradients of the FIRST step, averaged over ranks = the full-batch ones
-            for name, leaves in (("G", st.g), ("D", st.d)):
-                for k, v in leaves.items():
-                    if k not in got[name + ".grad"] or v.grad is None or (name, k) not in spread:
-                        continue
-                    mx = float(v.grad.abs().max())
-                    err = float((got[name + ".grad"][k] - v.grad).abs().max()) / mx
-                    tol = max(0.1, 5.0 * spread[(name, k)])
-                    assert err <= tol, f"grad {name}.{k}: {err:.2e} of the maximum > {tol:.2e} (one-ulp weight perturbations move it by {spread[(name, k)]:.2e})"
-    for k, v in st.g.items():
-        adam_close(got["G"][k], v, 5e-5, 2, "G." + k)
-    for k, v in st.d.items():
-        if v.is_floating_point() and "running" not in k:
-            adam_close(got["D"][k], v, 5e-5, 2, "D." + k)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    st32, cfg, batch = _oracle_step(config, nproc, torch.float32)
+    st64, _, batch64 = _oracle_step(config, nproc, torch.float64)
+    gan = cfg["kind"] == "gan"
+    step = OS.gan_step if gan else OS.pretrain_step
+    keys = ("l1", "vgg", "g", "tv", "d") if gan else ("l1",)
+    step(st64, *batch64(0))
+    checked, worst = 0, (0.0, None)
+    for it in range(cfg["steps"]):
+        lr, hr = batch(it)
+        ref = step(st32, lr, hr)
+        close(got["losses"][it].numpy(), np.array([ref[k] for k in keys]), 5e-5 if it == 0 else 5e-4, what=f"losses step {it}")
+        if it:
+            continue
+        for name, l32, l64 in (("G", st32.g, st64.g), ("D", st32.d, st64.d)):
+            errs = {}
+            for k, v in l32.items():
+                g64 = l64[k].grad if k in l64 else None
+                if k not in got[name + ".grad"] or v.grad is None or g64 is None or float(g64.abs().max()) == 0.0:
+                    continue
+                mx = float(g64.abs().max())
+                errs[k] = (float((v.grad.double() - g64).abs().max()) / mx, float((got[name + ".grad"][k].double() - g64).abs().max()) / mx)
+            if not errs:
+                continue
+            net_floor = max(e[0] for e in errs.values())
+            for k, (e_ref, e_ours) in errs.items():
+                tol = max(3.0 * e_ref, 2.0 * net_floor, 1e-6)
+                assert e_ours <= tol, f"{config} grad {name}.{k}: {e_ours:.2e} of the maximum vs fp64 > {tol:.2e} (fp32 oracle: {e_ref:.2e})"
+                checked += 1
+                if e_ours / tol > worst[0]:
+                    worst = (e_ours / tol, f"{name}.{k} {e_ours:.1e}/{tol:.1e}")
+            if config != "small":      # the well-conditioned steps really are held tightly (else this test pins nothing)
+                assert 2.0 * net_floor < 2e-3, (config, name, net_floor)
+    assert checked >= (20 if gan else 10), checked
+    print(f"[{config} x{nproc} {backend}] {checked} gradient tensors vs fp64, worst at {worst[0]:.2f} of its allowance: {worst[1]}")
+    for k, v in st32.g.items():
+        adam_close(got["G"][k], v, 5e-5, cfg["steps"], "G." + k)
+    if gan:
+        for k, v in st32.d.items():
+            if v.is_floating_point() and "running" not in k:
+                adam_close(got["D"][k], v, 5e-5, cfg["steps"], "D." + k)

@@ -477,3 +477,55 @@ def test_gan_step_hipgraph_replay_is_bit_identical_to_eager():
         assert tra.pretrain_step(lr, hr)["l1"].item() == pstep(lr, hr)["l1"].item()
     for pa, pb in zip(Ga.parameters(), Gb.parameters()):
         assert torch.equal(pa, pb)
+
+
+def test_hipgraph_replay_then_forward_at_a_new_shape_uses_fresh_weights():
+    """After replays, a packing that the captured step never built (validation runs G on full images of another shape and so
+    on another kernel dispatch) must be made from the CURRENT weights: the replayed Adam kernels write through raw pointers,
+    so Trainer._replay bumps the weight epochs and re-stamps only the packings the captured repack launches rebuild.  Twin
+    trainers, one eager and one replaying; a forward at a new shape BEFORE the capture creates the packing that would
+    otherwise be served stale afterwards."""
+    tra, Ga, Da = _trainer(16, 2, 8)
+    trb, Gb, Db = _trainer(16, 2, 8)
+    data = [(detrand.image_batch((4, 3, 8, 8), 50 + i).cuda(), detrand.image_batch((4, 3, 32, 32), 60 + i).cuda()) for i in range(5)]
+    probe = detrand.image_batch((1, 3, 10, 14), 77).cuda()       # width 14: not an F(4,3) shape -> F(2,3) / direct packings
+    for lr, hr in data[:2]:
+        tra.gan_step(lr, hr); trb.gan_step(lr, hr)
+    with torch.no_grad():
+        assert torch.equal(Ga(probe), Gb(probe))                 # builds the validation-shape packings from step-2 weights
+    step = trb.capture_gan_step(*data[0])
+    for lr, hr in data[2:]:
+        tra.gan_step(lr, hr); step(lr, hr)
+    Ga.eval(); Gb.eval()
+    with torch.no_grad():
+        ya, yb = Ga(probe), Gb(probe)
+        assert torch.equal(ya, yb), float((ya - yb).abs().max())
+        probe2 = detrand.image_batch((2, 3, 9, 6), 78).cuda()    # and a shape nobody has seen yet
+        assert torch.equal(Ga(probe2), Gb(probe2))
+        # D at another batch size as well (its classifier fixes the patch size)
+        hr1 = data[0][1][:2].contiguous(memory_format=torch.channels_last)
+        assert torch.equal(Da(hr1), Db(hr1))
+    # and the packings of the captured shape are still served (no rebuild storm): one more replay stays in lock-step
+    la, lb = tra.gan_step(*data[1]), step(*data[1])
+    assert la["vgg"].item() == lb["vgg"].item()
+
+
+def test_gradient_penalty_step_captured_as_hipgraph():
+    """--GP steps replay too: the interpolation weights u (reference train.py:217) are a graph input."""
+    from pesr_amd.step import Trainer
+    tra, Ga, Da = _trainer(16, 2, 8)
+    trb, Gb, Db = _trainer(16, 2, 8)
+    tra.gradient_penalty = trb.gradient_penalty = True
+    data = [(detrand.image_batch((4, 3, 8, 8), 50 + i).cuda(), detrand.image_batch((4, 3, 32, 32), 60 + i).cuda()) for i in range(4)]
+    us = [torch.rand(4, 1, 1, 1, generator=torch.Generator().manual_seed(i)).cuda() for i in range(4)]
+    for (lr, hr), u in zip(data[:2], us[:2]):
+        tra.gan_step(lr, hr, gp_u=u); trb.gan_step(lr, hr, gp_u=u)
+    step = trb.capture_gan_step(*data[0])
+    for (lr, hr), u in zip(data[2:], us[2:]):
+        la, lb = tra.gan_step(lr, hr, gp_u=u), step(lr, hr, gp_u=u)
+        for k in la:
+            assert la[k].item() == lb[k].item(), (k, la[k].item(), lb[k].item())
+    for pa, pb in zip(list(Ga.parameters()) + list(Da.parameters()), list(Gb.parameters()) + list(Db.parameters())):
+        assert torch.equal(pa, pb)
+    lr, hr = data[0]
+    assert "gp" in step(lr, hr)          # u drawn by the replay itself

@@ -59,9 +59,10 @@ def build_parser():
                    help="GAN phase without pretrained VGG19 weights: seeded random features (benchmarks / smoke runs only - the "
                         "perceptual loss is then NOT the reference's)")
     p.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (smoke runs)")
-    p.add_argument("--hip_graph", type=str2bool, default=False,
-                   help="GAN phase on one GPU: capture the step into a hipGraph after two eager iterations and replay it "
-                        "(same results bit for bit; the host no longer issues ~1000 launches per step)")
+    p.add_argument("--hip_graph", type=str, default="auto", choices=["auto", "true", "false", "True", "False"],
+                   help="capture the train step into a hipGraph after two eager iterations and replay it (same results bit for "
+                        "bit; the host no longer issues ~1000 launches per step).  auto = on for a single-GPU run, off under "
+                        "torch.distributed (there the RCCL all-reduces are captured with the step: opt in with true)")
     p.add_argument("--gpu_pipeline", type=str2bool, default=False,
                    help="keep the uint8 training images in HBM and crop/augment on the GPU (pesr_amd.input_pipeline)")
     return p
@@ -141,18 +142,30 @@ def build_vgg(args, device, rank, world):
     from model import VGG
     if args.vgg_weights:
         return VGG(args.vgg_weights).to(device)
+    # Only "the package or its model-zoo file is not there" counts as unavailable (ImportError; URLError / OSError of the
+    # download); anything else - a corrupt cache, out of memory - is an error, not a reason to train on random features.
+    import urllib.error
+    sd, why = None, ""
     try:
         import torchvision
         sd = torchvision.models.vgg19(pretrained=True).state_dict()
+    except (ImportError, urllib.error.URLError, OSError) as e:
+        why = type(e).__name__
+    if world > 1:
+        # every rank must take the same branch: the pretrained weights are used only if ALL ranks have them
+        ok = torch.tensor([1 if sd is not None else 0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            sd = None
+    if sd is not None:
         import tempfile
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
             torch.save(sd, f.name)
             return VGG(f.name).to(device)
-    except Exception as e:      # torchvision missing, or no network for its model zoo
-        if not (args.synthetic or args.allow_random_vgg):
-            raise SystemExit("train.py: the GAN phase needs torchvision's pretrained vgg19 weights (reference model/vgg.py:8): pass "
-                             "--vgg_weights <state_dict file>, or --allow_random_vgg true for a run whose perceptual loss is NOT the "
-                             f"reference's (torchvision unavailable: {type(e).__name__})")
+    if not (args.synthetic or args.allow_random_vgg):
+        raise SystemExit("train.py: the GAN phase needs torchvision's pretrained vgg19 weights (reference model/vgg.py:8): pass "
+                         "--vgg_weights <state_dict file>, or --allow_random_vgg true for a run whose perceptual loss is NOT the "
+                         f"reference's (torchvision's weights unavailable on at least one rank: {why or 'another rank'})")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         state = torch.random.get_rng_state()
@@ -234,6 +247,7 @@ def main(argv=None):
     best_psnr = 0.0
     keys = ("l1", "vgg", "g", "tv", "d") if gan else ("l1",)
     graphed, graph_shapes, eager_at_shape = None, None, 0
+    use_graph = device.type == "cuda" and (world == 1 if args.hip_graph == "auto" else str2bool(args.hip_graph))
 
     for epoch in range(1, args.num_epochs + 1):
         # The reference calls scheduler.step() at epoch START (train.py:156,185-186); under its pinned torch 0.4 the
@@ -250,14 +264,14 @@ def main(argv=None):
                 logs = graphed(lr_img, hr_img)
             else:
                 logs = trainer.gan_step(lr_img, hr_img) if gan else trainer.pretrain_step(lr_img, hr_img)
-                if gan and args.hip_graph and world == 1 and not args.GP and graphed is None and device.type == "cuda":
+                if use_graph and graphed is None:
                     # capture after TWO eager steps at these shapes: the second one has seen every weight packing the first one
                     # created (some only in its backward pass), so nothing is allocated or uploaded under capture
                     shapes = (lr_img.shape, hr_img.shape)
                     eager_at_shape = eager_at_shape + 1 if shapes == graph_shapes else 1
                     graph_shapes = shapes
                     if eager_at_shape >= 2:
-                        graphed = trainer.capture_gan_step(lr_img, hr_img)
+                        graphed = (trainer.capture_gan_step if gan else trainer.capture_pretrain_step)(lr_img, hr_img)
             running += torch.stack([logs[k].float() for k in keys])
             iters += 1
             if args.max_iters and iters >= args.max_iters:
