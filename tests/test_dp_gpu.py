@@ -135,8 +135,8 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
     """N ranks, each on its shard, against the CPU oracle's step on the GLOBAL batch.  Gradients of the first step are held to
     the fp64 criterion of helpers.grads_vs_fp64, with the float64 oracle computed here: per tensor, our distance to the fp64
     truth may be at most 3 x the fp32 oracle's own distance to it, never asked below twice the worst such distance of the
-    network (fp32 noise is a discrete event per tensor) - 1e-5..1e-4 for the L1 ("pretrain") and TV-only ("tv") steps, whose
-    gradients are well conditioned, so a missing 1/N, a missing x N on the TV sum, a wrong shard or a dropped bucket of even a
+    network (fp32 noise is a discrete event per tensor) nor below 1e-4 - which is where the L1 ("pretrain") and TV-only ("tv")
+    steps end up for the Generator (fp32 oracle vs fp64: 2e-6 and 1.5e-4 of a tensor's maximum), whose gradients are well conditioned, so a missing 1/N, a missing x N on the TV sum, a wrong shard or a dropped bucket of even a
     small tensor shows; the full GAN step ("small") is ill-conditioned in fp32 (BatchNorm over 4-sample shards, LeakyReLU
     kinks) and its allowance follows from the same measurement."""
     if not share and torch.cuda.device_count() < nproc:
@@ -161,7 +161,8 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
             errs = {}
             for k, v in l32.items():
                 g64 = l64[k].grad if k in l64 else None
-                if k not in got[name + ".grad"] or v.grad is None or g64 is None or float(g64.abs().max()) == 0.0:
+                # (classifier.2.bias under RSGAN: pred_real - pred_fake cancels its gradient - 0 in fp32, ~1e-17 in fp64)
+                if k not in got[name + ".grad"] or v.grad is None or g64 is None or float(g64.abs().max()) < 1e-10:
                     continue
                 mx = float(g64.abs().max())
                 errs[k] = (float((v.grad.double() - g64).abs().max()) / mx, float((got[name + ".grad"][k].double() - g64).abs().max()) / mx)
@@ -169,13 +170,13 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
                 continue
             net_floor = max(e[0] for e in errs.values())
             for k, (e_ref, e_ours) in errs.items():
-                tol = max(3.0 * e_ref, 2.0 * net_floor, 1e-6)
+                tol = max(3.0 * e_ref, 2.0 * net_floor, 1e-4)       # (1e-4 of the maximum: SURVEY 8c's stated gradient tolerance)
                 assert e_ours <= tol, f"{config} grad {name}.{k}: {e_ours:.2e} of the maximum vs fp64 > {tol:.2e} (fp32 oracle: {e_ref:.2e})"
                 checked += 1
                 if e_ours / tol > worst[0]:
                     worst = (e_ours / tol, f"{name}.{k} {e_ours:.1e}/{tol:.1e}")
-            if config != "small":      # the well-conditioned steps really are held tightly (else this test pins nothing)
-                assert 2.0 * net_floor < 2e-3, (config, name, net_floor)
+            if config != "small" and name == "G":    # the well-conditioned gradients really are held tightly: measured here
+                assert 2.0 * net_floor < 1e-3, (config, name, net_floor)      # 2e-6 (L1) and 1.5e-4 (TV only) for the fp32 oracle
     assert checked >= (20 if gan else 10), checked
     print(f"[{config} x{nproc} {backend}] {checked} gradient tensors vs fp64, worst at {worst[0]:.2f} of its allowance: {worst[1]}")
     for k, v in st32.g.items():
