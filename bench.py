@@ -30,7 +30,7 @@ GFLOP_PER_PATCH = {"gan": 844.10, "pretrain": 694.69}   # SURVEY.md 8(d), necess
 K1_GFLOP = 2.0 * 16 * 48 * 48 * 256 * 256 * 9 / 1e9     # body conv 256->256 @48x48, batch 16: 43.487 GFLOP per launch
 
 
-PMC_SUMMARIES = ("r02_k1_pmc_summary.csv", "r01_final3_k1_pmc_summary.csv")     # newest first
+PMC_SUMMARIES = ("r03_k1_pmc_summary.csv", "r02_k1_pmc_summary.csv", "r01_final3_k1_pmc_summary.csv")     # newest first
 
 
 def k1_hbm_traffic_bytes(kernel_substr):
@@ -209,8 +209,10 @@ def main():
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket every n-th launch of each watched kernel kind with HIP events (all ~200 per step cost 2 %% of the step)")
     ap.add_argument("--hip-graph", action="store_true",
-                    help="N=1 GAN workload: capture the step into a hipGraph after the warm-up and time replays (bit-identical "
-                         "results; the roofline kernel events are then taken from two extra eager steps outside the timed region)")
+                    help="capture the step into a hipGraph after the warm-up and time replays (bit-identical results; with N > 1 the "
+                         "RCCL all-reduces are captured with it; the roofline kernel events are then taken from two extra eager steps "
+                         "outside the timed region)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
     args = ap.parse_args()
 
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
@@ -239,47 +241,77 @@ def main():
     if args.workload == "infer512":
         return bench_infer512(args, device)
     trainer, G, D, vgg = build(args, device, world)
-    lr, hr = synth_batch(args.batch, args.patch_size, 1234 + rank, device)
-    step = trainer.gan_step if args.workload == "gan" else trainer.pretrain_step
+    # NBATCH distinct synthetic batches, rotated: with ONE fixed batch the Discriminator separates it within ~20 steps, its loss
+    # falls to 1e-7 and D's backward pass then runs on near-zero data (never time kernels on zeros)
+    batches = [synth_batch(args.batch, args.patch_size, 1234 + rank + 1000 * i, device) for i in range(max(1, args.batches))]
+    lr, hr = batches[0]
+    eager_step = trainer.gan_step if args.workload == "gan" else trainer.pretrain_step
+    step = eager_step
     want_cpu = not args.no_cpu_baseline and world == 1
     state0 = snapshot_state(G, D, vgg) if want_cpu else None
+    nstep = [0]
 
-    first_log = None
-    for _ in range(args.warmup):
-        log = step(lr, hr)
-        first_log = first_log or log
+    def run(fn):
+        b = batches[nstep[0] % len(batches)]
+        nstep[0] += 1
+        return fn(*b)
+
+    # step 0 (always eager, on batch 0): its losses go to the parity check as host floats, and the matrix-pipe work of one
+    # step is tallied while it runs
+    ops.FLOPS.start()
+    first_log = {k: float(v) for k, v in run(eager_step).items()}
+    flops = ops.FLOPS.stop()
+    use_graph = args.hip_graph and args.workload in ("gan", "pretrain")
+    for _ in range(max(args.warmup, 2 if use_graph else 0) - 1):     # (a capture needs two eager steps behind it)
+        run(eager_step)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    use_graph = args.hip_graph and world == 1 and args.workload in ("gan", "pretrain")
     watch = (args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels, 1)
     if use_graph:
-        for _ in range(max(0, 2 - args.warmup)):    # the capture needs two eager steps behind it (Trainer.capture_gan_step)
-            step(lr, hr)
         step = trainer.capture_gan_step(lr, hr) if args.workload == "gan" else trainer.capture_pretrain_step(lr, hr)
-        step(lr, hr)                                # first replay outside the timed region (graph upload)
+        run(step)                                   # first replay outside the timed region (graph upload)
         torch.cuda.synchronize()
     elif not args.no_kernel_events:
         ops.KERNEL_EVENTS.enable(shape=watch, every=args.event_every)
+    optims = [o for o in (trainer.optim_D, trainer.optim_G) if o is not None]
+    for o in optims:
+        o.buckets.measure_exposed = not use_graph
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        logs = step(lr, hr)
-        first_log = first_log or logs
+        logs = run(step)
+    host_done = time.perf_counter() - t0            # the host has enqueued all K steps; the GPU is (normally) still running
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = my_elapsed = time.perf_counter() - t0
+    exposed = [o.buckets.exposed_ms() for o in optims]
+    for o in optims:
+        o.buckets.measure_exposed = False
     if use_graph and not args.no_kernel_events:     # events cannot be read back from inside a graph: two eager steps for them
         ops.KERNEL_EVENTS.enable(shape=watch)
         for _ in range(2):
-            (trainer.gan_step if args.workload == "gan" else trainer.pretrain_step)(lr, hr)
+            run(eager_step)
     kern = ops.KERNEL_EVENTS.drain()
+    # host cost of ONE eager step: enqueue three steps on an idle GPU without waiting for it (python + launches only)
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    for _ in range(3):
+        run(eager_step)
+    host_enqueue_ms = 1e3 * (time.perf_counter() - th) / 3
+    torch.cuda.synchronize()
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
+        elapsed = max(per_rank)
+        hh = torch.tensor([host_enqueue_ms, host_done], device=device, dtype=torch.float64)
+        dist.all_reduce(hh, op=dist.ReduceOp.MAX)
+        host_enqueue_ms, host_done = float(hh[0]), float(hh[1])
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -298,15 +330,35 @@ def main():
                                f"{4 * args.patch_size}x{4 * args.patch_size}, {args.num_channels} ch x {args.num_blocks} blocks",
                    "global_batch": global_batch, "parallelism": f"dp{world}"},
         "step_tflops_per_gpu": round(value / world * flop_patch / 1e12, 2),
+        # ALGORITHMIC flops / time / peak: may exceed 1 because the Winograd kernels issue 1/2 .. 2/3 of them
         "step_frac_of_mfma_peak": round(value / world * flop_patch / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+        # flops the step's kernels really ISSUE on the matrix pipe (tallied per launch during step 0) / time / peak: the honest
+        # whole-step hardware fraction
+        "step_issued_frac": round(flops["issued"] / (1e3 * elapsed / args.steps) / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+        "step_flops": {"algorithmic_tflop_counted": round(flops["algorithmic"] / 1e12, 3), "issued_tflop": round(flops["issued"] / 1e12, 3),
+                       "by_kernel_family_tflop": {k: [round(a / 1e12, 3), round(b / 1e12, 3)] for k, (a, b) in flops["by_kernel_family"].items()},
+                       "note": "per family: [algorithmic, issued on the matrix pipe]; counted from the launches of step 0"},
         "losses": {k: float(v) for k, v in logs.items()},
+        "batches_rotated": len(batches),
         "hip_graph": bool(use_graph),
+        # host side: time to ENQUEUE one eager step (python + launches, GPU idle at start, no waiting) and the moment the host
+        # had enqueued all K timed steps relative to their completion (max over ranks)
+        "host_enqueue_ms": round(host_enqueue_ms, 2),
+        "host_enqueue_frac_of_step": round(host_enqueue_ms / (1e3 * elapsed / args.steps), 3),
+        "host_done_ms_before_gpu": round(1e3 * (my_elapsed - host_done), 1),
+        "force_dp": os.environ.get("PESR_FORCE_DP") == "1",
     }
+    if any(n for _, n in exposed):
+        out["comm_exposed_ms"] = round(sum(ms for ms, n in exposed if n), 3)
+        out["comm_exposed_note"] = ("per step: time the compute stream stood waiting in FlatAdam.step for gradient all-reduces that "
+                                    "backward had not covered (HIP events around the waits, D + G optimizers, rank 0)")
+    if per_rank:
+        out["per_rank_ms_per_step"] = {"min": round(1e3 * min(per_rank) / args.steps, 3), "max": round(1e3 * max(per_rank) / args.steps, 3)}
     if kern:
         out.update(roofline_objects(args, kern))
     if want_cpu:
-        out["cpu_baseline"], ref0 = cpu_baseline(args, state0, (lr.cpu(), hr.cpu()))
-        got0 = {k: float(v) for k, v in first_log.items()}
+        out["cpu_baseline"], ref0 = cpu_baseline(args, state0, (batches[0][0].cpu(), batches[0][1].cpu()))
+        got0 = first_log
         rel = {k: abs(got0[k] - ref0[k]) / max(abs(ref0[k]), 1e-12) for k in ref0 if abs(ref0[k]) > 0 or abs(got0[k]) > 0}
         worst = max(rel.values()) if rel else 0.0
         out["parity_check"] = {"what": "losses of GPU step 0 vs the CPU oracle's step from the same initial weights and batch "
@@ -353,7 +405,9 @@ def roofline_objects(args, kern):
              "traffic_note": (f"HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in profiles/{src}"
                               if src else "no committed PMC summary found"),
              "launches_timed": n, "avg_launch_us": round(ms * 1e3, 2),
-             "sampling": f"every {getattr(args, 'event_every', 1)}-th launch of this kind inside the timed steps is bracketed by HIP events"}
+             "sampling": ("every launch of this kind in two eager steps after the timed graph replays is bracketed by HIP events"
+                          if getattr(args, "hip_graph", False) else
+                          f"every {getattr(args, 'event_every', 1)}-th launch of this kind inside the timed steps is bracketed by HIP events")}
         if issue_frac < 1.0:
             o["note"] = (f"1-D Winograd {'F(4,3)' if issue_frac == 0.5 else 'F(2,3)'}: the kernel issues "
                          f"{'1/2' if issue_frac == 0.5 else '2/3'} of the direct conv's MFMA flops; frac counts the ISSUED flops "

@@ -74,6 +74,41 @@ class _KernelEvents:
 
 KERNEL_EVENTS = _KernelEvents()
 
+
+class _FlopCount:
+    """Optional tally of the matrix-pipe work of a step (bench.py's step_issued_frac): per conv / Linear launch the
+    ALGORITHMIC flops of the op and the flops the dispatched kernel ISSUES for them (x 1/2 on the F(4,3) kernels, x 2/3 on
+    F(2,3), x 1 on the direct ones; zero padding of the direct kernels' tiles is not counted as issued work)."""
+
+    def __init__(self):
+        self.on, self.alg, self.issued, self.by = False, 0.0, 0.0, {}
+
+    def start(self):
+        self.on, self.alg, self.issued, self.by = True, 0.0, 0.0, {}
+
+    def stop(self):
+        self.on = False
+        return {"algorithmic": self.alg, "issued": self.issued, "by_kernel_family": dict(self.by)}
+
+    def add(self, flops, frac, family):
+        if self.on:
+            self.alg += flops
+            self.issued += flops * frac
+            a = self.by.setdefault(family, [0.0, 0.0])
+            a[0] += flops
+            a[1] += flops * frac
+
+
+FLOPS = _FlopCount()
+
+
+def _conv_family(wp):
+    if isinstance(wp, Wino4Packed):
+        return 0.5, "F(4,3)"
+    if isinstance(wp, WinoPacked):
+        return 2.0 / 3.0, "F(2,3)"
+    return 1.0, "direct"
+
 _workspaces = {}
 
 
@@ -236,16 +271,20 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     if Cin == 3 and stride == 1 and skip is None and mask is None and not ps_out and alpha == 1.0 and w_oihw is not None \
             and cout % 4 == 0 and 256 % (cout // 4) == 0:
         # RGB input layer: dedicated HBM-bound direct kernel on the un-packed OIHW weights
+        FLOPS.add(18.0 * N * OH * OW * Cin * cout, 0.0, "rgb (HBM-bound, VALU)")
         rc = _lib.lib().pesr_conv3x3_rgb_fwd(_p(x), _p(w_oihw), _p(bias), _p(y), N, H, W, cout, act, slope, _stream())
         _lib.check(rc, f"pesr_conv3x3_rgb_fwd[{N}x{H}x{W}x3->{cout}]")
         return y
     if rgb_out_eligible(Cin, cout, stride) and skip is None and mask is None and not ps_out and alpha == 1.0 and w_oihw is not None:
         # -> RGB output layer: dedicated HBM-bound kernel on the un-packed OIHW weights (no pack, no padded MFMAs)
+        FLOPS.add(18.0 * N * OH * OW * Cin * cout, 1.0, "rgb (HBM-bound, MFMA)")
         rc = _lib.lib().pesr_conv3x3_rgb_out_fwd(_p(x), _p(w_oihw), _p(bias), _p(y), N, H, W, Cin, act, slope, _stream())
         _lib.check(rc, f"pesr_conv3x3_rgb_out_fwd[{N}x{H}x{W}x{Cin}->3]")
         return y
     if callable(wp):
         wp = wp()
+    if FLOPS.on:
+        FLOPS.add(18.0 * N * OH * OW * Cin * cout, *_conv_family(wp))
     br = KERNEL_EVENTS.begin("fwd", N, H, W, Cin, cout, stride)
     L = _lib.lib()
     if isinstance(wp, (WinoPacked, Wino4Packed)):
@@ -275,6 +314,8 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
             _chk(t, f"conv3x3_dgrad.{n}")
             assert t.shape == dx.shape
     L = _lib.lib()
+    if FLOPS.on:
+        FLOPS.add(18.0 * N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * Cin * cout, *_conv_family(wpd))
     br = KERNEL_EVENTS.begin("dgrad", N, H, W, Cin, cout, stride)
     if isinstance(wpd, (WinoPacked, Wino4Packed)):     # the input gradient is the conv of dy with the flipped, transposed kernel
         assert stride == 1
@@ -296,6 +337,7 @@ def conv3x3_rgb_dgrad(dy: torch.Tensor, w_oihw: torch.Tensor, in_shape) -> torch
     N, H, W, C = in_shape
     assert dy.shape == (N, H, W, 3) and w_oihw.shape == (3, C, 3, 3)
     dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+    FLOPS.add(18.0 * N * H * W * C * 3, 0.0, "rgb (HBM-bound, VALU)")
     rc = _lib.lib().pesr_conv3x3_rgb_dgrad(_p(dy), _p(w_oihw), _p(dx), N, H, W, C, _stream())
     _lib.check(rc, f"pesr_conv3x3_rgb_dgrad[{N}x{H}x{W}x{C}<-3]")
     return dx
@@ -329,6 +371,12 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
     ws = workspace(nbytes, x.device)
     dw = _out(dw_out, (cout, Cin, 3, 3), x.device)
     db = _out(db_out, (cout,), x.device) if want_bias else None
+    if FLOPS.on:
+        name, frac = wgrad_kernel_for(N, H, W, Cin, cout) if (stride == 1 and algo != WGRAD_DIRECT) else ("conv3x3_wgrad_kernel", 1.0)
+        if algo == WGRAD_WINO23 and frac == 0.5:
+            frac = 2.0 / 3.0
+        FLOPS.add(18.0 * N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * Cin * cout, frac,
+                  {0.5: "F(4,3)", 1.0: "direct"}.get(frac, "F(2,3)"))
     br = KERNEL_EVENTS.begin("wgrad", N, H, W, Cin, cout, stride)
     rc = L.pesr_conv3x3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, H, W, Cin, cout, stride, alpha, int(ps_in), algo, _p(ws),
                               ws.numel(), _stream())
@@ -351,6 +399,7 @@ def conv3x3_wgrad_rgb(a: torch.Tensor, b3: torch.Tensor, mode: int, alpha: float
     ws = workspace(nbytes, a.device)
     dw = _out(dw_out, (C, 3, 3, 3) if mode == 0 else (3, C, 3, 3), a.device)
     db = _out(db_out, (C if mode == 0 else 3,), a.device) if want_bias else None
+    FLOPS.add(18.0 * N * H * W * C * 3, 1.0 if C % 256 == 0 else 0.0, "rgb (HBM-bound, MFMA)" if C % 256 == 0 else "rgb (HBM-bound, VALU)")
     rc = L.pesr_conv3x3_wgrad_rgb(_p(a), _p(b3), _p(dw), _p(db), N, H, W, C, mode, alpha, _p(ws), ws.numel(), _stream())
     _lib.check(rc, "pesr_conv3x3_wgrad_rgb")
     return dw, db
@@ -512,6 +561,7 @@ def linear_fwd(x, w, b, act=ACT_NONE, slope=0.0):
     Nf = w.shape[0]
     L = _lib.lib()
     y = torch.empty((M, Nf), dtype=torch.float32, device=x.device)
+    FLOPS.add(2.0 * M * Nf * K, 1.0, "linear (HBM-bound, MFMA)")
     for m0 in range(0, M, LIN_MAXM):
         m = min(LIN_MAXM, M - m0)
         ws = workspace(L.pesr_linear_workspace_bytes(m, Nf, K), x.device)
@@ -526,6 +576,7 @@ def linear_dgrad(dy, w):
     K = w.shape[1]
     L = _lib.lib()
     dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    FLOPS.add(2.0 * M * Nf * K, 0.0, "linear (HBM-bound, VALU)")
     for m0 in range(0, M, LIN_MAXM):
         m = min(LIN_MAXM, M - m0)
         ws = workspace(L.pesr_linear_workspace_bytes(m, Nf, K), dy.device)
@@ -541,6 +592,7 @@ def linear_wgrad(dy, x, want_bias=True, dw_out=None, db_out=None, accumulate=Fal
     assert not accumulate or (dw_out is not None and (db_out is not None or not want_bias))
     dw = _out(dw_out, (Nf, K), dy.device)
     db = _out(db_out, (Nf,), dy.device) if want_bias else None
+    FLOPS.add(2.0 * M * Nf * K, 0.0, "linear (HBM-bound, VALU)")
     for m0 in range(0, M, LIN_MAXM):
         m = min(LIN_MAXM, M - m0)
         _lib.check(_lib.lib().pesr_linear_wgrad(_p(dy[m0:m0 + m]), _p(x[m0:m0 + m]), _p(dw), _p(db), m, Nf, K, int(accumulate or m0 > 0), _stream()),
