@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 class A: pass
-args = A(); args.patch_size = 48; args.num_channels = 256; args.num_blocks = 32; args.workload = sys.argv[1] if len(sys.argv) > 1 else "gan"; args.batch = 16
+args = A(); args.patch_size = 48; args.num_channels = 256; args.num_blocks = 32; args.workload = sys.argv[1] if len(sys.argv) > 1 else "gan"; args.batch = 16; args.lr = 5e-7
 dev = torch.device("cuda", 0)
 trainer, G, D, vgg = bench.build(args, dev, 1)
 lr, hr = bench.synth_batch(16, 48, 1234, dev)

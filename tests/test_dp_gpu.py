@@ -110,15 +110,22 @@ def _launch_worker(nproc, config, backend, share_gpu, out):
     return torch.load(out)
 
 
-def _oracle_step(config, nproc, dt):
-    """The CPU oracle's FIRST step on the GLOBAL batch in dtype dt (DataParallel's per-replica BatchNorm statistics) ->
-    (state, losses).  The float64 run is the truth the fp32 runs - the oracle's and ours - are measured against."""
+def _oracle_step(config, nproc, dt, perturb_seed=0):
+    """The CPU oracle's state for a step on the GLOBAL batch in dtype dt (DataParallel's per-replica BatchNorm statistics) ->
+    (state, config, batch(it)).  The float64 run is the truth the fp32 runs - the oracle's and ours - are measured against;
+    perturb_seed > 0 moves every G / D weight by one ulp up or down (an independent fp32 evaluation of the same step)."""
     from dp_worker import CONFIGS
     cfg = CONFIGS[config]
     C, depth, ps, B = cfg["C"], cfg["depth"], cfg["ps"], cfg["B"]
-    f = lambda sd: {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+
+    def f(sd, seed=0):
+        if perturb_seed and seed:
+            gen = torch.Generator().manual_seed(seed + perturb_seed)
+            sd = {k: (v * (1.0 + (torch.randint(0, 2, v.shape, generator=gen).to(v.dtype) * 2 - 1) * 2.0 ** -23)
+                      if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+        return {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
     ocfg = {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5, "dp_replicas": nproc, **cfg["alphas"]}
-    st = OS.TrainState(f(gen_sd(C, depth)), f(dis_sd(ps)), f(vgg_sd()), ocfg)
+    st = OS.TrainState(f(gen_sd(C, depth), 100), f(dis_sd(ps), 200), f(vgg_sd()), ocfg)
     return st, cfg, (lambda it: (detrand.image_batch((B * nproc, 3, ps, ps), 700 + it).to(dt),
                                  detrand.image_batch((B * nproc, 3, 4 * ps, 4 * ps), 800 + it).to(dt)))
 
@@ -134,7 +141,9 @@ LAUNCHES = [(1, "nccl", False), (2, "nccl", False), (2, "gloo", True)]
 def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_path):
     """N ranks, each on its shard, against the CPU oracle's step on the GLOBAL batch.  Gradients of the first step are held to
     the fp64 criterion of helpers.grads_vs_fp64, with the float64 oracle computed here: per tensor, our distance to the fp64
-    truth may be at most 3 x the fp32 oracle's own distance to it, never asked below twice the worst such distance of the
+    truth may be at most 3 x the fp32 oracle's own distance to it - the largest over FOUR independent fp32 evaluations (the
+    oracle itself and three with every weight moved by one ulp: a flipped LeakyReLU / ReLU mask is a discrete event, one
+    evaluation can be lucky) - never asked below twice the worst such distance of the
     network (fp32 noise is a discrete event per tensor) nor below 1e-4 - which is where the L1 ("pretrain") and TV-only ("tv")
     steps end up for the Generator (fp32 oracle vs fp64: 2e-6 and 1.5e-4 of a tensor's maximum), whose gradients are well conditioned, so a missing 1/N, a missing x N on the TV sum, a wrong shard or a dropped bucket of even a
     small tensor shows; the full GAN step ("small") is ill-conditioned in fp32 (BatchNorm over 4-sample shards, LeakyReLU
@@ -150,6 +159,11 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
     step = OS.gan_step if gan else OS.pretrain_step
     keys = ("l1", "vgg", "g", "tv", "d") if gan else ("l1",)
     step(st64, *batch64(0))
+    extra = []                  # three more fp32 evaluations of step 0 (one-ulp weight perturbations)
+    for seed in (1, 2, 3):
+        stp, _, _ = _oracle_step(config, nproc, torch.float32, perturb_seed=seed)
+        step(stp, *batch(0))
+        extra.append(stp)
     checked, worst = 0, (0.0, None)
     for it in range(cfg["steps"]):
         lr, hr = batch(it)
@@ -157,7 +171,7 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
         close(got["losses"][it].numpy(), np.array([ref[k] for k in keys]), 5e-5 if it == 0 else 5e-4, what=f"losses step {it}")
         if it:
             continue
-        for name, l32, l64 in (("G", st32.g, st64.g), ("D", st32.d, st64.d)):
+        for name, l32, l64, lex in (("G", st32.g, st64.g, [e.g for e in extra]), ("D", st32.d, st64.d, [e.d for e in extra])):
             errs = {}
             for k, v in l32.items():
                 g64 = l64[k].grad if k in l64 else None
@@ -165,7 +179,8 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
                 if k not in got[name + ".grad"] or v.grad is None or g64 is None or float(g64.abs().max()) < 1e-10:
                     continue
                 mx = float(g64.abs().max())
-                errs[k] = (float((v.grad.double() - g64).abs().max()) / mx, float((got[name + ".grad"][k].double() - g64).abs().max()) / mx)
+                e_ref = max(float((t[k].grad.double() - g64).abs().max()) / mx for t in [l32] + lex)
+                errs[k] = (e_ref, float((got[name + ".grad"][k].double() - g64).abs().max()) / mx)
             if not errs:
                 continue
             net_floor = max(e[0] for e in errs.values())
