@@ -113,6 +113,12 @@ def gan_step(st: TrainState, lr, hr, gp_u=None):
     if c.get("gan_type", "RSGAN") == "SGAN":
         d_loss = F.binary_cross_entropy_with_logits(pred_real, target_real) + \
             F.binary_cross_entropy_with_logits(pred_fake, target_fake)
+    elif c.get("gan_type") == "RaSGAN":
+        # NOT in the reference (train.py:210-213 has SGAN / RSGAN): Jolicoeur-Martineau 2018, relativistic average standard GAN,
+        # as in the paper's published code - restated here as the checker of the product's extension; batch means are over the
+        # whole (global) batch
+        d_loss = 0.5 * (F.binary_cross_entropy_with_logits(pred_real - pred_fake.mean(), target_real) +
+                        F.binary_cross_entropy_with_logits(pred_fake - pred_real.mean(), target_fake))
     else:
         d_loss = F.binary_cross_entropy_with_logits(pred_real - pred_fake, target_real)
     gp = None
@@ -134,11 +140,12 @@ def gan_step(st: TrainState, lr, hr, gp_u=None):
     tv = tv_loss(sr) * c.get("alpha_tv", 1e-6)
     gamma = c.get("fl_gamma", 1.0)
     use_focal = c.get("focal_loss", True)
-    if c.get("gan_type", "RSGAN") == "SGAN":
-        z = pred_fake
+    lf = (lambda z, t: focal_loss(z, t, gamma)) if use_focal else F.binary_cross_entropy_with_logits
+    if c.get("gan_type") == "RaSGAN":       # extension, see the discriminator phase
+        g_loss = 0.5 * (lf(pred_real - pred_fake.mean(), target_fake) + lf(pred_fake - pred_real.mean(), target_real))
     else:
-        z = pred_fake - pred_real
-    g_loss = focal_loss(z, target_real, gamma) if use_focal else F.binary_cross_entropy_with_logits(z, target_real)
+        z = pred_fake if c.get("gan_type", "RSGAN") == "SGAN" else pred_fake - pred_real
+        g_loss = lf(z, target_real)
     g_loss = g_loss * c.get("alpha_gan", 1.0)
     total = l1 + vgg + g_loss + tv
     total.backward()

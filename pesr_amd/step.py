@@ -19,6 +19,50 @@ from .model.basic import nhwc
 from .model.focal_loss import FocalLoss
 
 
+class _GlobalBatchMean(torch.autograd.Function):
+    """mean of a [B, 1] tensor over the GLOBAL batch of a data-parallel run (every rank holds B samples), differentiable.
+    The reference computes its losses on the gathered full batch (nn.DataParallel, train.py:114-118), so a loss term that
+    contains a batch mean - RaSGAN's mean(C(x)) - needs it over all ranks.  forward: all-reduce of the local sums;
+    backward: every rank's loss depends on the mean, and gradients are AVERAGED over ranks afterwards (optim.GradBuckets), so
+    a rank's samples receive sum_over_ranks(dL_r/dm) / (N B)."""
+
+    @staticmethod
+    def forward(ctx, x, world):
+        import torch.distributed as dist
+        ctx.world, ctx.n = world, x.numel()
+        s = x.sum()
+        if world > 1:
+            dist.all_reduce(s)
+        return s / (world * x.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.clone()
+        if ctx.world > 1:
+            dist.all_reduce(g)
+        return (g / (ctx.world * ctx.n)).expand(ctx.n, 1), None
+
+
+def batch_mean(x, world=1):
+    return x.mean() if world == 1 else _GlobalBatchMean.apply(x, world)
+
+
+def rasgan_d_loss(pred_real, pred_fake, target_real, target_fake, world=1):
+    """Relativistic AVERAGE standard GAN, discriminator side (Jolicoeur-Martineau 2018, eq. 10 / the published RaSGAN code):
+    [BCE(C(x_r) - mean C(x_f), 1) + BCE(C(x_f) - mean C(x_r), 0)] / 2.  An extension: the reference implements SGAN and RSGAN
+    only (train.py:210-213), while the task statement names the relativistic-average form."""
+    return 0.5 * (F.binary_cross_entropy_with_logits(pred_real - batch_mean(pred_fake, world), target_real) +
+                  F.binary_cross_entropy_with_logits(pred_fake - batch_mean(pred_real, world), target_fake))
+
+
+def rasgan_g_loss(pred_real, pred_fake, target_real, target_fake, loss_fn, world=1):
+    """Generator side: the same with the labels swapped; loss_fn = BCE-with-logits or the FocalLoss module, as the reference
+    chooses for its other GAN types (train.py:244-253)."""
+    return 0.5 * (loss_fn(pred_real - batch_mean(pred_fake, world), target_fake) +
+                  loss_fn(pred_fake - batch_mean(pred_real, world), target_real))
+
+
 def _img(x: torch.Tensor) -> torch.Tensor:
     """logical NCHW image batch -> NHWC-contiguous view/copy for the loss kernels"""
     return nhwc(x).contiguous()
@@ -84,6 +128,8 @@ class Trainer:
                 F.binary_cross_entropy_with_logits(pred_fake, target_fake)
         elif self.gan_type == "RSGAN":
             total_D_loss = F.binary_cross_entropy_with_logits(pred_real - pred_fake, target_real)
+        elif self.gan_type == "RaSGAN":
+            total_D_loss = rasgan_d_loss(pred_real, pred_fake, target_real, target_fake, self.world_size)
         else:
             raise ValueError(f"unknown gan_type {self.gan_type}")
         gp = None
@@ -114,11 +160,11 @@ class Trainer:
         pred_fake = D(sr)
         with torch.no_grad():          # D's parameters are frozen and hr needs no grad: a pure forward, as in the reference
             pred_real = D(hr_cl)
-        z = pred_fake if self.gan_type == "SGAN" else pred_fake - pred_real
-        if self.use_focal:
-            G_loss = self.f_loss_fn(z, target_real)
+        loss_fn = self.f_loss_fn if self.use_focal else F.binary_cross_entropy_with_logits
+        if self.gan_type == "RaSGAN":
+            G_loss = rasgan_g_loss(pred_real, pred_fake, target_real, target_fake, loss_fn, self.world_size)
         else:
-            G_loss = F.binary_cross_entropy_with_logits(z, target_real)
+            G_loss = loss_fn(pred_fake if self.gan_type == "SGAN" else pred_fake - pred_real, target_real)
         G_loss = G_loss * self.alpha_gan
         total_G_loss = l1_loss + vgg_loss + G_loss + tv_local * float(self.world_size)
         total_G_loss.backward()

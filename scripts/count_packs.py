@@ -5,7 +5,7 @@ import torch
 import bench
 from pesr_amd import ops
 class A: pass
-args = A(); args.patch_size = 48; args.num_channels = 256; args.num_blocks = 32; args.workload = "gan"; args.batch = 16
+args = A(); args.patch_size = 48; args.num_channels = 256; args.num_blocks = 32; args.workload = "gan"; args.batch = 16; args.lr = 5e-7
 dev = torch.device("cuda", 0)
 trainer, G, D, vgg = bench.build(args, dev, 1)
 lr, hr = bench.synth_batch(16, 48, 1234, dev)

@@ -112,3 +112,66 @@ def test_flat_params_views_and_zero_grad():
     assert v1 is not None and v1.data_ptr() == flat.flat_g.data_ptr() and v2 is None
     flat.zero_grad()
     assert PF.grad_out(ps[0]) is not None
+
+
+def _rasgan_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pesr_amd.model.focal_loss import FocalLoss
+        from pesr_amd.step import rasgan_d_loss, rasgan_g_loss
+        gen = torch.Generator().manual_seed(5)
+        B = 3
+        pr_all, pf_all = torch.randn(B * world, 1, generator=gen) * 2, torch.randn(B * world, 1, generator=gen) * 2
+        sh = slice(rank * B, (rank + 1) * B)
+        pr, pf = pr_all[sh].clone().requires_grad_(True), pf_all[sh].clone().requires_grad_(True)
+        ones, zeros = torch.ones(B, 1), torch.zeros(B, 1)
+        ld = rasgan_d_loss(pr, pf, ones, zeros, world)
+        lg = rasgan_g_loss(pr, pf, ones, zeros, FocalLoss(1.0), world)
+        (ld + 3.0 * lg).backward()
+        # what the optimizers do with the result: the local losses are MEANS over the shard, gradients are averaged over ranks
+        out = torch.stack([ld.detach(), lg.detach()])
+        dist.all_reduce(out); out /= world
+        grads = [torch.zeros(2 * B, 1) for _ in range(world)]
+        dist.all_gather(grads, torch.cat([pr.grad, pf.grad]) / world)
+        if rank == 0:
+            q.put((out, torch.cat([g[:B] for g in grads]), torch.cat([g[B:] for g in grads])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_rasgan_losses_equal_full_batch():
+    """RaSGAN's batch means are over the GLOBAL batch (step._GlobalBatchMean): two ranks with 3 samples each must produce the
+    losses and the per-sample logit gradients of one process holding all 6 (oracle-style full-batch evaluation)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    result = None
+    for attempt in range(3):
+        port, q = _free_port(), ctx.Queue()
+        procs = [ctx.Process(target=_rasgan_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            result = q.get(timeout=120)
+        except Exception:
+            result = None
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+        if result is not None and all(p.exitcode == 0 for p in procs):
+            break
+        result = None
+    assert result is not None, "the 2-rank gloo job failed three times"
+    losses, g_pr, g_pf = result
+    gen = torch.Generator().manual_seed(5)
+    pr = (torch.randn(6, 1, generator=gen) * 2).requires_grad_(True)
+    pf = (torch.randn(6, 1, generator=gen) * 2).requires_grad_(True)
+    ones, zeros = torch.ones(6, 1), torch.zeros(6, 1)
+    bce = F.binary_cross_entropy_with_logits
+    ld = 0.5 * (bce(pr - pf.mean(), ones) + bce(pf - pr.mean(), zeros))
+    lg = 0.5 * (OS.focal_loss(pr - pf.mean(), zeros, 1.0) + OS.focal_loss(pf - pr.mean(), ones, 1.0))
+    (ld + 3.0 * lg).backward()
+    assert torch.allclose(losses, torch.stack([ld.detach(), lg.detach()]), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(g_pr, pr.grad, rtol=1e-5, atol=1e-8) and torch.allclose(g_pf, pf.grad, rtol=1e-5, atol=1e-8)

@@ -244,7 +244,7 @@ def test_config5_large_tiles_64bit_indexing():
         assert float((a - b).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize("gan_type,focal", [("SGAN", False), ("SGAN", True), ("RSGAN", False)])
+@pytest.mark.parametrize("gan_type,focal", [("SGAN", False), ("SGAN", True), ("RSGAN", False), ("RaSGAN", True), ("RaSGAN", False)])
 def test_gan_step_other_branches_vs_oracle(gan_type, focal):
     """The non-default branches of reference train.py:210-213,244-253 (SGAN, plain BCE generator loss), one step."""
     from model import Discriminator, Generator, VGG

@@ -228,3 +228,36 @@ def test_gv11_gradient_penalty_step():
             continue                                              # (the golden was taken before the G phase's two D forwards)
         else:
             close(v.detach().reshape(-1)[g["pidx." + k]], g["pval." + k], 1e-5)
+
+
+def test_rasgan_extension_closed_form_gradient():
+    """RaSGAN is NOT in the reference (train.py:210-213 implements SGAN / RSGAN); the oracle restates Jolicoeur-Martineau's
+    published form.  Its discriminator-side gradient against the closed form:
+    dL/dr_i = [ (s(r_i - mf) - 1) - mean_j s(f_j - mr) ] / (2B),  dL/df_i = [ s(f_i - mr) - mean_j (s(r_j - mf) - 1) ] / (2B),
+    s = sigmoid, mr / mf the batch means; and the product's loss functions give the same numbers on the CPU."""
+    import torch.nn.functional as F
+    from pesr_amd.model.focal_loss import FocalLoss
+    from pesr_amd.step import rasgan_d_loss, rasgan_g_loss
+    gen = torch.Generator().manual_seed(9)
+    B = 7
+    r = (torch.randn(B, 1, generator=gen, dtype=torch.float64) * 3).requires_grad_(True)
+    f = (torch.randn(B, 1, generator=gen, dtype=torch.float64) * 3).requires_grad_(True)
+    ones, zeros = torch.ones(B, 1, dtype=torch.float64), torch.zeros(B, 1, dtype=torch.float64)
+    ld = 0.5 * (F.binary_cross_entropy_with_logits(r - f.mean(), ones) + F.binary_cross_entropy_with_logits(f - r.mean(), zeros))
+    ld.backward()
+    sr, sf = torch.sigmoid(r - f.mean()).detach(), torch.sigmoid(f - r.mean()).detach()
+    assert torch.allclose(r.grad, ((sr - 1) - sf.mean()) / (2 * B), rtol=1e-12, atol=1e-15)
+    assert torch.allclose(f.grad, (sf - (sr - 1).mean()) / (2 * B), rtol=1e-12, atol=1e-15)
+    r2, f2 = r.detach().clone().requires_grad_(True), f.detach().clone().requires_grad_(True)
+    l2 = rasgan_d_loss(r2, f2, ones, zeros)
+    l2.backward()
+    assert float(l2) == pytest.approx(float(ld), rel=1e-12) and torch.allclose(r2.grad, r.grad) and torch.allclose(f2.grad, f.grad)
+    # generator side with the focal loss: product module (closed-form backward) vs the oracle's composite
+    r3, f3 = r.detach().clone().requires_grad_(True), f.detach().clone().requires_grad_(True)
+    lg = rasgan_g_loss(r3, f3, ones, zeros, FocalLoss(1.0))
+    lg.backward()
+    r4, f4 = r.detach().clone().requires_grad_(True), f.detach().clone().requires_grad_(True)
+    lo = 0.5 * (OS.focal_loss(r4 - f4.mean(), zeros, 1.0) + OS.focal_loss(f4 - r4.mean(), ones, 1.0))
+    lo.backward()
+    assert float(lg) == pytest.approx(float(lo), rel=1e-12)
+    assert torch.allclose(r3.grad, r4.grad, rtol=1e-10, atol=1e-14) and torch.allclose(f3.grad, f4.grad, rtol=1e-10, atol=1e-14)
