@@ -11,6 +11,7 @@
 //             dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))
 #include "common.h"
 #include "launchers.h"
+#include "reduce_rows.h"
 
 // partial sums over rows [r0, r1) of a [M][C] array of f(x): which = 0: {x, x^2}; which = 1: {dz, dz*xhat}
 template <int WHICH>
@@ -68,13 +69,18 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ dsum, int C, long M, float eps, float momentum,
-                                   float* __restrict__ mean_invstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, long long* __restrict__ num_batches) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches) *num_batches += 1;
-    if (c >= C) return;
-    const double s = dsum[c], ss = dsum[C + c];
+// second stage of the statistics (fixed-order row reduce of the per-block partials, reduce_rows.h) and the finalize step in
+// ONE launch: block = 64 channels; the small layers' BatchNorm is launch-bound, every launch saved is ~4.5 us
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nb, int C, long M, float eps,
+                                                           float momentum, float* __restrict__ mean_invstd,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           long long* __restrict__ num_batches) {
+    __shared__ double red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const double s = reduce_rows_block(part, nb, 2 * C, c, c < C, red);
+    const double ss = reduce_rows_block(part, nb, 2 * C, C + c, c < C, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
+    if (c >= C || (threadIdx.x >> 6) != 0) return;
     const double mean = s / (double)M;
     double var = ss / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -87,14 +93,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ dsum, int C, long 
     }
 }
 
-// second-stage reduce for backward: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat
-__global__ void bn_bwd_sums_kernel(const double* __restrict__ dsum, int C, float* __restrict__ sums, float* __restrict__ dbeta,
-                                   float* __restrict__ dgamma) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * C) return;
-    const float v = (float)dsum[e];
-    sums[e] = v;
-    if (e < C) { if (dbeta) dbeta[e] = v; } else if (dgamma) dgamma[e - C] = v;   // dbeta = sum dz, dgamma = sum dz*xhat
+// second stage for backward, same fusion: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat (+ dbeta, dgamma)
+__global__ __launch_bounds__(1024) void bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    __shared__ double red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const double s0 = reduce_rows_block(part, nb, 2 * C, c, c < C, red);
+    const double s1 = reduce_rows_block(part, nb, 2 * C, C + c, c < C, red);
+    if (c >= C || (threadIdx.x >> 6) != 0) return;
+    const float a = (float)s0, b = (float)s1;
+    sums[c] = a; sums[C + c] = b;
+    if (dbeta) dbeta[c] = a;        // dbeta = sum dz, dgamma = sum dz*xhat
+    if (dgamma) dgamma[c] = b;
 }
 
 __global__ void bn_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
@@ -172,9 +182,7 @@ int pesr_bn_lrelu_fwd_launch(const float* x, const float* gamma, const float* be
     float* part = (float*)((char*)ws + dsum_bytes);
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, part, M, C, rpb, slope, 0L, 1L, 0L, HW);
-    int rc0 = pesr_reduce_rows_launch(part, dsum, (int)nb, 2 * C, stream);
-    if (rc0) return rc0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)dsum, C, M, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, M, eps, momentum,
                        mean_invstd, running_mean, running_var, num_batches);
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -201,9 +209,7 @@ int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma
     if (dy_nchw) { sn = HW * C; sc = HW; sp = 1; }
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb, slope,
                        sn, sc, sp, HW);
-    int rc0 = pesr_reduce_rows_launch(part, dsum, (int)nb, 2 * C, stream);
-    if (rc0) return rc0;
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const double*)dsum, C, sums, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, sums, dbeta, dgamma);
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, dy, mean_invstd, gamma, beta, (const float*)sums,
@@ -243,9 +249,7 @@ int pesr_bn_lrelu_bwd_eval_launch(const float* x, const float* dy, const float* 
     if (dgamma || dbeta) {
         hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb,
                            slope, sn, sc, sp, HW);
-        int rc0 = pesr_reduce_rows_launch(part, dsum, (int)nb, 2 * C, stream);
-        if (rc0) return rc0;
-        hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const double*)dsum, C, sums, dbeta, dgamma);
+        hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, sums, dbeta, dgamma);
     }
     hipError_t e = hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;

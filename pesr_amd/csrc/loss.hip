@@ -6,6 +6,7 @@
 // Sums go through per-block fp32 partials and a fixed-order double finalize (deterministic).
 #include "common.h"
 #include "launchers.h"
+#include "reduce_rows.h"
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
@@ -38,8 +39,11 @@ __global__ __launch_bounds__(256) void l1_tv_kernel(const float* __restrict__ sr
     __syncthreads();
     if (threadIdx.x < 2) part[blockIdx.x * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void l1_tv_final_kernel(const double* __restrict__ dsum, float* __restrict__ out, double inv_numel) {
-    if (threadIdx.x < 2) out[threadIdx.x] = (float)(threadIdx.x == 0 ? dsum[0] * inv_numel : dsum[1]);   // L1 mean, TV sum
+// second stage (fixed-order row reduce, reduce_rows.h) and the scalar finish in one launch
+__global__ __launch_bounds__(1024) void l1_tv_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out, double inv_numel) {
+    __shared__ double red[16][64];
+    const double t = reduce_rows_block(part, nb, 2, threadIdx.x & 63, (threadIdx.x & 63) < 2, red);
+    if (threadIdx.x < 2) out[threadIdx.x] = (float)(threadIdx.x == 0 ? t * inv_numel : t);   // L1 mean, TV sum
 }
 
 __global__ __launch_bounds__(256) void mse_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ grad,
@@ -56,8 +60,10 @@ __global__ __launch_bounds__(256) void mse_kernel(const f32x4* __restrict__ a, c
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void mse_final_kernel(const double* __restrict__ dsum, float* __restrict__ out, double inv_numel) {
-    if (threadIdx.x == 0) out[0] = (float)(dsum[0] * inv_numel);
+__global__ __launch_bounds__(1024) void mse_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out, double inv_numel) {
+    __shared__ double red[16][64];
+    const double t = reduce_rows_block(part, nb, 1, 0, (threadIdx.x & 63) == 0, red);
+    if (threadIdx.x == 0) out[0] = (float)(t * inv_numel);
 }
 
 int pesr_loss_l1_tv_launch(const float* sr, const float* hr, float* grad, float* out2, int N, int H, int W, float g_l1, float g_tv,
@@ -67,9 +73,7 @@ int pesr_loss_l1_tv_launch(const float* sr, const float* hr, float* grad, float*
     double* dsum = (double*)ws;
     float* part = (float*)((char*)ws + 64);
     hipLaunchKernelGGL(l1_tv_kernel, dim3(nb), dim3(256), 0, stream, sr, hr, grad, part, N, H, W, g_l1, g_tv);
-    const int rc = pesr_reduce_rows_launch(part, dsum, nb, 2, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(l1_tv_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)dsum, out2, 1.0 / ((double)N * H * W * 3));
+    hipLaunchKernelGGL(l1_tv_final_kernel, dim3(1), dim3(1024), 0, stream, (const float*)part, nb, out2, 1.0 / ((double)N * H * W * 3));
     return pesr_launch_status();
 }
 int pesr_loss_mse_launch(const float* a, const float* b, float* grad, float* out1, long n, float gscale, void* ws, size_t ws_bytes,
@@ -80,9 +84,7 @@ int pesr_loss_mse_launch(const float* a, const float* b, float* grad, float* out
     double* dsum = (double*)ws;
     float* part = (float*)((char*)ws + 64);
     hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, stream, (const f32x4*)a, (const f32x4*)b, (f32x4*)grad, part, n / 4, gscale);
-    const int rc = pesr_reduce_rows_launch(part, dsum, nb, 1, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)dsum, out1, 1.0 / (double)n);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(1024), 0, stream, (const float*)part, nb, out1, 1.0 / (double)n);
     return pesr_launch_status();
 }
 

@@ -6,30 +6,15 @@
 // reproducible), and no atomics are used.
 #include "common.h"
 #include "launchers.h"
+#include "reduce_rows.h"
 
 __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ part, double* __restrict__ dsum, int nb,
                                                            int ncols) {
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl;
-    double s = 0.0;
-    if (col < ncols) {
-        int k = rl;
-        for (; k + 48 < nb; k += 64) {   // 4 independent loads in flight
-            const float a = part[(size_t)k * ncols + col], b = part[(size_t)(k + 16) * ncols + col];
-            const float c = part[(size_t)(k + 32) * ncols + col], d = part[(size_t)(k + 48) * ncols + col];
-            s += (double)a; s += (double)b; s += (double)c; s += (double)d;
-        }
-        for (; k < nb; k += 16) s += (double)part[(size_t)k * ncols + col];
-    }
     __shared__ double red[16][64];
-    red[rl][cl] = s;
-    __syncthreads();
-    if (rl == 0 && col < ncols) {
-        double t = red[0][cl];
-#pragma unroll
-        for (int j = 1; j < 16; ++j) t += red[j][cl];
-        dsum[col] = t;
-    }
+    const double t = reduce_rows_block(part, nb, ncols, col, col < ncols, red);
+    if (rl == 0 && col < ncols) dsum[col] = t;
 }
 
 int pesr_reduce_rows_launch(const float* part, double* dsum, int nb, int ncols, hipStream_t stream) {

@@ -88,12 +88,13 @@ _ALL_PACKS = []   # weak registry of every PackedConvWeights (for the batched re
 
 class _PackSlot:
     """The packed layouts of one weight tensor ON ONE DEVICE."""
-    __slots__ = ("fwd", "dgrad", "bias", "wfwd", "wdgrad", "w4fwd", "w4dgrad", "kf", "kd", "kb", "kwf", "kwd", "k4f", "k4d", "wref")
+    __slots__ = ("fwd", "dgrad", "bias", "wfwd", "wdgrad", "w4fwd", "w4dgrad", "kf", "kd", "kb", "kwf", "kwd", "k4f", "k4d", "wref", "bref")
 
     def __init__(self):
         self.fwd = self.dgrad = self.bias = self.wfwd = self.wdgrad = self.w4fwd = self.w4dgrad = None
         self.kf = self.kd = self.kb = self.kwf = self.kwd = self.k4f = self.k4d = None
         self.wref = None            # weakref to the weight tensor this slot was last built from
+        self.bref = None            # ... and to the bias tensor of its PixelShuffle-permuted copy
 
 
 class PackedConvWeights:
@@ -192,6 +193,9 @@ class PackedConvWeights:
             if sl.kb != k:
                 sl.bias = ops.pack_bias_ps(b.detach())
                 sl.kb = k
+            if sl.bref is None or sl.bref() is not b:
+                import weakref
+                sl.bref = weakref.ref(b)
             return sl.bias
 
 
@@ -274,7 +278,8 @@ _REPACK_TABLES_MAX = 8
 # the packings the replayed launch refreshed.
 _REPACK_RECORD = None
 
-_SLOT_FIELD = {0: ("fwd", "kf"), 1: ("dgrad", "kd"), 2: ("wfwd", "kwf"), 3: ("wdgrad", "kwd"), 4: ("w4fwd", "k4f"), 5: ("w4dgrad", "k4d")}
+_SLOT_FIELD = {0: ("fwd", "kf"), 1: ("dgrad", "kd"), 2: ("wfwd", "kwf"), 3: ("wdgrad", "kwd"), 4: ("w4fwd", "k4f"), 5: ("w4dgrad", "k4d"),
+               6: ("bias", "kb")}      # 6: the PixelShuffle-permuted bias (its source tensor is the slot's bref, not wref)
 
 
 def _slot_buffer(sl, mode):
@@ -287,7 +292,7 @@ def stamp_repacked(jobs) -> None:
     buffer is no longer the recorded one (an eager rebuild replaced it) is left alone: its key then misses and it is rebuilt
     on next use."""
     for sl, wref, mode, ptr in jobs:
-        w = wref()
+        w = wref()          # (mode 6: the bias tensor)
         buf = _slot_buffer(sl, mode)
         if w is None or buf is None or buf.data_ptr() != ptr:
             continue
@@ -322,6 +327,24 @@ def repack_all(params) -> None:
                 if wpk is not None:
                     fwd_like = mode in (2, 4)
                     jobs.append((sl, w, mode, (w.data_ptr(), wpk.t.data_ptr(), O, I, mode, int(c.ps), I if fwd_like else O, O if fwd_like else I)))
+    # PixelShuffle-permuted biases of these parameters: refreshed in place too (two tiny launches for the Generator).  Left to the
+    # lazy per-forward check they were re-packed on every forward - and a captured step whose capture happened to find the key
+    # current (a forward between the last optimizer step and the capture) would never refresh them at all.
+    bias_rec = []
+    for ref in list(_ALL_PACKS):
+        c = ref()
+        if c is None:
+            continue
+        for sl in list(c._slots.values()):
+            b = sl.bref() if sl.bref is not None else None
+            if b is None or sl.bias is None or id(b) not in ids or not b.is_cuda:
+                continue
+            ops.pack_bias_ps(b.detach(), out=sl.bias)
+            bias_rec.append((sl, sl.bref, 6, sl.bias.data_ptr()))
+    if bias_rec:
+        if _REPACK_RECORD is not None:
+            _REPACK_RECORD.append((bias_rec, None, [sl.bias for sl, _, _, _ in bias_rec]))
+        stamp_repacked(bias_rec)
     if not jobs:
         return
     dev = jobs[0][1].device

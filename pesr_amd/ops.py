@@ -137,9 +137,11 @@ def pack_conv3x3(w: torch.Tensor, mode: int, ps: bool = False) -> torch.Tensor:
     return out
 
 
-def pack_bias_ps(b: torch.Tensor) -> torch.Tensor:
+def pack_bias_ps(b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(b, "pack_bias_ps.b")
-    out = torch.empty_like(b)
+    if out is None:
+        out = torch.empty_like(b)
+    assert out.shape == b.shape and out.is_contiguous()
     _lib.check(_lib.lib().pesr_pack_bias_ps(_p(b), _p(out), b.numel(), _stream()), "pesr_pack_bias_ps")
     return out
 
