@@ -71,13 +71,17 @@ int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float
  * 64-multiple channels; half the multiplies), else the F(2,3) one (even width >= 48; 2/3), else the direct kernel;
  * PESR_WGRAD_DIRECT = the direct kernel everywhere; PESR_WGRAD_WINO23 = F(2,3) where it applies, else direct.  All produce
  * the same gradient up to fp32 rounding (measured vs fp64: <= 2e-6 of the gradient's maximum); the choice is an argument,
- * never process state. */
+ * never process state.
+ * accumulate = 1: dw (and db) are ADDED TO instead of overwritten - the second contribution of a layer that is used twice in one
+ * backward pass (the Discriminator sees hr and sr in one graph, reference train.py:205-214), written straight into the
+ * gradient buffer the first use filled; stands in for autograd's fan-in add_.  (The F(2,3) form has no such mode: an
+ * accumulating call runs on the F(4,3) or the direct kernel.) */
 #define PESR_WGRAD_AUTO 0
 #define PESR_WGRAD_DIRECT 1
 #define PESR_WGRAD_WINO23 2
 size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo);
 int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                       int stride, float alpha, int ps_in, int algo, void* workspace, size_t ws_bytes, void* stream);
+                       int stride, float alpha, int ps_in, int algo, int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
 /* Stride-1 3x3 conv (pad 1) with a 1-D Winograd F(2,3) transform along x: 2/3 of the multiplies of pesr_conv3x3_fwd, same
  * tensors and fused epilogue (y = act(alpha * (conv + bias) [masked] + skip)), for even W, Cin % 16 == 0, Cout % 128 == 0
@@ -123,10 +127,11 @@ int pesr_conv3x3_rgb_dgrad(const float* dy, const float* w, float* dx, int N, in
 /* Weight gradient of the RGB-boundary convs (one operand has 3 channels): reference `embed`
  * (model/pesr.py:23), Discriminator features.0 (model/pesr.py:53), Upsampler's last conv (model/basic.py:60).
  * a: the C-channel tensor [N][H][W][C], b3: the 3-channel tensor [N][H][W][3].
- * mode 0 (3 -> C): a = dy, b3 = x, dw [C][3][3][3], db [C].  mode 1 (C -> 3): a = x, b3 = dy, dw [3][C][3][3], db [3]. */
+ * mode 0 (3 -> C): a = dy, b3 = x, dw [C][3][3][3], db [C].  mode 1 (C -> 3): a = x, b3 = dy, dw [3][C][3][3], db [3].
+ * accumulate = 1: dw is added to (db must then be NULL), as for pesr_conv3x3_wgrad. */
 size_t pesr_conv3x3_wgrad_rgb_workspace_bytes(int N, int H, int W, int C);
 int pesr_conv3x3_wgrad_rgb(const float* a, const float* b3, float* dw, float* db, int N, int H, int W, int C, int mode,
-                           float alpha, void* workspace, size_t ws_bytes, void* stream);
+                           float alpha, int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- MeanShift: trainable 1x1 conv 3->3 (reference model/basic.py:9-17) ----------- */
 /* x_nchw / y_nchw: the 3-channel tensor is stored NCHW-contiguous instead of NHWC (folds the layout
@@ -159,9 +164,10 @@ size_t pesr_bn_workspace_bytes(long M, int C);
 int pesr_bn_lrelu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_invstd,
                       float* running_mean, float* running_var, long long* num_batches, int N, int H, int W, int C, float eps,
                       float momentum, float slope, int y_nchw, void* workspace, size_t ws_bytes, void* stream);
+/* accumulate = 1: dgamma / dbeta are added to instead of overwritten (second use of the layer in one backward pass). */
 int pesr_bn_lrelu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
                       float* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw,
-                      void* workspace, size_t ws_bytes, void* stream);
+                      int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
 /* Eval-mode BatchNorm2d (+ activation): the statistics are GIVEN - mean_invstd [2][C] = {running_mean, 1/sqrt(running_var + eps)}
  * (nn.BatchNorm2d in .eval(), a constructor branch of reference model/basic.py:29 the reference's own scripts never take).

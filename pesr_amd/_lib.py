@@ -26,13 +26,13 @@ SIGNATURES = {
     "pesr_conv3x3_dgrad": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P,
                                    c_size_t, _P]),
     "pesr_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "pesr_conv3x3_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P,
+    "pesr_conv3x3_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, _P,
                                    c_size_t, _P]),
 }
 
 SIGNATURES.update({
     "pesr_conv3x3_wgrad_rgb_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "pesr_conv3x3_wgrad_rgb": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    "pesr_conv3x3_wgrad_rgb": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_size_t, _P]),
     "pesr_conv3x3_wino_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "pesr_pack_conv3x3_wino": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "pesr_conv3x3_wino": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
@@ -54,7 +54,7 @@ SIGNATURES.update({
     "pesr_bn_workspace_bytes": (c_size_t, [c_long, c_int]),
     "pesr_bn_lrelu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                                   c_int, _P, c_size_t, _P]),
-    "pesr_bn_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_size_t,
+    "pesr_bn_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P, c_size_t,
                                   _P]),
     "pesr_bn_lrelu_eval_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "pesr_bn_lrelu_eval_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_size_t, _P]),

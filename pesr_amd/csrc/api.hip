@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 7; }
+PESR_API int pesr_abi_version(void) { return 8; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -48,8 +48,9 @@ PESR_API size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin,
     return pesr_conv3x3_wgrad_ws_bytes(N, H, W, Cin, Cout, stride, algo);
 }
 PESR_API int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                                int stride, float alpha, int ps_in, int algo, void* workspace, size_t ws_bytes, void* stream) {
-    return pesr_conv3x3_wgrad_launch(x, dy, dw, db, N, H, W, Cin, Cout, stride, alpha, ps_in, algo, workspace, ws_bytes,
+                                int stride, float alpha, int ps_in, int algo, int accumulate, void* workspace, size_t ws_bytes,
+                                void* stream) {
+    return pesr_conv3x3_wgrad_launch(x, dy, dw, db, N, H, W, Cin, Cout, stride, alpha, ps_in, algo, accumulate, workspace, ws_bytes,
                                      (hipStream_t)stream);
 }
 
@@ -57,8 +58,8 @@ PESR_API size_t pesr_conv3x3_wgrad_rgb_workspace_bytes(int N, int H, int W, int 
     return pesr_conv3x3_wgrad_rgb_ws_bytes(N, H, W, C);
 }
 PESR_API int pesr_conv3x3_wgrad_rgb(const float* a, const float* b3, float* dw, float* db, int N, int H, int W, int C, int mode,
-                                    float alpha, void* workspace, size_t ws_bytes, void* stream) {
-    return pesr_conv3x3_wgrad_rgb_launch(a, b3, dw, db, N, H, W, C, mode, alpha, workspace, ws_bytes, (hipStream_t)stream);
+                                    float alpha, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_conv3x3_wgrad_rgb_launch(a, b3, dw, db, N, H, W, C, mode, alpha, accumulate, workspace, ws_bytes, (hipStream_t)stream);
 }
 
 PESR_API int pesr_meanshift_fwd(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int x_nchw,
@@ -101,9 +102,9 @@ PESR_API int pesr_bn_lrelu_fwd(const float* x, const float* gamma, const float* 
 }
 PESR_API int pesr_bn_lrelu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
                                float* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw,
-                               void* workspace, size_t ws_bytes, void* stream) {
+                               int accumulate, void* workspace, size_t ws_bytes, void* stream) {
     return pesr_bn_lrelu_bwd_launch(x, dy, gamma, beta, mean_invstd, dx, dgamma, dbeta, (long)N * H * W, C, (long)H * W, slope,
-                                    dy_nchw, workspace, ws_bytes, (hipStream_t)stream);
+                                    dy_nchw, accumulate, workspace, ws_bytes, (hipStream_t)stream);
 }
 
 PESR_API int pesr_bn_lrelu_eval_fwd(const float* x, const float* gamma, const float* beta, const float* mean_invstd, float* y, int N,

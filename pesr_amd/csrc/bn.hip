@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 
 // second stage for backward, same fusion: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat (+ dbeta, dgamma)
 __global__ __launch_bounds__(1024) void bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums,
-                                                           float* __restrict__ dbeta, float* __restrict__ dgamma) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma, int accumulate) {
     __shared__ double red[16][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const double s0 = reduce_rows_block(part, nb, 2 * C, c, c < C, red);
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_sums_kernel(const float* __restri
     if (c >= C || (threadIdx.x >> 6) != 0) return;
     const float a = (float)s0, b = (float)s1;
     sums[c] = a; sums[C + c] = b;
-    if (dbeta) dbeta[c] = a;        // dbeta = sum dz, dgamma = sum dz*xhat
-    if (dgamma) dgamma[c] = b;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;        // dbeta = sum dz, dgamma = sum dz*xhat
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + b : b;
 }
 
 __global__ void bn_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
@@ -195,8 +195,8 @@ int pesr_bn_lrelu_fwd_launch(const float* x, const float* gamma, const float* be
 
 // backward: dy is the gradient w.r.t. the LeakyReLU output (NHWC, or NCHW when dy_nchw); dgamma/dbeta may be NULL
 int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
-                             float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, void* ws,
-                             size_t ws_bytes, hipStream_t stream) {
+                             float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, int accumulate,
+                             void* ws, size_t ws_bytes, hipStream_t stream) {
     if (C % 4) return PESR_EINVAL;
     long nb, rpb; bn_grid(M, &nb, &rpb);
     const size_t part_bytes = (size_t)nb * 2 * C * sizeof(float);
@@ -209,7 +209,8 @@ int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma
     if (dy_nchw) { sn = HW * C; sc = HW; sp = 1; }
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb, slope,
                        sn, sc, sp, HW);
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, sums, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, sums, dbeta, dgamma,
+                       accumulate);
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, dy, mean_invstd, gamma, beta, (const float*)sums,
@@ -249,7 +250,7 @@ int pesr_bn_lrelu_bwd_eval_launch(const float* x, const float* dy, const float* 
     if (dgamma || dbeta) {
         hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb,
                            slope, sn, sc, sp, HW);
-        hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, sums, dbeta, dgamma);
+        hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, sums, dbeta, dgamma, 0);
     }
     hipError_t e = hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;

@@ -236,9 +236,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
 // dw[o][i][t] = alpha * sum_s slab[s][t][p][i]   (p = packed channel of o when ps).
 // The fused bias gradient rides along: db[o] = alpha * sum_rows bias_part[row][p] (fixed order, double) for the first
 // Cout threads of the grid.
+// accumulate: dw / db are added to instead of overwritten (a layer's SECOND contribution inside one backward pass).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int split, int Cout, int Cin,
                                     float alpha, int ps, const float* __restrict__ bias_part, int bias_rows,
-                                    float* __restrict__ db) {
+                                    float* __restrict__ db, int accumulate) {
     const long total = 9L * Cout * Cin;
     const int C = Cout >> 2;
     if (bias_part) {
@@ -248,7 +249,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
             for (int k = 0; k < bias_rows; ++k) s += (double)bias_part[(size_t)k * Cout + p];
             int o = (int)p;
             if (ps) { const int sub = (int)p / C, cc = (int)p - sub * C; o = 4 * cc + sub; }
-            db[o] = alpha * (float)s;
+            db[o] = alpha * (float)s + (accumulate ? db[o] : 0.f);
         }
     }
     // one thread = 4 consecutive ci of one (tap, co): `split` independent 16-B loads, 8 in flight, summed in slab order
@@ -272,7 +273,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
         int o = p;
         if (ps) { const int sub = p / C, cc = p - sub * C; o = 4 * cc + sub; }
         float* d = dw + ((size_t)o * Cin + ci) * 9 + t;
-        d[0] = alpha * s.x; d[9] = alpha * s.y; d[18] = alpha * s.z; d[27] = alpha * s.w;
+        if (accumulate) { d[0] += alpha * s.x; d[9] += alpha * s.y; d[18] += alpha * s.z; d[27] += alpha * s.w; }
+        else { d[0] = alpha * s.x; d[9] = alpha * s.y; d[18] = alpha * s.z; d[27] = alpha * s.w; }
     }
 }
 
@@ -407,10 +409,11 @@ static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
 }  // namespace
 
 int pesr_wgrad_reduce_launch(const float* slab, float* dw, int split, int Cout, int Cin, float alpha, int ps, const float* bias_part,
-                             int bias_rows, float* db, hipStream_t stream) {
+                             int bias_rows, float* db, int accumulate, hipStream_t stream) {
     const long total = 9L * Cout * Cin;
     const int rgrid = (int)((total / 4 + 255) / 256 < 2048 ? (total / 4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, slab, dw, split, Cout, Cin, alpha, ps, bias_part, bias_rows, db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, slab, dw, split, Cout, Cin, alpha, ps, bias_part, bias_rows, db,
+                       accumulate);
     return pesr_launch_status();
 }
 
@@ -433,17 +436,18 @@ size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int s
 }
 
 int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                              int stride, float alpha, int ps_in, int algo, void* ws, size_t ws_bytes, hipStream_t stream) {
+                              int stride, float alpha, int ps_in, int algo, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
     WgradPlan p;
     if (algo < 0 || algo > 2) return PESR_EINVAL;
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return PESR_EINVAL;
     if (ws_bytes < p.total_bytes || !ws) return PESR_EWORKSPACE;
     if (ps_in && (stride != 1 || Cout % 16)) return PESR_EINVAL;
     if (stride == 1 && algo == 0) {   // Winograd F(4,3) where it applies (width % 4 == 0 and >= 48, 64-multiple channels)
-        const int rc = pesr_conv3x3_wgrad_wino4_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, ws, ws_bytes, stream);
+        const int rc = pesr_conv3x3_wgrad_wino4_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, accumulate, ws, ws_bytes, stream);
         if (rc != PESR_EINVAL && rc != PESR_EWORKSPACE) return rc;
     }
-    if (stride == 1 && (algo == 0 || algo == 2)) {   // Winograd F(2,3) where it applies (even width >= 48, 64-multiple channels)
+    // (the F(2,3) form's own reduce kernel has no accumulate mode: such a call goes to the direct kernel)
+    if (stride == 1 && (algo == 0 || algo == 2) && !accumulate) {   // Winograd F(2,3) where it applies (even width >= 48, 64-multiple channels)
         const int rc = pesr_conv3x3_wgrad_wino_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, ws, ws_bytes, stream);
         if (rc != PESR_EINVAL && rc != PESR_EWORKSPACE) return rc;
     }
@@ -457,6 +461,7 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     const size_t bias_rows = (size_t)p.split;
     const size_t bias_need = (size_t)Cout * sizeof(double) + bias_rows * Cout * sizeof(float) + 256;
     const bool fuse_bias = db != nullptr && ws_bytes - p.slab_bytes >= bias_need;
+    if (accumulate && db && !fuse_bias) return PESR_EWORKSPACE;      // the stand-alone bias-gradient kernels overwrite
     a.bias_part = fuse_bias ? (float*)((char*)ws + p.slab_bytes + (((size_t)Cout * sizeof(double) + 255) / 256) * 256) : nullptr;
     int rc;
 #define PESR_WG(S_, TWO_, R_) (p.cow == 4 ? launch_wgrad<4, S_, TWO_, R_>(a, p.split, stream) : launch_wgrad<2, S_, TWO_, R_>(a, p.split, stream))
@@ -467,7 +472,7 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     const long total = 9L * Cout * Cin;
     const int rgrid = (int)((total / 4 + 255) / 256 < 2048 ? (total / 4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in,
-                       fuse_bias ? (const float*)a.bias_part : (const float*)nullptr, (int)bias_rows, db);
+                       fuse_bias ? (const float*)a.bias_part : (const float*)nullptr, (int)bias_rows, db, accumulate);
     rc = pesr_launch_status();
     if (rc || !db || fuse_bias) return rc;
     float* part = (float*)((char*)ws + p.slab_bytes);

@@ -431,7 +431,7 @@ size_t pesr_conv3x3_wgrad_wino4_ws_bytes(int N, int H, int W, int Cin, int Cout)
 
 // returns PESR_EINVAL when the shape is not covered (the caller then tries the F(2,3) form / the direct kernel)
 int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                                    float alpha, int ps_in, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                    float alpha, int ps_in, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
     Wg4Plan p;
     if (!wg4_plan(N, H, W, Cin, Cout, &p)) return PESR_EINVAL;
     if (!ws || ws_bytes < p.total_bytes) return PESR_EWORKSPACE;
@@ -455,5 +455,5 @@ int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, 
     int rc = pesr_launch_status();
     if (rc) return rc;
     // the partial blocks already are dw in tap order: the direct kernel's fixed-order reduce finishes the job
-    return pesr_wgrad_reduce_launch((const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in, (const float*)a.bias_part, p.split, db, stream);
+    return pesr_wgrad_reduce_launch((const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in, (const float*)a.bias_part, p.split, db, accumulate, stream);
 }

@@ -15,13 +15,13 @@ int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* 
 
 size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo);
 int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                              int stride, float alpha, int ps_in, int algo, void* ws, size_t ws_bytes, hipStream_t stream);
+                              int stride, float alpha, int ps_in, int algo, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 int pesr_bias_grad_launch(const float* dy, float* db, long pixels, int Cout, int OW, float alpha, int ps_in, float* part,
                           size_t part_bytes, hipStream_t stream);
 
 size_t pesr_conv3x3_wgrad_rgb_ws_bytes(int N, int H, int W, int C);
 int pesr_conv3x3_wgrad_rgb_launch(const float* A, const float* b3, float* dw, float* db, int N, int H, int W, int C, int mode,
-                                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream);
+                                  float alpha, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 
 int pesr_meanshift_fwd_launch(const float* x, const float* w, const float* b, float* y, int N, int H, int W, long xsn, long xsc,
                               long xsp, long ysn, long ysc, long ysp, hipStream_t stream);
@@ -37,8 +37,8 @@ int pesr_bn_lrelu_fwd_launch(const float* x, const float* gamma, const float* be
                              float* running_mean, float* running_var, long long* num_batches, long M, int C, long HW, float eps,
                              float momentum, float slope, int y_nchw, void* ws, size_t ws_bytes, hipStream_t stream);
 int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
-                             float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, void* ws,
-                             size_t ws_bytes, hipStream_t stream);
+                             float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, int accumulate,
+                             void* ws, size_t ws_bytes, hipStream_t stream);
 
 int pesr_bn_lrelu_apply_launch(const float* x, const float* gamma, const float* beta, const float* mean_invstd, float* y, long M,
                                int C, long HW, float slope, int y_nchw, hipStream_t stream);
@@ -72,11 +72,11 @@ int pesr_reduce_rows_launch(const float* part, double* dsum, int nb, int ncols, 
 
 // fixed-order split-K reduce of the direct wgrad kernel: slab [split][9][Cout][Cin] -> dw OIHW (+ bias partials -> db)
 int pesr_wgrad_reduce_launch(const float* slab, float* dw, int split, int Cout, int Cin, float alpha, int ps, const float* bias_part,
-                             int bias_rows, float* db, hipStream_t stream);
+                             int bias_rows, float* db, int accumulate, hipStream_t stream);
 // transposed Winograd F(4,3) weight gradient (conv3x3_wgrad_wino4.hip); PESR_EINVAL for shapes it does not cover
 size_t pesr_conv3x3_wgrad_wino4_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                                    float alpha, int ps_in, void* ws, size_t ws_bytes, hipStream_t stream);
+                                    float alpha, int ps_in, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 // transposed Winograd weight gradient (conv3x3_wgrad_wino.hip); the launch returns PESR_EINVAL for shapes it does not cover
 size_t pesr_conv3x3_wgrad_wino_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int pesr_conv3x3_wgrad_wino_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,

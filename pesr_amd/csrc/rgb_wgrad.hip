@@ -10,6 +10,7 @@
 // second kernel in a fixed order (deterministic).
 #include "common.h"
 #include "launchers.h"
+#include "reduce_rows.h"
 
 // B3 [N][H][W][3] -> zero-padded [N][H+2][W+2][3]
 __global__ void pad_rgb_kernel(const float* __restrict__ b3, float* __restrict__ out, int N, int H, int W) {
@@ -151,15 +152,19 @@ __global__ __launch_bounds__(256) void corr_rgb_mfma_kernel(const float* __restr
             }
 }
 
-__global__ void corr_rgb_final_kernel(const double* __restrict__ dsum, float* __restrict__ dw, int C, int mode, float alpha) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // e = c*27 + oy*9 + ox*3 + k
-    if (e >= C * 27) return;
-    const double s = dsum[e];
+// second stage (fixed-order row reduce over the split partials, reduce_rows.h) and the store into the parameter's layout
+__global__ __launch_bounds__(1024) void corr_rgb_final_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ dw, int C,
+                                                              int mode, float alpha, int accumulate) {
+    __shared__ double red[16][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);  // e = c*27 + oy*9 + ox*3 + k
+    const double s = reduce_rows_block(part, nsplit, C * 27, e, e < C * 27, red);
+    if (e >= C * 27 || (threadIdx.x >> 6) != 0) return;
     const int c = e / 27, rem = e - c * 27;
     const int oy = rem / 9, ox = (rem - oy * 9) / 3, k = rem % 3;
     const float v = alpha * (float)s;
-    if (mode == 0) dw[((c * 3 + k) * 3 + oy) * 3 + ox] = v;                    // [C][3][3][3]
-    else dw[(((size_t)k * C + c) * 3 + (2 - oy)) * 3 + (2 - ox)] = v;          // [3][C][3][3]
+    float* d = mode == 0 ? dw + ((c * 3 + k) * 3 + oy) * 3 + ox                        // [C][3][3][3]
+                         : dw + (((size_t)k * C + c) * 3 + (2 - oy)) * 3 + (2 - ox);   // [3][C][3][3]
+    *d = accumulate ? *d + v : v;
 }
 
 // column sums of a 3-channel tensor [P][3] -> db[3]
@@ -208,9 +213,10 @@ size_t pesr_conv3x3_wgrad_rgb_ws_bytes(int N, int H, int W, int C) {
 }
 
 int pesr_conv3x3_wgrad_rgb_launch(const float* A, const float* b3, float* dw, float* db, int N, int H, int W, int C, int mode,
-                                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                  float alpha, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
     RgbPlan p;
     if (!rgb_plan(N, H, W, C, &p)) return PESR_EINVAL;
+    if (accumulate && db) return PESR_EINVAL;
     if (!ws || ws_bytes < p.total) return PESR_EWORKSPACE;
     float* b3p = (float*)ws;
     float* part = (float*)((char*)ws + p.pad_bytes);
@@ -225,10 +231,9 @@ int pesr_conv3x3_wgrad_rgb_launch(const float* A, const float* b3, float* dw, fl
     } else {
         hipLaunchKernelGGL(corr_rgb_kernel, dim3(((C + 63) / 64) * p.nsplit), dim3(64), 0, stream, A, (const float*)b3p, part, N * H, H, W, C, p.rows_per_split);
     }
-    int rc = pesr_reduce_rows_launch(part, dsum, p.nsplit, C * 27, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(corr_rgb_final_kernel, dim3((C * 27 + 255) / 256), dim3(256), 0, stream, (const double*)dsum, dw, C, mode, alpha);
-    rc = pesr_launch_status();
+    hipLaunchKernelGGL(corr_rgb_final_kernel, dim3((C * 27 + 63) / 64), dim3(1024), 0, stream, (const float*)part, p.nsplit, dw, C, mode, alpha,
+                       accumulate);
+    int rc = pesr_launch_status();
     if (rc || !db) return rc;
     const long P = (long)N * H * W;
     if (mode == 0) return pesr_bias_grad_launch(A, db, P, C, W, alpha, 0, bpart, p.bias_bytes, stream);  // needs C % 4 == 0

@@ -208,6 +208,7 @@ _SIDE = {}
 # without BatchNorm (the Generator's), "d" only the conv+BN blocks (the Discriminator's)
 SIDE_MODE = __import__("os").environ.get("PESR_SIDE_STREAM", "0")
 USE_SIDE_STREAM = SIDE_MODE != "0"
+_SIDE_OFF = SIDE_MODE == "0"     # (in-place second-use accumulation assumes every weight gradient is written on ONE stream)
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -585,11 +586,30 @@ class ConvBnLReluFn(Function):
         gy = _c(gy)
         need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         bwd = ops.bn_lrelu_bwd if ctx.training else ops.bn_lrelu_eval_bwd
-        dz, dgamma, dbeta = bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p,
-                                dgamma_out=grad_out(gamma) if need_p else None, dbeta_out=grad_out(beta) if need_p else None)
+        # SECOND use of this block inside one backward pass (the Discriminator sees hr and sr in one graph, reference
+        # train.py:205-214): the parameter gradients are ADDED to the flat-gradient slices the first use wrote and autograd gets
+        # nothing to add - its fan-in add_ plus the copy of the sum into the flat buffer were two launches per parameter tensor
+        # (see INPLACE_SECOND_USE for when this is allowed)
+        again = INPLACE_SECOND_USE and ctx.training and need_p and ctx.needs_input_grad[1] and ctx.bias_ref is None and \
+            _SIDE_OFF and all(grad_view_claimed(p) and p.grad is None for p in (gamma, beta, weight))
+        if again:
+            a_g, a_b, a_w = grad_out_again(gamma), grad_out_again(beta), grad_out_again(weight)
+            again = a_g is not None and a_b is not None and a_w is not None
+        if again:
+            dz, _, _ = bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, True, dgamma_out=a_g, dbeta_out=a_b,
+                           accumulate=True)
+            dgamma = dbeta = None
+        else:
+            dz, dgamma, dbeta = bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p,
+                                    dgamma_out=grad_out(gamma) if need_p else None, dbeta_out=grad_out(beta) if need_p else None)
         dx = dw = db = None
         wpd = ctx.cache.for_dgrad(weight, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
-        if ctx.needs_input_grad[1]:
+        if again:
+            if x.shape[3] == 3:
+                ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=False, dw_out=a_w, accumulate=True)
+            else:
+                ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=False, dw_out=a_w, accumulate=True)
+        elif ctx.needs_input_grad[1]:
             want_b = ctx.bias_ref is not None and ctx.needs_input_grad[2]
             o_w = grad_out(weight)
             o_b = grad_out(ctx.bias_ref) if want_b else None

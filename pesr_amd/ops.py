@@ -357,9 +357,11 @@ WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23 = 0, 1, 2      # include/pesr_hip.h PESR_
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: float = 1.0, want_bias: bool = True,
-                  ps_in: bool = False, dw_out=None, db_out=None, algo=None):
+                  ps_in: bool = False, dw_out=None, db_out=None, algo=None, accumulate: bool = False):
     """(dw [O, I, 3, 3], db [O] | None).  algo: None = by the PESR_* switches (default: auto = F(4,3) where it applies, else
-    F(2,3), else direct), or one of WGRAD_AUTO / WGRAD_DIRECT / WGRAD_WINO23."""
+    F(2,3), else direct), or one of WGRAD_AUTO / WGRAD_DIRECT / WGRAD_WINO23.  accumulate: add to dw_out / db_out (which then
+    must be given) instead of overwriting them."""
+    assert not accumulate or (dw_out is not None and (db_out is not None or not want_bias))
     _chk(x, "conv3x3_wgrad.x")
     _chk(dy, "conv3x3_wgrad.dy")
     N, H, W, Cin = x.shape
@@ -380,15 +382,15 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
         FLOPS.add(18.0 * N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * Cin * cout, frac,
                   {0.5: "F(4,3)", 1.0: "direct"}.get(frac, "F(2,3)"))
     br = KERNEL_EVENTS.begin("wgrad", N, H, W, Cin, cout, stride)
-    rc = L.pesr_conv3x3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, H, W, Cin, cout, stride, alpha, int(ps_in), algo, _p(ws),
-                              ws.numel(), _stream())
+    rc = L.pesr_conv3x3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, H, W, Cin, cout, stride, alpha, int(ps_in), algo, int(accumulate),
+                              _p(ws), ws.numel(), _stream())
     KERNEL_EVENTS.end(br)
     _lib.check(rc, f"pesr_conv3x3_wgrad[{N}x{H}x{W}x{Cin}->{cout},s{stride}]")
     return dw, db
 
 
 def conv3x3_wgrad_rgb(a: torch.Tensor, b3: torch.Tensor, mode: int, alpha: float = 1.0, want_bias: bool = True,
-                      dw_out=None, db_out=None):
+                      dw_out=None, db_out=None, accumulate: bool = False):
     """Weight grad of a conv with a 3-channel side. mode 0: a=dy [N,H,W,C], b3=x -> dw [C,3,3,3]; mode 1: a=x, b3=dy -> dw [3,C,3,3]."""
     _chk(a, "conv3x3_wgrad_rgb.a")
     _chk(b3, "conv3x3_wgrad_rgb.b3")
@@ -402,7 +404,8 @@ def conv3x3_wgrad_rgb(a: torch.Tensor, b3: torch.Tensor, mode: int, alpha: float
     dw = _out(dw_out, (C, 3, 3, 3) if mode == 0 else (3, C, 3, 3), a.device)
     db = _out(db_out, (C if mode == 0 else 3,), a.device) if want_bias else None
     FLOPS.add(18.0 * N * H * W * C * 3, 1.0 if C % 256 == 0 else 0.0, "rgb (HBM-bound, MFMA)" if C % 256 == 0 else "rgb (HBM-bound, VALU)")
-    rc = L.pesr_conv3x3_wgrad_rgb(_p(a), _p(b3), _p(dw), _p(db), N, H, W, C, mode, alpha, _p(ws), ws.numel(), _stream())
+    assert not accumulate or (dw_out is not None and not want_bias)
+    rc = L.pesr_conv3x3_wgrad_rgb(_p(a), _p(b3), _p(dw), _p(db), N, H, W, C, mode, alpha, int(accumulate), _p(ws), ws.numel(), _stream())
     _lib.check(rc, "pesr_conv3x3_wgrad_rgb")
     return dw, db
 
@@ -494,8 +497,11 @@ def bn_lrelu_fwd(x, gamma, beta, running_mean, running_var, num_batches, eps=1e-
     return y, stats
 
 
-def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param_grads=True, dgamma_out=None, dbeta_out=None):
+def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param_grads=True, dgamma_out=None, dbeta_out=None,
+                 accumulate=False):
+    """accumulate: add to dgamma_out / dbeta_out (which then must be given) instead of overwriting them."""
     _chk(dy, "bn_lrelu_bwd.dy")
+    assert not accumulate or (dgamma_out is not None and dbeta_out is not None)
     N, H, W, C = x.shape
     L = _lib.lib()
     ws = workspace(L.pesr_bn_workspace_bytes(N * H * W, C), x.device)
@@ -503,7 +509,7 @@ def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param
     dgamma = _out(dgamma_out, (C,), x.device) if need_param_grads else None
     dbeta = _out(dbeta_out, (C,), x.device) if need_param_grads else None
     rc = L.pesr_bn_lrelu_bwd(_p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), N, H, W, C, slope,
-                             int(dy_nchw), _p(ws), ws.numel(), _stream())
+                             int(dy_nchw), int(accumulate), _p(ws), ws.numel(), _stream())
     _lib.check(rc, "pesr_bn_lrelu_bwd")
     return dx, dgamma, dbeta
 
