@@ -231,6 +231,18 @@ int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 int pesr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* state, float beta1, float beta2, float eps,
                        float grad_scale, void* stream);
 
+/* ---- spectral normalisation of a conv weight (reference model/basic.py:25 `spectral_norm(Conv(...))`: an undefined name there;
+ * the evident intent is torch.nn.utils.spectral_norm, whose algorithm - one power iteration per training forward - this is) ---- */
+/* w [O][K] (the OIHW tensor as it lies in memory, K = Cin * 9).  update = 1 (training): v <- normalize(W^T u), u <- normalize(W v)
+ * in place (x / max(||x||, eps)); always: sigma[0] = u^T W v, w_hat = w / sigma.  workspace: pesr_spectral_norm_workspace_bytes. */
+size_t pesr_spectral_norm_workspace_bytes(int O, int K);
+int pesr_spectral_norm_fwd(const float* w, float* u, float* v, float* w_hat, float* sigma, int O, int K, int update, float eps,
+                           void* workspace, size_t ws_bytes, void* stream);
+/* dw = (g - <g, w_hat> u v^T) / sigma for g = dL/d(w_hat), with the u, v, sigma of that forward (constants, as in torch);
+ * accumulate = 1 adds to dw. */
+int pesr_spectral_norm_bwd(const float* g, const float* w_hat, const float* u, const float* v, const float* sigma, float* dw, int O,
+                           int K, int accumulate, void* workspace, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,9 @@ def fill_state_dict(shapes: dict, seed: int, scheme: str = "default") -> dict:
             out[name] = torch.zeros(shape)
         elif name.endswith("running_var"):
             out[name] = torch.ones(shape)
+        elif name.endswith(("weight_u", "weight_v")):          # spectral norm's singular-vector estimates: unit vectors
+            t = uniform(shape, s, -1.0, 1.0)
+            out[name] = t / t.norm()
         elif len(shape) == 1 and _BN.search(name) and name.endswith("weight"):  # BatchNorm gamma (features.N.1.weight)
             out[name] = uniform(shape, s, 0.5, 1.5)
         elif len(shape) == 1 and _BN.search(name) and name.endswith("bias"):    # BatchNorm beta

@@ -61,11 +61,16 @@ def discriminator_plan():
     return plan
 
 
-def discriminator_shapes(patch_size):
-    """model/pesr.py:41-75 (patch_size is the LR size; the classifier sees 4*ps/16 squared x 512)."""
+def discriminator_shapes(patch_size, spectral_norm=False):
+    """model/pesr.py:41-75 (patch_size is the LR size; the classifier sees 4*ps/16 squared x 512).  spectral_norm: the conv
+    entries follow torch.nn.utils.spectral_norm's schema (weight_orig, weight_u [Cout], weight_v [Cin*9])."""
     s = OrderedDict()
     for i, (cin, cout, _) in enumerate(discriminator_plan()):
-        s[f"features.{i}.0.weight"] = (cout, cin, 3, 3)
+        if spectral_norm:
+            s[f"features.{i}.0.weight_orig"] = (cout, cin, 3, 3)
+            s[f"features.{i}.0.weight_u"], s[f"features.{i}.0.weight_v"] = (cout,), (cin * 9,)
+        else:
+            s[f"features.{i}.0.weight"] = (cout, cin, 3, 3)
         s[f"features.{i}.1.weight"], s[f"features.{i}.1.bias"] = (cout,), (cout,)
         s[f"features.{i}.1.running_mean"], s[f"features.{i}.1.running_var"] = (cout,), (cout,)
         s[f"features.{i}.1.num_batches_tracked"] = ()
@@ -130,13 +135,32 @@ def generator_forward(sd, x, depth, res_scale):
     return F.conv2d(h, sd["add_mean.weight"], sd["add_mean.bias"])
 
 
+def spectral_normalize(w, u, v, training, eps=1e-12):
+    """torch.nn.utils.spectral_norm's compute_weight with n_power_iterations = 1 - what reference model/basic.py:25 evidently
+    means by its (undefined) `spectral_norm`: in training mode v <- normalize(W^T u), u <- normalize(W v) IN PLACE under
+    no_grad, then sigma = u^T W v on clones of u, v (constants for autograd) and w / sigma.  Pinned against torch's own
+    implementation by tests/test_oracle_golden.py."""
+    wm = w.reshape(w.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps))
+            u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=eps))
+    uc, vc = u.clone(), v.clone()
+    sigma = torch.dot(uc, torch.mv(wm, vc))
+    return w / sigma
+
+
 def discriminator_forward(sd, x, update_running_stats=True):
     """model/pesr.py:77-81; every BasicBlock = conv(no bias) -> BatchNorm2d in TRAINING mode -> LeakyReLU(0.2)
     (model/basic.py:26-30; D is never put in eval mode).  Running stats are updated in place in
     `sd` when asked, as nn.BatchNorm2d would (momentum 0.1, unbiased variance)."""
     h = x
     for i, (_, _, stride) in enumerate(discriminator_plan()):
-        h = F.conv2d(h, sd[f"features.{i}.0.weight"], None, stride=stride, padding=1)
+        if f"features.{i}.0.weight_orig" in sd:        # --spectral_norm true: torch's spectral_norm state_dict schema
+            w = spectral_normalize(sd[f"features.{i}.0.weight_orig"], sd[f"features.{i}.0.weight_u"], sd[f"features.{i}.0.weight_v"], True)
+        else:
+            w = sd[f"features.{i}.0.weight"]
+        h = F.conv2d(h, w, None, stride=stride, padding=1)
         rm, rv = sd[f"features.{i}.1.running_mean"], sd[f"features.{i}.1.running_var"]
         if update_running_stats:
             h = F.batch_norm(h, rm, rv, sd[f"features.{i}.1.weight"], sd[f"features.{i}.1.bias"], True, 0.1, 1e-5)

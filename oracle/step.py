@@ -45,13 +45,18 @@ def tv_loss(y):
 # ------------------------------------------------------------------------------------------------
 # train state
 # ------------------------------------------------------------------------------------------------
+def is_buffer(name):
+    """state_dict entries that are buffers, not parameters: BatchNorm running statistics / counters and spectral norm's u, v."""
+    return "running" in name or name.endswith(("num_batches_tracked", "weight_u", "weight_v"))
+
+
 class TrainState:
     """Parameters as leaf tensors + torch.optim.Adam exactly as train.py:123-128 builds them."""
 
     def __init__(self, g_sd, d_sd, vgg_sd, cfg):
         self.cfg = dict(cfg)
         self.g = {k: v.clone().requires_grad_(True) for k, v in g_sd.items()}            # all of G trains (Q1)
-        self.d = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+        self.d = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not is_buffer(k) else v.clone())
                   for k, v in (d_sd or {}).items()}
         self.vgg = {k: v.clone() for k, v in (vgg_sd or {}).items()}
         lr = cfg.get("learning_rate", 5e-5)
@@ -101,7 +106,7 @@ def gan_step(st: TrainState, lr, hr, gp_u=None):
     B = lr.size(0)
     target_real = torch.ones(B, 1)
     target_fake = torch.zeros(B, 1)
-    d_leaves = [v for k, v in st.d.items() if v.is_floating_point() and "running" not in k]
+    d_leaves = [v for k, v in st.d.items() if v.is_floating_point() and not is_buffer(k)]
 
     # ---- discriminator phase (:202-229)
     for p in d_leaves:

@@ -205,3 +205,13 @@ PESR_API int pesr_psnr_y(const float* a, const float* b, double* out2, int H, in
                          size_t ws_bytes, void* stream) {
     return pesr_psnr_y_launch(a, b, out2, H, W, a_nhwc, b_nhwc, workspace, ws_bytes, (hipStream_t)stream);
 }
+
+PESR_API size_t pesr_spectral_norm_workspace_bytes(int O, int K) { return pesr_spectral_norm_ws_bytes(O, K); }
+PESR_API int pesr_spectral_norm_fwd(const float* w, float* u, float* v, float* w_hat, float* sigma, int O, int K, int update, float eps,
+                                    void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_spectral_norm_fwd_launch(w, u, v, w_hat, sigma, O, K, update, eps, workspace, ws_bytes, (hipStream_t)stream);
+}
+PESR_API int pesr_spectral_norm_bwd(const float* g, const float* w_hat, const float* u, const float* v, const float* sigma, float* dw,
+                                    int O, int K, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_spectral_norm_bwd_launch(g, w_hat, u, v, sigma, dw, O, K, accumulate, workspace, ws_bytes, (hipStream_t)stream);
+}

@@ -101,6 +101,12 @@ int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bi
                                  float slope, hipStream_t stream);
 int pesr_conv_rgb_out_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream);
 
+size_t pesr_spectral_norm_ws_bytes(int O, int K);
+int pesr_spectral_norm_fwd_launch(const float* W, float* u, float* v, float* w_hat, float* sigma, int O, int K, int update, float eps,
+                                  void* ws, size_t ws_bytes, hipStream_t stream);
+int pesr_spectral_norm_bwd_launch(const float* G, const float* w_hat, const float* u, const float* v, const float* sigma, float* dW, int O,
+                                  int K, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+
 int pesr_crop_augment_launch(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, hipStream_t stream);
 
 int pesr_psnr_y_launch(const float* a, const float* b, double* out2, int H, int W, int a_nhwc, int b_nhwc, void* ws, size_t ws_bytes,

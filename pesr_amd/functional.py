@@ -623,6 +623,40 @@ class ConvBnLReluFn(Function):
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------
+# spectral normalisation of a conv weight (reference model/basic.py:25; torch.nn.utils.spectral_norm semantics)
+# ------------------------------------------------------------------------------------------------
+_SN_STAMP = [0]
+
+
+class SpectralNormFn(Function):
+    """w_hat = w / sigma(w), sigma = u^T W v after (in training mode) one power iteration that rewrites the u / v buffers in
+    place.  backward: dw = (g - <g, w_hat> u v^T) / sigma with that forward's u, v (constants, as in torch)."""
+
+    @staticmethod
+    def forward(ctx, weight, u, v, update, eps):
+        w_hat, sigma = ops.spectral_norm_fwd(_c(weight.detach()), u, v, update, eps)
+        # (clones: the next forward's power iteration rewrites the buffers - torch clones them for the same reason, so that
+        # loss = D(real) - D(fake) can back-propagate through two forward passes)
+        ctx.save_for_backward(w_hat, u.clone(), v.clone(), sigma)
+        ctx.weight_ref = weight
+        return w_hat
+
+    @staticmethod
+    def backward(ctx, g):
+        w_hat, u, v, sigma = ctx.saved_tensors
+        return ops.spectral_norm_bwd(_c(g), w_hat, u, v, sigma, dw_out=grad_out(ctx.weight_ref)), None, None, None, None
+
+
+def spectral_normalize(weight, u, v, training, eps=1e-12):
+    """The normalised weight of a spectral_norm-wrapped conv for THIS forward.  It is a fresh tensor every time; a unique
+    (negative) epoch keeps the packed-weight caches from mistaking it for an earlier one whose memory the allocator re-used."""
+    w_hat = SpectralNormFn.apply(weight, u, v, bool(training), eps)
+    _SN_STAMP[0] += 1
+    setattr(w_hat, _EPOCH_ATTR, -_SN_STAMP[0])
+    return w_hat
+
+
 class ScaleAddFn(Function):
     """y = alpha * a + b (`res = body(x).mul(res_scale); res += x`, reference model/basic.py:49-50) - only the un-fused
     ResBlock variants need it; the default ResBlock has it in its second conv's epilogue."""

@@ -24,9 +24,23 @@ def nchw(y: torch.Tensor) -> torch.Tensor:
     return y.permute(0, 3, 1, 2)
 
 
-def spectral_norm(*_a, **_k):
-    # reference model/basic.py:25 calls an undefined name (NameError when --spectral_norm true)
-    raise NotImplementedError("spectral_norm=True is unreachable in the reference (NameError); not supported")
+def spectral_norm(conv, eps=1e-12):
+    """reference model/basic.py:25 calls `spectral_norm(Conv(...))` without importing it (NameError when --spectral_norm true,
+    SURVEY Q3); the evident intent - torch.nn.utils.spectral_norm, one power iteration per training forward - is what this
+    does to a pesr_amd Conv: same parameter / buffer names (`weight_orig`, `weight_u`, `weight_v`: torch's state_dict schema),
+    same RNG draws in the same order (u then v, standard normal, normalised), the normalised weight computed by the HIP
+    kernels of spectral_norm.hip at every forward."""
+    import torch.nn.functional as F
+    w = conv.weight
+    with torch.no_grad():
+        u = F.normalize(w.new_empty(w.shape[0]).normal_(0, 1), dim=0, eps=eps)
+        v = F.normalize(w.new_empty(w[0].numel()).normal_(0, 1), dim=0, eps=eps)
+    del conv.weight
+    conv.register_parameter("weight_orig", w)
+    conv.register_buffer("weight_u", u)
+    conv.register_buffer("weight_v", v)
+    conv._sn_eps = eps
+    return conv
 
 
 class Conv(nn.Module):
@@ -41,9 +55,16 @@ class Conv(nn.Module):
         self.bias = nn.Parameter(init.bias.data) if bias else None
         self.in_channels, self.out_channels, self.stride = in_planes, out_planes, stride
         self.packed = PF.PackedConvWeights(ps=False)
+        self._sn_eps = None          # set by spectral_norm(): the weight is then weight_orig / sigma, recomputed per forward
+
+    def effective_weight(self):
+        """The weight this forward convolves with: the parameter itself, or - under spectral_norm - weight_orig / sigma."""
+        if self._sn_eps is None:
+            return self.weight
+        return PF.spectral_normalize(self.weight_orig, self.weight_u, self.weight_v, self.training, self._sn_eps)
 
     def forward(self, x, act=ops.ACT_NONE, relu_in=False, relu_grad_by_consumer=False):
-        return nchw(PF.conv3x3(nhwc(x), self.weight, self.bias, self.packed, self.stride, act, relu_in,
+        return nchw(PF.conv3x3(nhwc(x), self.effective_weight(), self.bias, self.packed, self.stride, act, relu_in,
                                relu_grad_by_consumer))
 
     def extra_repr(self):
@@ -109,15 +130,16 @@ def _act_slope(act):
 def _conv_act(conv, x_nhwc, act):
     """conv (+bias) followed by an activation module (or None), un-fused with whatever comes next."""
     slope = _act_slope(act)
+    w = conv.effective_weight()
     if slope == 1.0:
-        return PF.conv3x3(x_nhwc, conv.weight, conv.bias, conv.packed, conv.stride)
+        return PF.conv3x3(x_nhwc, w, conv.bias, conv.packed, conv.stride)
     if slope == 0.0:
-        return PF.conv3x3(x_nhwc, conv.weight, conv.bias, conv.packed, conv.stride, act=ops.ACT_RELU)
-    return PF.ConvLReluFn.apply(x_nhwc, conv.weight, conv.bias, conv.packed, conv.stride, slope)
+        return PF.conv3x3(x_nhwc, w, conv.bias, conv.packed, conv.stride, act=ops.ACT_RELU)
+    return PF.ConvLReluFn.apply(x_nhwc, w, conv.bias, conv.packed, conv.stride, slope)
 
 
 def _conv_bn_act(conv, bn, x_nhwc, act, y_nchw=False):
-    return PF.ConvBnLReluFn.apply(x_nhwc, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+    return PF.ConvBnLReluFn.apply(x_nhwc, conv.effective_weight(), conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked, conv.packed, conv.stride, bn.eps, bn.momentum, _act_slope(act), y_nchw,
                                   bn.training or bn.running_mean is None)
 

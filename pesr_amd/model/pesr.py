@@ -79,7 +79,7 @@ def _forward_second_order(self, x):
     h = nhwc(x)
     for blk in self.features:
         conv, bn, act = blk[0], blk[1], blk[2]
-        z = PF.Conv2Fn.apply(h, conv.weight, conv.packed, conv.stride)
+        z = PF.Conv2Fn.apply(h, conv.effective_weight(), conv.packed, conv.stride)
         u = PF.Bn2Fn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum)
         h = PF.LRelu2Fn.apply(u, float(act.negative_slope))
     flat = nchw(h).contiguous().view(h.size(0), -1)          # NCHW flatten (reference model/pesr.py:79)

@@ -672,3 +672,37 @@ def psnr_y(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     rc = _lib.lib().pesr_psnr_y(ta.data_ptr(), tb.data_ptr(), out.data_ptr(), H, W, la, lb, ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "pesr_psnr_y")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# spectral normalisation (reference model/basic.py:25; torch.nn.utils.spectral_norm semantics)
+# ------------------------------------------------------------------------------------------------
+def spectral_norm_fwd(w: torch.Tensor, u: torch.Tensor, v: torch.Tensor, update: bool, eps: float = 1e-12):
+    """w [O, ...] -> (w_hat = w / sigma, sigma [1]); update: one power iteration first, u and v rewritten IN PLACE."""
+    for t, n in ((w, "w"), (u, "u"), (v, "v")):
+        _chk(t, "spectral_norm_fwd." + n)
+    O = w.shape[0]
+    K = w.numel() // O
+    assert u.numel() == O and v.numel() == K
+    L = _lib.lib()
+    ws = workspace(L.pesr_spectral_norm_workspace_bytes(O, K), w.device)
+    w_hat = torch.empty_like(w)
+    sigma = torch.empty(1, dtype=torch.float32, device=w.device)
+    rc = L.pesr_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(w_hat), _p(sigma), O, K, int(update), eps, _p(ws), ws.numel(), _stream())
+    _lib.check(rc, f"pesr_spectral_norm_fwd[{O}x{K}]")
+    return w_hat, sigma
+
+
+def spectral_norm_bwd(g: torch.Tensor, w_hat: torch.Tensor, u: torch.Tensor, v: torch.Tensor, sigma: torch.Tensor, dw_out=None,
+                      accumulate: bool = False):
+    """dL/dw for g = dL/d(w_hat) with the u, v, sigma of that forward."""
+    _chk(g, "spectral_norm_bwd.g")
+    O = g.shape[0]
+    K = g.numel() // O
+    L = _lib.lib()
+    ws = workspace(L.pesr_spectral_norm_workspace_bytes(O, K), g.device)
+    assert not accumulate or dw_out is not None
+    dw = _out(dw_out, tuple(g.shape), g.device)
+    rc = L.pesr_spectral_norm_bwd(_p(g), _p(w_hat), _p(u), _p(v), _p(sigma), _p(dw), O, K, int(accumulate), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, f"pesr_spectral_norm_bwd[{O}x{K}]")
+    return dw

@@ -208,6 +208,7 @@ class Trainer:
         steps = [o.steps for o in optims]
         watched, ops.KERNEL_EVENTS.shape = ops.KERNEL_EVENTS.shape, None       # no timing events inside a graph
         torch.cuda.synchronize()
+        self._quiesce_process_group()
         st["graph"] = torch.cuda.CUDAGraph()
         # The captured repack launches hold raw pointers of their descriptor tables and packed buffers: the record keeps those
         # objects alive for as long as the graph lives, and tells _replay which packings a replay refreshes.
@@ -224,6 +225,20 @@ class Trainer:
             self._graph = {}
         self._graph[kind] = st
         return self.gan_step_graphed if kind == "gan" else self.pretrain_step_graphed
+
+    @staticmethod
+    def _quiesce_process_group():
+        """Before a capture in a process that has issued RCCL collectives: give ProcessGroupNCCL's watchdog thread time to reap
+        the finished work objects of the eager steps.  The watchdog polls every 100 ms and hipEventQuery()s the end events of
+        the works still on its list; those events live on RCCL's communication stream, which becomes part of the capture when the
+        first captured all-reduce forks into it - a query from the watchdog then fails with "operation not permitted when stream
+        is capturing", the watchdog throws and the process aborts (seen once in three runs of the forced-DP graph test).  Works
+        launched UNDER capture are never put on that list.  After a device synchronize every listed work is complete, so two
+        polling periods empty the list."""
+        import time
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            time.sleep(0.3)
 
     def _replay(self, kind, lr, hr, gp_u=None):
         assert self._graph and kind in self._graph, f"capture_{kind}_step first"

@@ -21,8 +21,8 @@ def gen_sd(C, depth, seed=0):
     return {k: sd[k] for k in OM.generator_shapes(C, depth)}
 
 
-def dis_sd(ps, seed=1):
-    return detrand.fill_state_dict(OM.discriminator_shapes(ps), seed)
+def dis_sd(ps, seed=1, spectral_norm=False):
+    return detrand.fill_state_dict(OM.discriminator_shapes(ps, spectral_norm), seed)
 
 
 def vgg_sd(seed=2):

@@ -193,3 +193,26 @@ def test_train_refuses_a_gan_run_without_pretrained_vgg():
         Tm.check_limits(Tm.build_parser().parse_args(["--batch_size", "10"]), 4)
     with pytest.raises(SystemExit, match="patch_size"):
         Tm.check_limits(Tm.build_parser().parse_args(["--patch_size", "22"]), 1)
+
+
+def test_spectral_norm_discriminator_schema_matches_torch():
+    """Discriminator(spectral_norm=True): state_dict keys / shapes / order and the seeded construction (RNG draws of the conv
+    init, then u, then v) equal those of the module the reference's line evidently means - its BasicBlock with
+    torch.nn.utils.spectral_norm around an nn.Conv2d (reference model/basic.py:19-31 with the missing import supplied)."""
+    import torch.nn as nn
+    from model import Discriminator
+
+    def ref_block(cin, cout, stride):
+        conv = torch.nn.utils.spectral_norm(nn.Conv2d(cin, cout, 3, padding=1, stride=stride, bias=False))
+        return nn.Sequential(conv, nn.BatchNorm2d(cout), nn.LeakyReLU(0.2, True))
+    torch.manual_seed(11)
+    ours = Discriminator({"patch_size": 8, "spectral_norm": True})
+    torch.manual_seed(11)
+    plan = [(3, 64, 1), (64, 64, 2), (64, 128, 1), (128, 128, 2), (128, 256, 1), (256, 256, 2), (256, 512, 1), (512, 512, 2)]
+    feats = nn.Sequential(*[ref_block(*p) for p in plan])
+    cls = nn.Sequential(nn.Linear(512 * 2 * 2, 1024), nn.LeakyReLU(0.2, True), nn.Linear(1024, 1))
+    ref = {**{"features." + k: v for k, v in feats.state_dict().items()}, **{"classifier." + k: v for k, v in cls.state_dict().items()}}
+    mine = ours.state_dict()
+    assert list(mine.keys()) == list(ref.keys())
+    for k in ref:
+        assert mine[k].shape == ref[k].shape and torch.equal(mine[k], ref[k]), k

@@ -529,3 +529,34 @@ def test_gradient_penalty_step_captured_as_hipgraph():
         assert torch.equal(pa, pb)
     lr, hr = data[0]
     assert "gp" in step(lr, hr)          # u drawn by the replay itself
+
+
+def test_discriminator_with_spectral_norm_step_vs_oracle():
+    """--spectral_norm true (reference model/basic.py:25 is a NameError there; torch.nn.utils.spectral_norm is what it means):
+    one full GAN step with a spectrally normalised Discriminator against the CPU oracle - four D forwards with one power
+    iteration each (u / v carried from call to call), D's update through weight_orig, losses, buffers, post-Adam parameters."""
+    from model import Discriminator, Generator, VGG
+    from pesr_amd.optim import FlatAdam
+    from pesr_amd.step import Trainer
+    g_sd, d_sd, v_sd = gen_sd(16, 1), dis_sd(8, spectral_norm=True), vgg_sd()
+    G = Generator({"num_channels": 16, "depth": 1, "res_scale": 0.1}); G.load_state_dict(g_sd); G.cuda()
+    D = Discriminator({"patch_size": 8, "spectral_norm": True})
+    assert list(D.state_dict().keys()) == list(d_sd.keys())          # torch's spectral_norm schema, in torch's order
+    D.load_state_dict(d_sd); D.cuda()
+    V = VGG(); V.load_state_dict(v_sd); V.cuda()
+    tr = Trainer(G, D, V, FlatAdam(G.parameters(), lr=5e-5), FlatAdam(D.parameters(), lr=5e-5))
+    st = OS.TrainState(g_sd, d_sd, v_sd, {"depth": 1, "res_scale": 0.1, "learning_rate": 5e-5})
+    for it in range(2):
+        lr = detrand.image_batch((4, 3, 8, 8), 510 + it); hr = detrand.image_batch((4, 3, 32, 32), 520 + it)
+        ref = OS.gan_step(st, lr, hr)
+        log = tr.gan_step(lr.cuda(), hr.cuda())
+        for k in ("l1", "vgg", "g", "tv", "d"):
+            assert float(log[k]) == pytest.approx(ref[k], rel=5e-5 if it == 0 else 5e-4, abs=1e-7), (it, k)
+    got = D.state_dict()
+    for k, v in st.d.items():
+        if k.endswith(("weight_u", "weight_v")):
+            close(got[k], v, 2e-4, what=k)                           # eight power iterations in, still the same vectors
+        elif v.is_floating_point() and "running" not in k:
+            adam_close(got[k], v, 5e-5, 2, "D." + k)
+    for k, v in G.state_dict().items():
+        adam_close(v, st.g[k], 5e-5, 2, "G." + k)

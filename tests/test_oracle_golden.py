@@ -261,3 +261,36 @@ def test_rasgan_extension_closed_form_gradient():
     lo.backward()
     assert float(lg) == pytest.approx(float(lo), rel=1e-12)
     assert torch.allclose(r3.grad, r4.grad, rtol=1e-10, atol=1e-14) and torch.allclose(f3.grad, f4.grad, rtol=1e-10, atol=1e-14)
+
+
+def test_spectral_norm_restatement_vs_torch():
+    """reference model/basic.py:25 wraps the Discriminator's convs in an undefined `spectral_norm` (NameError); the
+    evident intent is torch.nn.utils.spectral_norm.  The oracle's restatement (oracle/model.py spectral_normalize) against
+    torch's own implementation on a conv: two training forwards before one backward (the GAN pattern loss = D(real) - D(fake)),
+    then an eval forward - outputs, the gradient of weight_orig, and the u / v buffers after every call."""
+    torch.manual_seed(3)
+    conv = torch.nn.utils.spectral_norm(torch.nn.Conv2d(5, 7, 3, padding=1, bias=False))
+    w = conv.weight_orig.detach().clone().requires_grad_(True)
+    u, v = conv.weight_u.clone(), conv.weight_v.clone()
+    xa, xb = torch.randn(2, 5, 6, 6), torch.randn(2, 5, 6, 6)
+    ya, yb = conv(xa), conv(xb)
+    (ya.sum() - 2.0 * yb.square().sum()).backward()
+    oa = F.conv2d(xa, OM.spectral_normalize(w, u, v, True), padding=1)
+    ob = F.conv2d(xb, OM.spectral_normalize(w, u, v, True), padding=1)
+    (oa.sum() - 2.0 * ob.square().sum()).backward()
+    assert torch.allclose(oa, ya, rtol=1e-6, atol=1e-7) and torch.allclose(ob, yb, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(u, conv.weight_u, rtol=1e-6, atol=1e-8) and torch.allclose(v, conv.weight_v, rtol=1e-6, atol=1e-8)
+    assert torch.allclose(w.grad, conv.weight_orig.grad, rtol=1e-5, atol=1e-7)
+    conv.eval()
+    ye = conv(xa)
+    oe = F.conv2d(xa, OM.spectral_normalize(w, u, v, False), padding=1)
+    assert torch.allclose(oe, ye, rtol=1e-6, atol=1e-7) and torch.allclose(u, conv.weight_u)
+    # closed form of the gradient the HIP kernel implements: dW = (G - <G, W_hat> u v^T) / sigma
+    w2 = w.detach().clone().requires_grad_(True)
+    u2, v2 = u.clone(), v.clone()
+    wh = OM.spectral_normalize(w2, u2, v2, True)
+    G = torch.randn_like(wh)
+    wh.backward(G)
+    sigma = torch.dot(u2, torch.mv(w2.detach().reshape(7, -1), v2))
+    closed = (G - (G * wh.detach()).sum() * torch.outer(u2, v2).view_as(G)) / sigma
+    assert torch.allclose(w2.grad, closed, rtol=1e-5, atol=1e-7)
