@@ -230,16 +230,18 @@ def test_bn_backward_of_backward(N, C, H, W):
     _close(_nchw(a), l_du.float(), 2e-5, "dL/d(du)"); _close(_nchw(b), l_z.float(), 5e-5, "dL/dz"); _close(c.cpu(), l_ga.float(), 5e-5, "dL/dgamma")
 
 
-@pytest.mark.parametrize("O,I", [(64, 3), (128, 64), (512, 512)])
-def test_spectral_norm_kernels_vs_oracle(O, I):
+@pytest.mark.parametrize("Co,Ci", [(64, 3), (128, 64), (512, 512)])
+def test_spectral_norm_kernels_vs_oracle(Co, Ci):
     """pesr_spectral_norm_fwd / _bwd (torch.nn.utils.spectral_norm semantics; reference model/basic.py:25) vs the oracle's
     restatement: power iteration (u, v rewritten in place), sigma, the normalised weight, the gradient; eval mode too."""
     from oracle import model as OM
-    gen = torch.Generator().manual_seed(O + I)
-    w = (torch.rand(O, I, 3, 3, generator=gen) * 2 - 1) / (I * 9) ** 0.5
-    u = torch.nn.functional.normalize(torch.randn(O, generator=gen), dim=0)
+    from pesr_amd import ops
+    O_, I = Co, Ci
+    gen = torch.Generator().manual_seed(O_ + I)
+    w = (torch.rand(O_, I, 3, 3, generator=gen) * 2 - 1) / (I * 9) ** 0.5
+    u = torch.nn.functional.normalize(torch.randn(O_, generator=gen), dim=0)
     v = torch.nn.functional.normalize(torch.randn(I * 9, generator=gen), dim=0)
-    g = torch.randn(O, I, 3, 3, generator=gen)
+    g = torch.randn(O_, I, 3, 3, generator=gen)
     for update in (True, True, False):            # two training calls in a row (the buffers carry over), then eval
         wr = w.clone().requires_grad_(True)
         ur, vr = u.clone(), v.clone()
@@ -247,11 +249,11 @@ def test_spectral_norm_kernels_vs_oracle(O, I):
         ref.backward(g)
         ud, vd = u.cuda(), v.cuda()
         w_hat, sigma = ops.spectral_norm_fwd(w.cuda(), ud, vd, update)
-        close(w_hat, ref.detach(), 2e-6, what=f"w_hat update={update}")
-        close(ud, ur, 5e-6, what="u"); close(vd, vr, 5e-6, what="v")
+        _close(w_hat.cpu(), ref.detach(), 2e-6, what=f"w_hat update={update}")
+        _close(ud.cpu(), ur, 5e-6, what="u"); _close(vd.cpu(), vr, 5e-6, what="v")
         dw = ops.spectral_norm_bwd(g.cuda(), w_hat, ud, vd, sigma)
-        close(dw, wr.grad, 5e-6, what="dw")
-        acc = torch.ones(O, I, 3, 3).cuda()
+        _close(dw.cpu(), wr.grad, 5e-6, what="dw")
+        acc = torch.ones(O_, I, 3, 3).cuda()
         ops.spectral_norm_bwd(g.cuda(), w_hat, ud, vd, sigma, dw_out=acc, accumulate=True)
-        close(acc, wr.grad + 1.0, 5e-6, what="dw accumulate")
+        _close(acc.cpu(), wr.grad + 1.0, 5e-6, what="dw accumulate")
         u, v = ur, vr                              # carry the oracle's buffers into the next round
