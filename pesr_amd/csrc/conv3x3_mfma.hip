@@ -19,6 +19,7 @@
 //     and the 3-channel input.)
 // fp32 MFMA is an exact k-ordered fmaf chain, so results differ from a CPU conv only by
 // summation order.
+#include <mutex>
 #include "common.h"
 #include "launchers.h"
 
@@ -549,11 +550,10 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
 #define PESR_LAUNCH_MODE(M_)                                                                              \
     {                                                                                                      \
         auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, M_>;                              \
-        static bool attr_set = false; /* benign race: idempotent */                                        \
-        if (!attr_set) {                                                                                   \
+        static std::once_flag attr_once;                                        \
+        std::call_once(attr_once, [&] {                                                           \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_set = true;                                                                               \
-        }                                                                                                  \
+        });                                                                                                  \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);                          \
     }
     if (mode == 2) PESR_LAUNCH_MODE(2) else if (mode == 1) PESR_LAUNCH_MODE(1) else PESR_LAUNCH_MODE(0)

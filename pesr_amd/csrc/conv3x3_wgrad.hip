@@ -16,6 +16,7 @@
 // un-permutation.  The bias gradient (column sums of dy) is accumulated on the VALU from the A fragments.
 // Channel counts need only be multiples of 4: tiles that overhang Cin / Cout load zeros and skip their stores.
 #include <cstdlib>
+#include <mutex>
 #include "common.h"
 #include "launchers.h"
 
@@ -397,11 +398,10 @@ static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
     constexpr size_t lds = 2 * (size_t)(X_FLOATS + D_FLOATS) * sizeof(float);
     static_assert(lds <= 160 * 1024, "wgrad LDS budget");
     auto kern = conv3x3_wgrad_kernel<COW, S, TWO, R>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     const int grid = split * a.co_tiles * a.ci_tiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
     return pesr_launch_status();

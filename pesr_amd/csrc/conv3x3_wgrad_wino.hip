@@ -16,6 +16,7 @@
 // Split-K partial blocks go to a workspace slab; wgrad_wino_reduce_kernel sums them in a fixed order, applies the output
 // transform, alpha and the PixelShuffle channel un-permutation, and writes OIHW.  The bias gradient is accumulated on the
 // VALU from the dM fragments (dy0 + dy1 = dM0 - dM3).
+#include <mutex>
 #include "common.h"
 #include "launchers.h"
 
@@ -345,11 +346,10 @@ int pesr_conv3x3_wgrad_wino_launch(const float* x, const float* dy, float* dw, f
     a.bias_part = db ? (float*)((char*)ws + p.slab_bytes + (((size_t)Cout * sizeof(double) + 255) / 256) * 256) : nullptr;
     constexpr size_t lds = (size_t)(6 * WW_SLOT) * sizeof(float);
     static_assert(lds <= 160 * 1024, "wgrad-wino LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     const int grid = p.split * p.co_tiles * p.ci_tiles;
     hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3(grid), dim3(WW_NT), lds, stream, a);
 #ifdef WW_SKIP_REDUCE

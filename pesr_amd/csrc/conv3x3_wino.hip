@@ -20,6 +20,7 @@
 // DMA'd); fragments are read one 3-m-tile group ahead.  Layers with too few tiles split the Cin chunks over workgroups
 // (raw partial sums + the direct kernel's fixed-order finish kernel).  The output transform happens in registers before the tile leaves
 // through LDS as coalesced 16-byte stores with the usual fused epilogue (bias, scale, ReLU mask, skip, activation).
+#include <mutex>
 #include "common.h"
 #include "launchers.h"
 #include "wino_pack.h"
@@ -341,11 +342,10 @@ int pesr_conv3x3_wino_launch(const float* x, const float* wp, const float* bias,
     size_t lds = raw_bytes + (size_t)a.HT * 4 * a.TXT * 64 + (size_t)WINO_RING * WINO_SLAB;
     const size_t lds_out = (size_t)288 * (WINO_BN * 4 + 16);
     if (lds_out > lds) lds = lds_out;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     const long tiles = (long)N * a.tiles_y * a.tiles_x * a.n_tiles;
     // split-K over the Cin chunks when the tiles alone cannot fill the 256 CUs (the 24x24 512-channel layers)
     const int C16T = Cin / 16;

@@ -16,6 +16,7 @@
 // wider than 192 are cut into strips of 190 output columns whose 192 input columns overlap by one on each side.
 // Measured at 16 x 192 x 192 x 256: 166 us = 3.6 TB/s of activations (the implicit-GEMM kernel: 450 us); without the MFMAs
 // the same loop takes 159 us, i.e. the 64-byte-per-pixel access pattern of the A operand is the limit.
+#include <mutex>
 #include "common.h"
 #include "launchers.h"
 
@@ -193,12 +194,11 @@ int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bi
     else { a.halo = 1; a.outw = RO_COLS - 2; a.strips = pesr_cdiv(W, a.outw); }
     a.bands = pesr_cdiv(H, RO_TH);
     const size_t lds = ((size_t)(C / 16) * 512 + 4 * RO_PROW) * sizeof(float);
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv_rgb_out_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_rgb_out_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     const dim3 grid((unsigned)((size_t)N * a.bands * a.strips));
     if (C % 128 == 0) hipLaunchKernelGGL(conv_rgb_out_kernel<8>, grid, dim3(RO_NT), lds, stream, a);
     else hipLaunchKernelGGL(conv_rgb_out_kernel<4>, grid, dim3(RO_NT), lds, stream, a);

@@ -4,6 +4,7 @@
 //   fwd  : y[m][n]  = act(sum_k x[m][k] W[n][k] + b[n])     split-K partials + fixed-order finalize
 //   dgrad: dx[m][k] = sum_n dy[m][n] W[n][k]                 one launch, the N split over a workgroup's waves
 //   wgrad: dW[n][k] = sum_m dy[m][n] x[m][k],  db[n] = sum_m dy[m][n]
+#include <mutex>
 #include "common.h"
 #include "launchers.h"
 
@@ -267,11 +268,10 @@ int pesr_linear_dgrad_launch(const float* dy, const float* W, float* dx, int M, 
         hipLaunchKernelGGL(linear_dgrad_kernel<16>, dim3(grid), dim3(512), lds, stream, dy, W, dx, M, N, K);
     } else {
         constexpr size_t lds = (size_t)4 * 32 * 256 * sizeof(float);
-        static bool attr_set = false;               // 128 KiB of dynamic LDS needs the opt-in (idempotent)
-        if (!attr_set) {
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [&] {
             (void)hipFuncSetAttribute((const void*)linear_dgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        });
         hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(512), lds, stream, dy, W, dx, M, N, K);
     }
     return pesr_launch_status();

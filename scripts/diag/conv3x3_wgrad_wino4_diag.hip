@@ -1,3 +1,5 @@
+// DIAGNOSTIC COPY (ablation switches W4_ABL_* / G4_ABL_*, -DPESR_TIMING phase stamps) of the product kernel in pesr_amd/csrc:
+// built only by scripts/build_timing.sh / scripts/build_variant.sh into exp/lib*.so for A/B timing; never linked into libpesr_hip.so.
 // Weight gradient of the stride-1 3x3 conv with the transposed 1-D Winograd F(4,3) along x, fp32-input MFMA, gfx950.
 //
 // Same contract as conv3x3_wgrad.hip (ATen convolution_backward's grad_weight for the reference `Conv`,
@@ -23,8 +25,8 @@
 // has the direct kernel's [split][9][Cout][Cin] layout and its fixed-order reduce kernel (alpha, PixelShuffle channel
 // un-permutation, OIHW store, bias) is shared.  The bias gradient is accumulated on the VALU from the dM_1 fragments
 // (dy0+dy1+dy2+dy3).
-#include <mutex>
 #include "common.h"
+#include "timing.h"
 #include "launchers.h"
 
 struct Wg4Args {
@@ -46,8 +48,16 @@ constexpr int G4_VPLANE = G4_K4 * 128, G4_VROW = 6 * G4_VPLANE;       // floats:
 constexpr int G4_DPLANE = G4_K4 * 256, G4_DROW = 6 * G4_DPLANE;       // floats: dM row     [6 xi][3 blocks][4 x-tiles x 64 co]
 constexpr int G4_RING = 6;
 
+#ifdef PESR_TIMING
+__device__ unsigned long long g4_timing[4096 * PESR_TIMING_SLOTS];
+PESR_API int pesr_debug_timing_wgrad4(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_timing), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Args a) {
+    PESR_STAMP(g4_timing, 0);
+    PESR_STAMP_CLK(g4_timing, 6);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const vring = lds;                             // [6 slots] V rows
     float* const dmbuf = lds + G4_RING * G4_VROW;         // [2 buffers][2 rows] dM rows
@@ -144,6 +154,13 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             const f32x4 d0 = __builtin_bit_cast(f32x4, vx[0]), d1 = __builtin_bit_cast(f32x4, vx[1]), d2 = __builtin_bit_cast(f32x4, vx[2]),
                         d3 = __builtin_bit_cast(f32x4, vx[3]), d4 = __builtin_bit_cast(f32x4, vx[4]), d5 = __builtin_bit_cast(f32x4, vx[5]);
             float* p = vring + slot * G4_VROW + v_pos;
+#if defined(G4_ABL_XFORM)      // timing-only: raw values, no transform arithmetic
+            *(f32x4*)(p) = d0; *(f32x4*)(p + G4_VPLANE) = d1; *(f32x4*)(p + 2 * G4_VPLANE) = d2;
+            *(f32x4*)(p + 3 * G4_VPLANE) = d3; *(f32x4*)(p + 4 * G4_VPLANE) = d4; *(f32x4*)(p + 5 * G4_VPLANE) = d5;
+#elif defined(G4_ABL_LDSW)     // timing-only: the arithmetic, one ds_write instead of six
+            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
+            *(f32x4*)(p) = ((4.0f * d0 + (d4 - 5.0f * d2)) * (t1 + t2)) * ((t1 - t2) * (t3 + 2.0f * t4)) * ((t3 - 2.0f * t4) * (4.0f * d1 + (d5 - 5.0f * d3)));
+#else
             const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
             *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
             *(f32x4*)(p + G4_VPLANE) = t1 + t2;
@@ -151,6 +168,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             *(f32x4*)(p + 3 * G4_VPLANE) = t3 + 2.0f * t4;
             *(f32x4*)(p + 4 * G4_VPLANE) = t3 - 2.0f * t4;
             *(f32x4*)(p + 5 * G4_VPLANE) = 4.0f * d1 + (d5 - 5.0f * d3);
+#endif
         }
     };
     auto load_d = [&](int img, int oy) {                   // output-gradient row oy (>= H: zeros)
@@ -170,6 +188,13 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             const f32x4 g0 = __builtin_bit_cast(f32x4, dd[0]), g1 = __builtin_bit_cast(f32x4, dd[1]), g2 = __builtin_bit_cast(f32x4, dd[2]),
                         g3 = __builtin_bit_cast(f32x4, dd[3]);
             float* p = dmbuf + (buf * 2 + d_rr) * G4_DROW + d_pos;
+#if defined(G4_ABL_XFORM)
+            *(f32x4*)(p) = g0; *(f32x4*)(p + G4_DPLANE) = g1; *(f32x4*)(p + 2 * G4_DPLANE) = g2;
+            *(f32x4*)(p + 3 * G4_DPLANE) = g3; *(f32x4*)(p + 4 * G4_DPLANE) = g0; *(f32x4*)(p + 5 * G4_DPLANE) = g3;
+#elif defined(G4_ABL_LDSW)
+            const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
+            *(f32x4*)(p) = (g0 * (e02 + e13)) * ((e02 - e13) * (f02 + 2.0f * f13)) * ((f02 - 2.0f * f13) * g3);
+#else
             const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
             *(f32x4*)(p) = g0;
             *(f32x4*)(p + G4_DPLANE) = e02 + e13;
@@ -177,6 +202,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             *(f32x4*)(p + 3 * G4_DPLANE) = f02 + 2.0f * f13;
             *(f32x4*)(p + 4 * G4_DPLANE) = f02 - 2.0f * f13;
             *(f32x4*)(p + 5 * G4_DPLANE) = g3;
+#endif
         }
     };
     auto seg_coords = [&](int seg, int& img, int& xs, int& row) {
@@ -206,6 +232,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     // of segment s they were waited for a third of a segment later - under load an L2 / MALL round trip is longer than that.
     if (seg_begin + 1 < seg_end && row + 2 < a.H) { load_v(img, row + 3); load_d(img, row + 2 + d_rr); }
     __syncthreads();
+    PESR_STAMP(g4_timing, 1);
     int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
     // One common store point for all waves, two thirds into the segment, with the next loads issued right behind it.  Measured
     // alternatives: different store points for the two waves of a SIMD 1.4 % slower; the loads spread over three k-steps instead
@@ -248,6 +275,14 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
                     acc[ky * 3 + xl][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[xl * 2 + i], BV[ky * 3 + xl], acc[ky * 3 + xl][i], 0, 0, 0); \
         if (xh == 0) { _Pragma("unroll") for (int i = 0; i < 2; ++i) bsum[i] += AV[2 + i]; }   /* dM_1 = dy0+dy1+dy2+dy3 */
+#ifdef G4_ABL_READS
+#undef G4_READ
+#define G4_READ(AV, BV, STEP) if (a.ps_in == 12345) { _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) AV[q_] = db[q_ * 64 + (STEP)]; _Pragma("unroll") for (int q_ = 0; q_ < 9; ++q_) BV[q_] = vb[0][q_ * 64 + (STEP)]; }
+#pragma unroll
+        for (int q_ = 0; q_ < 6; ++q_) av0[q_] = av1[q_] = 1.0f;
+#pragma unroll
+        for (int q_ = 0; q_ < 9; ++q_) bv0[q_] = bv1[q_] = 1.0f;
+#endif
         G4_READ(av0, bv0, 0)
 #pragma unroll
         for (int stp = 0; stp < 2 * G4_K4; stp += 2) {
@@ -260,9 +295,27 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
                 // The staging stores go to LDS that nobody reads in this segment (the two free ring slots, the other dM
                 // buffer); right behind them the loads for the segment after next reuse the staging registers.
                 __builtin_amdgcn_sched_barrier(0);
+#if defined(G4_ABL_STAGE)     // timing-only ablation builds (scripts/wino4_ab.py wgrad): false at run time, nothing is DCE'd
+                if (cont && a.ps_in == 12345) {
+#else
                 if (cont) {
+#endif
                     int sl = base + 4 + v_rr; if (sl >= G4_RING) sl -= G4_RING;
+#ifdef G4_ABL_STORES
+                    if (a.ps_in == 12345)
+#endif
                     { store_v(sl); store_d(par ^ 1); }
+#ifdef G4_ABL_STORES
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(vx[j]));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(dd[j]));
+                    }
+#endif
+#ifdef G4_ABL_LOADS
+                    if (a.ps_in == 12345)
+#endif
                     if (cont2) { load_v(img, row + 5); load_d(img, row + 4 + d_rr); }
                 }
             }
@@ -273,20 +326,26 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
 #undef G4_READ
 #undef G4_MFMA
         if (cont) {                                         // rows +3, +4 went to the slots of rows -1, 0, which the next segment drops
+#ifdef G4_ABL_BARRIER
+            if (a.ps_in == 12345)
+#endif
             __syncthreads();
             base += 2; if (base >= G4_RING) base -= G4_RING;
             row += 2;
         } else if (more) {                                  // new strip / image: its four halo rows are staged from scratch
             __syncthreads();
+            PESR_STAMP(g4_timing, 4);
             seg_coords(seg + 1, img, xs, row);
             set_strip(xs);
             stage_strip_start(img, row, par ^ 1);
             if (seg + 2 < seg_end && row + 2 < a.H) { load_v(img, row + 3); load_d(img, row + 2 + d_rr); }
             __syncthreads();
+            PESR_STAMP(g4_timing, 5);
             base = 0;
         }
     }
     __syncthreads();
+    PESR_STAMP(g4_timing, 2);
 
     if (a.bias_part && cit == 0) {   // combine the 4 k-slot lane groups through LDS (the staging buffers are free now), fixed order
         float* red = lds;
@@ -338,6 +397,8 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
         }
         if (ph == 0) __syncthreads();
     }
+    PESR_STAMP(g4_timing, 3);
+    PESR_STAMP_CLK(g4_timing, 7);
 }
 
 namespace {
@@ -387,10 +448,11 @@ int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, 
     constexpr size_t lds = (size_t)(G4_RING * G4_VROW + 4 * G4_DROW) * sizeof(float);
     static_assert(lds >= (size_t)9 * 64 * 32 * sizeof(float), "epilogue staging fits");
     static_assert(lds <= 160 * 1024, "wgrad-wino4 LDS budget");
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+        attr_set = true;
+    }
     const int grid = p.split * p.co_tiles * p.ci_tiles;
     hipLaunchKernelGGL(conv3x3_wgrad_wino4_kernel, dim3(grid), dim3(G4_NT), lds, stream, a);
     int rc = pesr_launch_status();

@@ -1,3 +1,5 @@
+// DIAGNOSTIC COPY (ablation switches W4_ABL_* / G4_ABL_*, -DPESR_TIMING phase stamps) of the product kernel in pesr_amd/csrc:
+// built only by scripts/build_timing.sh / scripts/build_variant.sh into exp/lib*.so for A/B timing; never linked into libpesr_hip.so.
 // 3x3 stride-1 convolution with a 1-D Winograd F(4,3) transform along x, on the fp32-input MFMA, gfx950.
 //
 // Same contract as conv3x3_mfma.hip / conv3x3_wino.hip (reference nn.Conv2d(k=3, padding=1), model/basic.py:4-7, forward
@@ -25,8 +27,8 @@
 // The 16-byte k-groups of a V entry are XOR-swizzled by ((x-tile >> 1) ^ row term) so that the ds_read_b128 fragment reads
 // are bank-conflict free for TXT = 12 (48-wide images: row term 2 * (halo row & 1)) and TXT = 8 / 16 / 24 (no row term).
 // Layers with too few tiles split the Cin chunks over workgroups (raw partial sums + the direct kernel's finish kernel).
-#include <mutex>
 #include "common.h"
+#include "timing.h"
 #include "launchers.h"
 #include "wino4_pack.h"
 
@@ -58,6 +60,12 @@ constexpr int W4_BN = 64, W4_MG = 9;
 
 // Wave w owns the 16 channels w & 3 and HALF of the xi planes (w >> 2: xi 0..2 / 3..5): 27 accumulator tiles, 2 waves per SIMD.
 // (A 12-wave variant - a third of the xi planes per wave, 3 waves per SIMD in the 168-VGPR budget - measured 2 % slower.)
+#ifdef PESR_TIMING
+__device__ unsigned long long w4_timing[4096 * PESR_TIMING_SLOTS];
+PESR_API int pesr_debug_timing_wino4(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(w4_timing), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 // DENSE = false: the swizzle key of the rows of 8 / 12 / 16 / 24 x-tiles (the layers that matter), a_off ^ kxor for odd ky.
 // DENSE = true: any row length.  A V row is padded so that the 64-byte entries of consecutive x-tiles m = row * TXT + txt of one
@@ -66,6 +74,8 @@ constexpr int W4_BN = 64, W4_MG = 9;
 // function of the lane, so its XOR with the ky = 0 key comes from two packed per-lane tables (2 bits per m-tile and ky).
 template <bool DENSE>
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
+    PESR_STAMP(w4_timing, 0);
+    PESR_STAMP_CLK(w4_timing, 6);
     constexpr int NT = 512;                                // threads of the workgroup
     constexpr int NXL = 3;                                 // xi planes per wave
     constexpr int NSLAB = 3 * NXL;                         // weight slabs per wave and chunk: (ky, xl)
@@ -233,18 +243,34 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         stage_store(1, smem);
     }
     __syncthreads();
+    PESR_STAMP(w4_timing, 1);
 
 #pragma unroll 1
     for (int c = 0; c < C16; ++c) {
         char* const vcur = smem + (c & 1) * v_bytes;
         char* const vnext = smem + ((c & 1) ^ 1) * v_bytes;
+#ifdef W4_ABL_STAGE     // timing-only ablation builds (scripts/wino4_ab.py): the condition is false at run time, nothing is DCE'd
+        const bool more = c + 1 < C16 && a.slope == 12345.f;
+#else
         const bool more = c + 1 < C16;
+#endif
         if (more) stage_load(0, CB + c + 1);               // lands while this chunk computes
+#ifdef W4_ABL_READS
+#undef W4_READ_A
+#define W4_READ_A(FA, VB, KY, XL, GRP) if (a.slope == 12345.f) { _Pragma("unroll") for (int i = 0; i < 3; ++i) FA[i] = *(const f32x4*)((VB) + a_off[(GRP) * 3 + i] + (KY) * 64 + (XL) * 16); }
+        if (c == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { fa[0][i] = (f32x4){1.f, 2.f, 3.f, 4.f}; fa[1][i] = (f32x4){1.f, 2.f, 3.f, 4.f}; }
+        }
+#endif
         W4_READ_A(fa[0], vcur, 0, 0, 0)
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {                  // slab s = (ky, xl)
             const int ky = s / NXL, xl = s - ky * NXL;
             // weight slab s + 2 (of this chunk, or the first ones of the next)
+#ifdef W4_ABL_B
+            if (a.slope == 12345.f)
+#endif
             {
                 if (s + 2 < NSLAB) fb[(s + 2) % 3] = ldb((s + 2) / NXL, (s + 2) % NXL, CB + c);
                 else if (c + 1 < C16) fb[(s + 2) % 3] = ldb(0, s + 2 - NSLAB, CB + c + 1);
@@ -262,16 +288,23 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             if (s == 2 && more) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
             if (s == 6 && more) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
         }
+#ifdef W4_ABL_BARRIER
+        if (a.slope == 12345.f)
+#endif
         __syncthreads();                                   // V[next] complete and visible; everyone is done with V[cur]
     }
 #undef W4_READ_A
 #undef W4_MFMA
+    PESR_STAMP(w4_timing, 2);
     // ---- epilogue ------------------------------------------------------------------------------------------------------------
     // With the weights as the MFMA's A operand a lane holds, per m-tile i, FOUR CONSECUTIVE CHANNELS (cb*16 + 4g ..) of x-tile
     // 16 i + r for its three xi planes.  y0 = M0 + (M1+M2) + (M3+M4), y1 = (M1-M2) + 2(M3-M4), y2 = (M1+M2) + 4(M3+M4),
     // y3 = (M1-M2) + 8(M3-M4) + M5: the xi 0..2 wave finishes y0, y1 and the xi 3..5 wave y2, y3; each passes the other its two
     // partial terms through LDS (lane-linear 16-byte slots: same lane of the partner wave), adds what it receives and stores
     // 16 bytes per lane straight to global memory - the four channel-block waves fill a pixel's 256-byte line between them.
+#ifdef W4_ABL_EPI
+    if (a.slope != 12345.f) return;
+#endif
     char* const xb = smem;
     // slot (sender xh, i, k, cb, lane)
     auto slot = [&](int sender, int i, int k) -> char* { return xb + ((((sender * W4_MG + i) * 2 + k) * 4 + cb) * 64 + lane) * 16; };
@@ -290,6 +323,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         }
     }
     __syncthreads();
+    PESR_STAMP(w4_timing, 3);
     const size_t img_out = (size_t)img * a.H * a.W;
     const int co = n0 + cb * 16 + g * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -352,6 +386,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             *(f32x4*)(a.y + idx[e]) = o;
         }
     }
+    PESR_STAMP(w4_timing, 4);
+    PESR_STAMP_CLK(w4_timing, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -471,11 +507,12 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     a.ksplit = p.ksplit; a.chunks_per_split = p.chunks_per_split; a.slab = (float*)ws;
     a.stack = p.stack; a.stack_n = N; a.v_row = p.v_row;
     if (p.stack) a.N = 1;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+        attr_set = true;
+    }
     if (p.dense) hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
     else hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
     if (p.ksplit > 1)
