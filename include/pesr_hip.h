@@ -231,6 +231,17 @@ int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 int pesr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* state, float beta1, float beta2, float eps,
                        float grad_scale, void* stream);
 
+/* ---- generic k x k conv, odd k != 3 (reference `Conv(in, out, kernel_size, stride, bias)`, model/basic.py:4-7, accepts any
+ * kernel size; its networks only use 3): padding k/2, NHWC activations, w OIHW [Cout][Cin][k][k] (not packed).  Plain VALU
+ * kernels for completeness - untuned, deterministic.  fwd: y = conv(x, w) + bias (bias may be NULL); dgrad: dx [N][H][W][Cin] from
+ * dy [N][OH][OW][Cout]; wgrad: dw OIHW and db (may be NULL). */
+int pesr_conv_kxk_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int k,
+                      int stride, void* stream);
+int pesr_conv_kxk_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int k, int stride,
+                        void* stream);
+int pesr_conv_kxk_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout, int k, int stride,
+                        void* stream);
+
 /* ---- spectral normalisation of a conv weight (reference model/basic.py:25 `spectral_norm(Conv(...))`: an undefined name there;
  * the evident intent is torch.nn.utils.spectral_norm, whose algorithm - one power iteration per training forward - this is) ---- */
 /* w [O][K] (the OIHW tensor as it lies in memory, K = Cin * 9).  update = 1 (training): v <- normalize(W^T u), u <- normalize(W v)

@@ -215,3 +215,16 @@ PESR_API int pesr_spectral_norm_bwd(const float* g, const float* w_hat, const fl
                                     int O, int K, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
     return pesr_spectral_norm_bwd_launch(g, w_hat, u, v, sigma, dw, O, K, accumulate, workspace, ws_bytes, (hipStream_t)stream);
 }
+
+PESR_API int pesr_conv_kxk_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
+                               int k, int stride, void* stream) {
+    return pesr_conv_kxk_fwd_launch(x, w, bias, y, N, H, W, Cin, Cout, k, stride, (hipStream_t)stream);
+}
+PESR_API int pesr_conv_kxk_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int k, int stride,
+                                 void* stream) {
+    return pesr_conv_kxk_dgrad_launch(dy, w, dx, N, H, W, Cin, Cout, k, stride, (hipStream_t)stream);
+}
+PESR_API int pesr_conv_kxk_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout, int k,
+                                 int stride, void* stream) {
+    return pesr_conv_kxk_wgrad_launch(x, dy, dw, db, N, H, W, Cin, Cout, k, stride, (hipStream_t)stream);
+}

@@ -101,6 +101,13 @@ int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bi
                                  float slope, hipStream_t stream);
 int pesr_conv_rgb_out_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream);
 
+int pesr_conv_kxk_fwd_launch(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int Cin, int Cout, int k, int s,
+                             hipStream_t stream);
+int pesr_conv_kxk_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int k, int s,
+                               hipStream_t stream);
+int pesr_conv_kxk_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout, int k, int s,
+                               hipStream_t stream);
+
 size_t pesr_spectral_norm_ws_bytes(int O, int K);
 int pesr_spectral_norm_fwd_launch(const float* W, float* u, float* v, float* w_hat, float* sigma, int O, int K, int update, float eps,
                                   void* ws, size_t ws_bytes, hipStream_t stream);

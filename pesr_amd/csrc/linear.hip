@@ -1,8 +1,8 @@
 // Skinny-batch Linear for the Discriminator's classifier (reference model/pesr.py:69-74: Linear(73728, 1024)
 // -> LeakyReLU(0.2) -> Linear(1024, 1); ATen addmm / mm in forward and backward).  M (batch) <= 32.
 // All three passes are HBM-bound on the 302 MB weight matrix, which each streams exactly once:
-//   fwd  : y[m][n]  = act(sum_k x[m][k] W[n][k] + b[n])     split-K partials + fixed-order finalize
-//   dgrad: dx[m][k] = sum_n dy[m][n] W[n][k]                 one launch, the N split over a workgroup's waves
+//   fwd  : y[m][n]  = act(sum_k x[m][k] W[n][k] + b[n])     split-K partials (MFMA for M <= 16) + fixed-order finalize
+//   dgrad: dx[m][k] = sum_n dy[m][n] W[n][k]                 split-N partials + fixed-order finalize
 //   wgrad: dW[n][k] = sum_m dy[m][n] x[m][k],  db[n] = sum_m dy[m][n]
 #include <mutex>
 #include "common.h"
@@ -11,13 +11,9 @@
 #define LIN_MAXM 32
 
 // ---- forward -----------------------------------------------------------------------------------
-// One wave: NR consecutive output features, one K slice; lanes stride over K with 16-byte loads, so every load instruction of
-// the wave reads ONE KiB of ONE weight row (lane-linear): the access pattern the memory system serves best - the MFMA form
-// below reads 16 rows x 64 bytes per instruction and stays at 2.4 TB/s.  The x slice of the iteration (M rows x 1 KiB) comes
-// from L1 / L2: M / NR times the weight bytes, shared by the waves of a block (same K slice, neighbouring feature groups).
-// Used for 16 < M <= 32 (NR = 2); M <= 16 runs on linear_fwd_lds_kernel below.
+// one wave: NR consecutive output features, one K slice; lanes stride over K with float4 loads.
 template <int MB, int NR>
-__global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                          float* __restrict__ part, int M, int N, long K, int ksplit, long kchunk) {
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const int ngroups = (N + NR - 1) / NR;
@@ -31,22 +27,18 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const float* __restr
     for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (long k = k0 + lane * 4; k < k1; k += 256) {
         f32x4 w[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
-            w[r] = (n0 + r < N) ? __builtin_nontemporal_load((const f32x4*)(W + (size_t)(n0 + r) * K + k)) : zero;
+        for (int r = 0; r < NR; ++r) w[r] = (n0 + r < N) ? *(const f32x4*)(W + (size_t)(n0 + r) * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mb = 0; mb < MB; mb += 8) {          // the x rows in batches of 8 loads
-            f32x4 xv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xv[j] = (mb + j < M) ? *(const f32x4*)(x + (size_t)(mb + j) * K + k) : zero;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
+        for (int m = 0; m < MB; ++m) {
+            if (m < M) {
+                const f32x4 xv = *(const f32x4*)(x + (size_t)m * K + k);
 #pragma unroll
                 for (int r = 0; r < NR; ++r)
-                    acc[r][mb + j] = fmaf(w[r].w, xv[j].w, fmaf(w[r].z, xv[j].z, fmaf(w[r].y, xv[j].y, fmaf(w[r].x, xv[j].x, acc[r][mb + j]))));
+                    acc[r][m] = fmaf(w[r].w, xv.w, fmaf(w[r].z, xv.z, fmaf(w[r].y, xv.y, fmaf(w[r].x, xv.x, acc[r][m]))));
+            }
         }
     }
 #pragma unroll
@@ -57,63 +49,61 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const float* __restr
             if (lane == 0 && m < M && n0 + r < N) part[((size_t)ks * M + m) * N + n0 + r] = s;
         }
 }
-// M <= 16, the layer that matters (Linear(73728, 1024) at batch 16): a block's 4 waves take 8 features each (32 in all) of ONE K
-// slice; per 256-k step the block stages the x piece (M rows x 1 KiB) through LDS once - each wave fetches four of the rows,
-// double-buffered, one barrier per step - so x costs 0.5 x the weight bytes of vector-memory traffic instead of 2 x, and a lane
-// holds only one x piece at a time next to its 8 weight pieces and 128 accumulators (no spills at 2 waves per SIMD).
-template <int MB>
-__global__ __launch_bounds__(256, 2) void linear_fwd_lds_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                                float* __restrict__ part, int M, int N, long K, int ksplit, long kchunk) {
-    constexpr int NR = 8, RW = MB / 4;                      // x rows fetched per wave and step
-    __shared__ f32x4 xs[2][MB][64];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nblk = (N + 4 * NR - 1) / (4 * NR);
-    const int nb = blockIdx.x % nblk, ks = blockIdx.x / nblk;
-    const int n0 = nb * 4 * NR + wave * NR;
+// M <= 16: the batch IS an MFMA dimension.  One wave owns NB x 16 output features and one K slice; per 16-k step every
+// lane loads ONE 16-byte piece of x (row lane%16, k-slot lane/16) and NB pieces of W, and element e of the pieces feeds
+// MFMA k-step e (k-slot g of step e stands for k = k0 + 4g + e).  The x slice is thus read once per NB*16 features
+// (75 MB of L2 traffic for the 73728 -> 1024 layer instead of 600 MB with one feature row per lane group), and the
+// 302 MB weight matrix streams exactly once.  D tile: row m = 4*(lane/16) + reg, col n = lane%16.
+template <int NB>
+__global__ __launch_bounds__(256) void linear_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                              float* __restrict__ part, int M, int N, long K, int ksplit, long kchunk) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const int ngroups = (N + 16 * NB - 1) / (16 * NB);
+    const int ng = wave % ngroups, ks = wave / ngroups;
+    if (ks >= ksplit) return;
+    const int n0 = ng * 16 * NB;
     const long k0 = ks * kchunk;
     long k1 = k0 + kchunk; if (k1 > K) k1 = K;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    float acc[NR][MB];
+    const float* xr = x + (size_t)(i < M ? i : 0) * K;
+    const float* wr[NB];
+    bool wok[NB];
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
+    for (int b = 0; b < NB; ++b) { const int n = n0 + b * 16 + i; wok[b] = n < N; wr[b] = W + (size_t)(wok[b] ? n : 0) * K; }
+    const bool xok = i < M;
+    // LU 16-k steps per trip, all their loads issued before the first MFMA (the two 64-byte halves of every 128-byte line of W
+    // are then in flight together): LU * (NB + 1) KiB per wave
+#ifndef LF_U
+#define LF_U 2
+#endif
+    constexpr int LU = LF_U;
+    for (long k = k0 + 4 * g; k < k1 + 4 * g; k += 16 * LU) {   // uniform trip count; a lane's piece may lie past k1
+        f32x4 a[LU], w[LU][NB];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
-    f32x4 xn[RW];
-    auto load_x = [&](long k) {
+        for (int u = 0; u < LU; ++u) {
+            const long ku = k + 16 * u;
+            const bool in = ku < k1;
+            a[u] = (xok && in) ? *(const f32x4*)(xr + ku) : zero;
 #pragma unroll
-        for (int j = 0; j < RW; ++j) { const int m = wave * RW + j; xn[j] = (m < M && k < k1) ? *(const f32x4*)(x + (size_t)m * K + k) : zero; }
-    };
-    auto store_x = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < RW; ++j) xs[buf][wave * RW + j][lane] = xn[j];
-    };
-    load_x(k0 + lane * 4);
-    store_x(0);
-    int cur = 0;
-    for (long kb = k0; kb < k1; kb += 256, cur ^= 1) {      // uniform trip count for the whole block
-        const long k = kb + lane * 4;
-        f32x4 w[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            w[r] = (n0 + r < N && k < k1) ? __builtin_nontemporal_load((const f32x4*)(W + (size_t)(n0 + r) * K + k)) : zero;
-        const bool more = kb + 256 < k1;
-        if (more) load_x(k + 256);
-        __syncthreads();                                    // xs[cur] complete; everyone is done reading xs[cur ^ 1]
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const f32x4 xv = xs[cur][m][lane];
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-                acc[r][m] = fmaf(w[r].w, xv.w, fmaf(w[r].z, xv.z, fmaf(w[r].y, xv.y, fmaf(w[r].x, xv.x, acc[r][m]))));
+            for (int b = 0; b < NB; ++b) w[u][b] = (wok[b] && in) ? __builtin_nontemporal_load((const f32x4*)(wr[b] + ku)) : zero;
         }
-        if (more) store_x(cur ^ 1);
+#pragma unroll
+        for (int u = 0; u < LU; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], w[u][b][e], acc[b], 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const float s = wave_sum(acc[r][m]);
-            if (lane == 0 && m < M && n0 + r < N) part[((size_t)ks * M + m) * N + n0 + r] = s;
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = 4 * g + jj, n = n0 + b * 16 + i;
+            if (m < M && n < N) part[((size_t)ks * M + m) * N + n] = acc[b][jj];
         }
 }
 __global__ void linear_fwd_final_kernel(const float* __restrict__ part, const float* __restrict__ b, float* __restrict__ y, int M,
@@ -129,37 +119,35 @@ __global__ void linear_fwd_final_kernel(const float* __restrict__ part, const fl
 }
 
 // ---- dgrad -------------------------------------------------------------------------------------
-// dx[m][k] = sum_n dy[m][n] W[n][k] in ONE launch, the weight matrix streamed once and nothing else of size written:
-// a workgroup owns 256 consecutive k (one 16-byte piece per lane: every load instruction of a wave reads ONE KiB of ONE
-// weight row) for ALL rows; its 8 waves split the N rows 8 ways (LD_U rows' loads in flight per wave), keep M x 4 sums per
-// lane and meet in LDS at the end - waves 4..7 park their sums, waves 0..3 add their own, then the four partial rows are
-// summed in wave order: a fixed order, bit-reproducible.  64 KiB of LDS, ~110 VGPRs: two workgroups share a CU, so the
-// K / 256 = 288 workgroups of the 73728-column layer are all resident at once (no second round) with 72 KiB of loads in
-// flight per CU.  Round 2's form (thread = 4 k, grid over 16 N-slices, M x K partials per slice + a finalize launch) moved
-// 302 + 150 MB per call.  dy values are wave-uniform (scalar loads).
-#ifndef LD_U
-#define LD_U 8
-#endif
+// thread: 4 consecutive k, all M rows; loops over an N slice; dy values are wave-uniform (scalar loads).
 template <int MB>
-__global__ __launch_bounds__(512, (MB <= 16 ? 4 : 2)) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ W,
-                                                              float* __restrict__ dx, int M, int N, long K) {
-    extern __shared__ __attribute__((aligned(16))) float lds_red[];        // [4][MB][256] floats
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long k = (long)blockIdx.x * 256 + lane * 4;
-    const bool kok = k < K;
-    const long kc = kok ? k : 0;
-    const int nchunk = (N + 7) / 8;
-    const int n0 = wave * nchunk;
+#ifndef LD_BT
+#define LD_BT 256
+#endif
+#ifndef LD_U
+#define LD_U 4
+#endif
+__global__ __launch_bounds__(LD_BT) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                             float* __restrict__ part, int M, int N, long K, int nchunk) {
+    const long k = ((long)blockIdx.x * LD_BT + threadIdx.x) * 4;
+    const int ns = blockIdx.y;
+    const int n0 = ns * nchunk;
     int n1 = n0 + nchunk; if (n1 > N) n1 = N;
+    if (k >= K) return;
     f32x4 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // LD_U weight rows per step, all their 16-byte loads issued before the first FMA.  Round-3 sweep on one box (back-to-back /
+    // after a 512 MB flush): LD_U 4: 111 / 101 us, 8: 134 / 124, 16: 146 / 149 (round 2 had measured 8 as 106 on its box); 64- /
+    // 512- / 1024-thread blocks slower.  A one-launch form (a workgroup owns 256 k for ALL rows, its waves split N and meet in
+    // LDS: no partial slabs, no finalize launch, 302 instead of 457 MB moved) measured 131 - 234 us in four variants: with 4.5 - 9
+    // waves per CU it keeps too few loads in flight; this split-N form runs 16 waves per CU.
     constexpr int U = LD_U;
     int n = n0;
     for (; n + U <= n1; n += U) {
         f32x4 w[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load((const f32x4*)(W + (size_t)(n + u) * K + kc));
+        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load((const f32x4*)(W + (size_t)(n + u) * K + k));
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -167,31 +155,21 @@ __global__ __launch_bounds__(512, (MB <= 16 ? 4 : 2)) void linear_dgrad_kernel(c
                 if (m < M) acc[m] += w[u] * dy[(size_t)m * N + n + u];
     }
     for (; n < n1; ++n) {
-        const f32x4 w = *(const f32x4*)(W + (size_t)n * K + kc);
+        const f32x4 w = *(const f32x4*)(W + (size_t)n * K + k);
 #pragma unroll
         for (int m = 0; m < MB; ++m)
             if (m < M) acc[m] += w * dy[(size_t)m * N + n];
     }
-    f32x4* red = (f32x4*)lds_red + (size_t)(wave & 3) * MB * 64 + lane;      // [wave & 3][m][lane]
-    if (wave >= 4) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m) red[m * 64] = acc[m];
-    }
-    __syncthreads();
-    if (wave < 4) {
-#pragma unroll
-        for (int m = 0; m < MB; ++m) red[m * 64] = acc[m] + red[m * 64];     // wave w + wave w + 4
-    }
-    __syncthreads();
-    // 512 threads finish MB x 64 pieces: ((p0 + p1) + p2) + p3
-    const f32x4* all = (const f32x4*)lds_red;
-    for (int e = threadIdx.x; e < MB * 64; e += 512) {
-        const int m = e >> 6, l = e & 63;
-        const long kk = (long)blockIdx.x * 256 + l * 4;
-        if (m < M && kk < K) {
-            const f32x4 s = ((all[e] + all[MB * 64 + e]) + all[2 * MB * 64 + e]) + all[3 * MB * 64 + e];
-            *(f32x4*)(dx + (size_t)m * K + kk) = s;
-        }
+    for (int m = 0; m < MB; ++m)
+        if (m < M) *(f32x4*)(part + ((size_t)ns * M + m) * K + k) = acc[m];
+}
+// finalize: dx = sum over N-slices; the LeakyReLU derivative of the layer below is applied by its own backward
+__global__ void linear_dgrad_final_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dx, long MK4, int nsplit) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < MK4; e += (long)gridDim.x * blockDim.x) {
+        f32x4 s = part[e];
+        for (int k = 1; k < nsplit; ++k) s += part[(size_t)k * MK4 + e];
+        dx[e] = s;
     }
 }
 
@@ -212,6 +190,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 #pragma unroll
         for (int m = 0; m < MB; ++m)
             if (m < M) s += xv[m] * dy[(size_t)m * N + n];
+        // (non-temporal: the 302 MB stream is written once and not re-read by this kernel - 88 -> 78 us)
         if (accumulate) s += __builtin_nontemporal_load((const f32x4*)(dW + (size_t)n * K + k));   // dW += ... : a second use of the layer in one backward
         __builtin_nontemporal_store(s, (f32x4*)(dW + (size_t)n * K + k));
     }
@@ -225,22 +204,36 @@ __global__ void linear_bgrad_kernel(const float* __restrict__ dy, float* __restr
 }
 
 namespace {
-struct LinPlan { int ksplit; long kchunk; int nr; };
+struct LinPlan { int ksplit; long kchunk; int nsplit, nchunk; };
 static void lin_plan(int M, int N, long K, LinPlan* p) {
-    // forward: K slices in multiples of 256 (one KiB per lane-linear load); M <= 16: blocks of 32 features, ~512 of them (two
-    // waves per SIMD on every CU); else waves = ceil(N / 2) * ksplit ~ 4096
-    p->nr = M <= 16 ? 8 : 2;
-    const int ngroups = (N + p->nr - 1) / p->nr;
-    int ks = (M <= 16 ? 2048 : 4096) / ngroups; if (ks < 1) ks = 1;
-    long kc = ((K + ks - 1) / ks + 255) / 256 * 256;
-    if (kc < 256) kc = 256;
-    p->kchunk = kc; p->ksplit = (int)((K + kc - 1) / kc);
+    // forward: M <= 16: waves = ceil(N/64) * ksplit ~ 2048 (more waves or deeper unrolling measured slower), K slices in multiples of 16 (MFMA kernel);
+    //          M  > 16: waves = ceil(N/2) * ksplit ~ 4096, K slices in multiples of 256 (lane-strided kernel)
+    if (M <= 16) {
+        const int ngroups = (N + 63) / 64;
+        int ks = 2048 / ngroups; if (ks < 1) ks = 1;
+        long kc = ((K + ks - 1) / ks + 15) / 16 * 16;
+        if (kc < 64) kc = 64;
+        p->kchunk = kc; p->ksplit = (int)((K + kc - 1) / kc);
+    } else {
+        const int ngroups = (N + 1) / 2;
+        int ks = 4096 / ngroups; if (ks < 1) ks = 1;
+        long kc = ((K + ks - 1) / ks + 255) / 256 * 256;
+        if (kc < 256) kc = 256;
+        p->kchunk = kc; p->ksplit = (int)((K + kc - 1) / kc);
+    }
+    // dgrad: one-wave blocks, ceil(K/256) * nsplit ~ 1024 of them (every N slice writes an M x K partial: keep them few)
+    const long kb = (K + 4 * LD_BT - 1) / (4 * LD_BT);
+    int ns = (int)((1024 * 256 / LD_BT + kb - 1) / kb); if (ns < 1) ns = 1; if (ns > N) ns = N; if (ns > 16) ns = 16;
+    p->nchunk = (N + ns - 1) / ns; p->nsplit = (N + p->nchunk - 1) / p->nchunk;
+    (void)M;
 }
 }  // namespace
 
 size_t pesr_linear_ws_bytes(int M, int N, long K) {
     LinPlan p; lin_plan(M, N, K, &p);
-    return (size_t)p.ksplit * M * N * sizeof(float) + 256;
+    const size_t a = (size_t)p.ksplit * M * N * sizeof(float);
+    const size_t b = (size_t)p.nsplit * M * K * sizeof(float);
+    return a > b ? a : b;
 }
 
 int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float* y, int M, int N, long K, int act, float slope,
@@ -248,12 +241,11 @@ int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float
     if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
     LinPlan p; lin_plan(M, N, K, &p);
     if (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float)) return PESR_EWORKSPACE;
-    const long waves = (long)((N + p.nr - 1) / p.nr) * p.ksplit;
-    if (M <= 16)
-        hipLaunchKernelGGL(linear_fwd_lds_kernel<16>, dim3((unsigned)(((N + 31) / 32) * p.ksplit)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K,
-                           p.ksplit, p.kchunk);
-    else
-        hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), dim3((int)((waves + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+    if (M <= 16) {
+        const long waves = (long)((N + 63) / 64) * p.ksplit;
+        hipLaunchKernelGGL(linear_fwd_mfma_kernel<4>, dim3((int)((waves + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+    } else
+        hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), dim3((int)(((long)((N + 1) / 2) * p.ksplit + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
     hipLaunchKernelGGL(linear_fwd_final_kernel, dim3((M * N + 255) / 256), dim3(256), 0, stream, (const float*)ws, b, y, M, N, p.ksplit, act, slope);
     return pesr_launch_status();
 }
@@ -261,19 +253,14 @@ int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float
 int pesr_linear_dgrad_launch(const float* dy, const float* W, float* dx, int M, int N, long K, void* ws, size_t ws_bytes,
                              hipStream_t stream) {
     if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
-    (void)ws; (void)ws_bytes;                       // (the one-launch kernel needs no workspace; kept in the ABI)
-    const unsigned grid = (unsigned)((K + 255) / 256);
-    if (M <= 16) {
-        constexpr size_t lds = (size_t)4 * 16 * 256 * sizeof(float);
-        hipLaunchKernelGGL(linear_dgrad_kernel<16>, dim3(grid), dim3(512), lds, stream, dy, W, dx, M, N, K);
-    } else {
-        constexpr size_t lds = (size_t)4 * 32 * 256 * sizeof(float);
-        static std::once_flag attr_once;
-        std::call_once(attr_once, [&] {
-            (void)hipFuncSetAttribute((const void*)linear_dgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        });
-        hipLaunchKernelGGL(linear_dgrad_kernel<32>, dim3(grid), dim3(512), lds, stream, dy, W, dx, M, N, K);
-    }
+    LinPlan p; lin_plan(M, N, K, &p);
+    if (!ws || ws_bytes < (size_t)p.nsplit * M * K * sizeof(float)) return PESR_EWORKSPACE;
+    const dim3 grid((unsigned)((K / 4 + LD_BT - 1) / LD_BT), (unsigned)p.nsplit);
+    if (M <= 16) hipLaunchKernelGGL(linear_dgrad_kernel<16>, grid, dim3(LD_BT), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(LD_BT), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
+    const long MK4 = (long)M * K / 4;
+    hipLaunchKernelGGL(linear_dgrad_final_kernel, dim3((unsigned)((MK4 + 255) / 256 < 4096 ? (MK4 + 255) / 256 : 4096)), dim3(256), 0, stream,
+                       (const f32x4*)ws, (f32x4*)dx, MK4, p.nsplit);
     return pesr_launch_status();
 }
 

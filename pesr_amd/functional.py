@@ -457,6 +457,31 @@ class ConvLReluFn(Function):
         return dx, dw, db, None, None, None
 
 
+class ConvKxKFn(Function):
+    """y = conv(x, w) + b for an odd kernel size other than 3 (reference model/basic.py:4-7 accepts any; its networks use 3 only):
+    the generic, untuned kernels of conv_kxk.hip.  Activations are applied by the caller (ops.relu_mask)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        x = _c(x)
+        ctx.stride, ctx.bias_ref = stride, bias
+        ctx.save_for_backward(x, weight)
+        return ops.conv_kxk_fwd(x, _c(weight.detach()), None if bias is None else bias.detach(), stride)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _c(gy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_kxk_dgrad(gy, _c(weight.detach()), tuple(x.shape), ctx.stride)
+        if ctx.needs_input_grad[1]:
+            want_b = ctx.bias_ref is not None and ctx.needs_input_grad[2]
+            dw, db = ops.conv_kxk_wgrad(x, gy, weight.shape[2], ctx.stride, want_bias=want_b, dw_out=grad_out(weight),
+                                        db_out=grad_out(ctx.bias_ref) if want_b else None)
+        return dx, dw, db, None
+
+
 def conv3x3(x, weight, bias, cache, stride=1, act=ops.ACT_NONE, relu_in=False, relu_grad_by_consumer=False):
     return Conv3x3Fn.apply(x, weight, bias, cache, stride, act, relu_in, relu_grad_by_consumer)
 

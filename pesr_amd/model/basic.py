@@ -44,16 +44,17 @@ def spectral_norm(conv, eps=1e-12):
 
 
 class Conv(nn.Module):
-    """3x3 conv, padding k//2 (reference model/basic.py:4-7).  kernel_size 3 only on the HIP path."""
+    """k x k conv, padding k//2 (reference model/basic.py:4-7).  kernel_size 3 - the only size the reference's networks use -
+    runs on the MFMA / Winograd kernels; any other odd size on the generic kernels of conv_kxk.hip (complete, untuned)."""
 
     def __init__(self, in_planes, out_planes, kernel_size, stride=1, bias=True):
         super().__init__()
-        if kernel_size != 3:
-            raise NotImplementedError("pesr_amd Conv implements the reference's only case, kernel_size=3")
+        if kernel_size % 2 == 0:
+            raise NotImplementedError("pesr_amd Conv: even kernel sizes change the output size under padding k//2; odd sizes only")
         init = nn.Conv2d(in_planes, out_planes, kernel_size, padding=kernel_size // 2, stride=stride, bias=bias)
         self.weight = nn.Parameter(init.weight.data)
         self.bias = nn.Parameter(init.bias.data) if bias else None
-        self.in_channels, self.out_channels, self.stride = in_planes, out_planes, stride
+        self.in_channels, self.out_channels, self.stride, self.kernel_size = in_planes, out_planes, stride, kernel_size
         self.packed = PF.PackedConvWeights(ps=False)
         self._sn_eps = None          # set by spectral_norm(): the weight is then weight_orig / sigma, recomputed per forward
 
@@ -64,11 +65,15 @@ class Conv(nn.Module):
         return PF.spectral_normalize(self.weight_orig, self.weight_u, self.weight_v, self.training, self._sn_eps)
 
     def forward(self, x, act=ops.ACT_NONE, relu_in=False, relu_grad_by_consumer=False):
+        if self.kernel_size != 3:
+            assert act == ops.ACT_NONE and not relu_in, "fused activations exist for the 3x3 kernels only"
+            return nchw(PF.ConvKxKFn.apply(nhwc(x), self.effective_weight(), self.bias, self.stride))
         return nchw(PF.conv3x3(nhwc(x), self.effective_weight(), self.bias, self.packed, self.stride, act, relu_in,
                                relu_grad_by_consumer))
 
     def extra_repr(self):
-        return f"{self.in_channels}, {self.out_channels}, kernel_size=3, stride={self.stride}, bias={self.bias is not None}"
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"bias={self.bias is not None}")
 
 
 class MeanShift(nn.Module):
@@ -131,6 +136,9 @@ def _conv_act(conv, x_nhwc, act):
     """conv (+bias) followed by an activation module (or None), un-fused with whatever comes next."""
     slope = _act_slope(act)
     w = conv.effective_weight()
+    if conv.kernel_size != 3:       # generic kernel, activation as its own (differentiable) elementwise op
+        z = PF.ConvKxKFn.apply(x_nhwc, w, conv.bias, conv.stride)
+        return z if slope == 1.0 else PF.LRelu2Fn.apply(z, slope)
     if slope == 1.0:
         return PF.conv3x3(x_nhwc, w, conv.bias, conv.packed, conv.stride)
     if slope == 0.0:
@@ -139,6 +147,14 @@ def _conv_act(conv, x_nhwc, act):
 
 
 def _conv_bn_act(conv, bn, x_nhwc, act, y_nchw=False):
+    if conv.kernel_size != 3:       # generic conv -> BatchNorm -> activation, un-fused (training-mode statistics only)
+        if not (bn.training or bn.running_mean is None):
+            raise NotImplementedError("eval-mode BatchNorm behind a conv with kernel_size != 3")
+        z = PF.ConvKxKFn.apply(x_nhwc, conv.effective_weight(), conv.bias, conv.stride)
+        u = PF.Bn2Fn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum)
+        slope = _act_slope(act)
+        y = u if slope == 1.0 else PF.LRelu2Fn.apply(u, slope)
+        return nchw(y).contiguous() if y_nchw else y
     return PF.ConvBnLReluFn.apply(x_nhwc, conv.effective_weight(), conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked, conv.packed, conv.stride, bn.eps, bn.momentum, _act_slope(act), y_nchw,
                                   bn.training or bn.running_mean is None)

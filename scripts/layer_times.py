@@ -37,7 +37,7 @@ opt = {"patch_size": 48, "num_channels": 256, "depth": 32, "res_scale": 0.1, "sp
 G, D = Generator(opt).to(dev), Discriminator(opt).to(dev)
 with warnings.catch_warnings():
     warnings.simplefilter("ignore"); V = VGG().to(dev)
-oG, oD = FlatAdam([p for p in G.parameters() if p.requires_grad], lr=5e-5), FlatAdam(D.parameters(), lr=5e-5)
+oG, oD = FlatAdam([p for p in G.parameters() if p.requires_grad], lr=5e-7), FlatAdam(D.parameters(), lr=5e-7)   # (bench.py --lr: keeps D's loss O(1))
 tr = Trainer(G, D, V, oG, oD, gan_type="RSGAN", focal_loss=True, fl_gamma=1.0, alpha_vgg=50, alpha_gan=1, alpha_tv=1e-6, alpha_l1=0)
 lr = torch.randint(0, 256, (16, 3, 48, 48)).float().to(dev)
 hr = torch.randint(0, 256, (16, 3, 192, 192)).float().to(dev).contiguous(memory_format=torch.channels_last)
@@ -55,22 +55,29 @@ for name, shapes, extra, e0, e1 in REC:
     t, c = agg.get(key, (0.0, 0))
     agg[key] = (t + e0.elapsed_time(e1), c + 1)
 def conv_flops(name, shapes, extra):
+    """ALGORITHMIC flops of a conv op: 2 * N * OH * OW * Cin * Cout * 9 with OH x OW the OUTPUT size of the forward conv (round 2
+    used the input size: every stride-2 row was overstated 4 x).  `extra` = the call's keyword ints as (name, value) pairs, then
+    its first two positional ints: (cout, stride) for conv3x3_fwd, (stride,) for conv3x3_dgrad / conv3x3_wgrad."""
     try:
+        d = dict(e for e in extra if isinstance(e, tuple) and len(e) == 2 and isinstance(e[0], str))
+        ints = [x for x in extra if isinstance(x, int) and not isinstance(x, bool)]
         if name == "conv3x3_fwd":
-            N, H, W, Ci = shapes[0]; d = dict(e for e in extra if isinstance(e, tuple)); s = d.get("stride", 1)
-            co = d.get("cout") or [x for x in extra if isinstance(x, int) and not isinstance(x, bool)][0]
-            return 2.0 * N * (H // s) * (W // s) * Ci * co * 9
-        if name == "conv3x3_dgrad":
-            d = dict(e for e in extra if isinstance(e, tuple)); N, H, W, Ci = d["in"]; s = d.get("stride", 1)
+            N, H, W, Ci = shapes[0]
+            co = d.get("cout") or ints[0]
+            s = d.get("stride") or (ints[1] if len(ints) > 1 else 1)
+        elif name == "conv3x3_dgrad":
+            N, H, W, Ci = d["in"]
+            s = d.get("stride") or (ints[0] if ints else 1)
             co = shapes[0][3] * (4 if d.get("ps_in") else 1)
-            return 2.0 * N * (H // s) * (W // s) * Ci * co * 9
-        if name == "conv3x3_wgrad":
-            N, H, W, Ci = shapes[0]; d = dict(e for e in extra if isinstance(e, tuple)); s = d.get("stride", 1)
+        elif name == "conv3x3_wgrad":
+            N, H, W, Ci = shapes[0]
+            s = d.get("stride") or (ints[0] if ints else 1)
             co = shapes[1][3] * (4 if d.get("ps_in") else 1)
-            return 2.0 * N * (H // s) * (W // s) * Ci * co * 9
+        else:
+            return 0.0
+        return 2.0 * N * ((H - 1) // s + 1) * ((W - 1) // s + 1) * Ci * co * 9
     except Exception:
         return 0.0
-    return 0.0
 rows = []
 for (name, shapes, extra), (t, c) in agg.items():
     fl = conv_flops(name, shapes, extra)
@@ -79,7 +86,7 @@ rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"step {e_a.elapsed_time(e_b) / R:.2f} ms; sum of bracketed ops {tot:.2f} ms")
 print(f"{'ms/step':>8} {'calls':>5} {'us/call':>8} {'TF/s':>6} {'eff':>5} {'lost ms':>7}  op / shapes")
-for t, c, name, shapes, extra, fl in rows[:45]:
+for t, c, name, shapes, extra, fl in rows[:70]:
     us = t / c * 1e3
     tf = fl / (us * 1e-6) / 1e12 if fl else 0.0
     lost = t - c * fl / 157.3e12 * 1e3 if fl else 0.0

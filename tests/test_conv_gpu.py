@@ -374,3 +374,54 @@ def test_conv3x3_rgb_out_kernel(N, H, W, Cin, bias, act):
     finally:
         ops.USE_RGB_OUT = True
     _close(_nchw(y), _nchw(y2), 2e-6 * (Cin * 9) ** 0.5)
+
+
+@pytest.mark.parametrize("k,stride,bias", [(1, 1, True), (5, 1, True), (5, 2, False), (7, 1, False), (1, 2, True)])
+def test_conv_other_kernel_sizes_vs_torch(k, stride, bias):
+    """reference `Conv(in, out, kernel_size, stride, bias)` (model/basic.py:4-7) takes any kernel size; its networks use 3 only.
+    The generic kernels (conv_kxk.hip) behind pesr_amd's Conv for odd k != 3: forward, input gradient, weight and bias gradient
+    against torch's conv2d on the CPU, same seeded construction."""
+    from pesr_amd.model.basic import Conv
+    torch.manual_seed(k * 10 + stride)
+    ours = Conv(6, 10, k, stride=stride, bias=bias)
+    torch.manual_seed(k * 10 + stride)
+    ref = torch.nn.Conv2d(6, 10, k, padding=k // 2, stride=stride, bias=bias)
+    assert torch.equal(ours.weight.detach(), ref.weight.detach())
+    ours.cuda()
+    x = (torch.rand(2, 6, 9, 11, generator=torch.Generator().manual_seed(k)) * 2 - 1)
+    xr = x.clone().requires_grad_(True)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yr, yg = ref(xr), ours(xg)
+    assert yg.shape == yr.shape
+    g = torch.rand(yr.shape, generator=torch.Generator().manual_seed(k + 1)) * 2 - 1
+    yr.backward(g); yg.backward(g.cuda())
+    scale = lambda t: float(t.abs().max()) + 1e-30
+    assert float((yg.detach().cpu() - yr.detach()).abs().max()) <= 2e-6 * scale(yr)
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 2e-6 * scale(xr.grad)
+    assert float((ours.weight.grad.cpu() - ref.weight.grad).abs().max()) <= 5e-6 * scale(ref.weight.grad)
+    if bias:
+        assert float((ours.bias.grad.cpu() - ref.bias.grad).abs().max()) <= 5e-6 * scale(ref.bias.grad)
+
+
+def test_basic_block_with_5x5_conv_vs_torch():
+    """BasicBlock(kernel_size=5, bn=True, LeakyReLU) - a constructor combination of reference model/basic.py:19-31 - on the generic
+    conv followed by the BatchNorm / activation kernels, against the same block built from torch modules."""
+    import torch.nn as nn
+    from pesr_amd.model.basic import BasicBlock
+    torch.manual_seed(4)
+    ours = BasicBlock(4, 8, 5, stride=1, bias=True, bn=True, act=nn.LeakyReLU(0.2, True), sn=False)
+    torch.manual_seed(4)
+    ref = nn.Sequential(nn.Conv2d(4, 8, 5, padding=2, bias=True), nn.BatchNorm2d(8), nn.LeakyReLU(0.2, True))
+    ours.cuda()
+    x = torch.rand(3, 4, 8, 8, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    xr = x.clone().requires_grad_(True)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yr, yg = ref(xr), ours(xg)
+    g = torch.rand(yr.shape, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    yr.backward(g); yg.backward(g.cuda())
+    sc = lambda t: float(t.abs().max()) + 1e-30
+    assert float((yg.detach().cpu() - yr.detach()).abs().max()) <= 5e-6 * sc(yr)
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 2e-5 * sc(xr.grad)
+    assert float((ours[0].weight.grad.cpu() - ref[0].weight.grad).abs().max()) <= 2e-5 * sc(ref[0].weight.grad)
+    assert float((ours[1].weight.grad.cpu() - ref[1].weight.grad).abs().max()) <= 2e-5 * sc(ref[1].weight.grad)
+    assert torch.allclose(ours[1].running_mean.cpu(), ref[1].running_mean, rtol=1e-5, atol=1e-7)
