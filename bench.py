@@ -212,9 +212,6 @@ def main():
                     help="capture the step into a hipGraph after the warm-up and time replays (bit-identical results; with N > 1 the "
                          "RCCL all-reduces are captured with it; the roofline kernel events are then taken from two extra eager steps "
                          "outside the timed region)")
-    ap.add_argument("--no-graph-events", action="store_true",
-                    help="with --hip-graph: do not put external HIP event nodes into the graph (the roofline events then come from two "
-                         "eager steps after the timed replays)")
     ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--lr", type=float, default=5e-7,
                     help="Adam learning rate of both optimizers.  The reference's 5e-5 (SURVEY 8d) lets the Discriminator separate "
@@ -274,12 +271,8 @@ def main():
         run(eager_step)
     torch.cuda.synchronize()
     watch = (args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels, 1)
-    graph_events = use_graph and not args.no_kernel_events and not args.no_graph_events
     if use_graph:
-        if graph_events:   # HIP events recorded as EXTERNAL event nodes of the graph: every replay re-records them
-            ops.KERNEL_EVENTS.enable(shape=watch, every=args.event_every, external=True)
         step = trainer.capture_gan_step(lr, hr) if args.workload == "gan" else trainer.capture_pretrain_step(lr, hr)
-        ops.KERNEL_EVENTS.shape = None              # (nothing further is bracketed; the pairs inside the graph stay)
         run(step)                                   # first replay outside the timed region (graph upload)
         torch.cuda.synchronize()
     elif not args.no_kernel_events:
@@ -302,14 +295,11 @@ def main():
     exposed = [o.buckets.exposed_ms() for o in optims]
     for o in optims:
         o.buckets.measure_exposed = False
-    if graph_events:                                # the in-graph events hold the times of the LAST timed replay
-        kern = ops.KERNEL_EVENTS.drain()
-    else:
-        if use_graph and not args.no_kernel_events: # plain events cannot be read back from inside a graph: two eager steps for them
-            ops.KERNEL_EVENTS.enable(shape=watch)
-            for _ in range(2):
-                run(eager_step)
-        kern = ops.KERNEL_EVENTS.drain()
+    if use_graph and not args.no_kernel_events:     # events cannot be read back from inside a graph: two eager steps for them
+        ops.KERNEL_EVENTS.enable(shape=watch)
+        for _ in range(2):
+            run(eager_step)
+    kern = ops.KERNEL_EVENTS.drain()
     # host cost of ONE eager step: enqueue three steps on an idle GPU without waiting for it (python + launches only)
     torch.cuda.synchronize()
     th = time.perf_counter()
@@ -421,10 +411,7 @@ def roofline_objects(args, kern):
              "traffic_note": (f"HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in profiles/{src}"
                               if src else "no committed PMC summary found"),
              "launches_timed": n, "avg_launch_us": round(ms * 1e3, 2),
-             "sampling": ((f"every {getattr(args, 'event_every', 1)}-th launch of this kind is bracketed by HIP events recorded as external event "
-                           "nodes INSIDE the captured step; the figures are those of the last timed replay"
-                           if not getattr(args, "no_graph_events", False) else
-                           "every launch of this kind in two eager steps after the timed graph replays is bracketed by HIP events")
+             "sampling": ("every launch of this kind in two eager steps after the timed graph replays is bracketed by HIP events"
                           if getattr(args, "hip_graph", False) else
                           f"every {getattr(args, 'event_every', 1)}-th launch of this kind inside the timed steps is bracketed by HIP events")}
         if issue_frac < 1.0:

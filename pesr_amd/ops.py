@@ -33,67 +33,20 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-class _HipEvent:
-    """A raw HIP event recorded with hipEventRecordExternal: under stream capture it becomes an event-record NODE of the graph
-    (torch.cuda.Event.record() under capture only adds a dependency and cannot be timed), so every replay re-records it and
-    hipEventElapsedTime works after the replay.  ctypes on the HIP runtime torch itself loaded."""
-    _hip = None
-
-    @classmethod
-    def hip(cls):
-        if cls._hip is None:
-            import ctypes
-            import glob
-            import os
-            cand = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*"))
-            h = ctypes.CDLL(cand[0] if cand else "libamdhip64.so")
-            h.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
-            h.hipEventRecordWithFlags.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
-            h.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
-            h.hipEventDestroy.argtypes = [ctypes.c_void_p]
-            cls._hip = h
-        return cls._hip
-
-    def __init__(self):
-        import ctypes
-        self.h = ctypes.c_void_p()
-        rc = self.hip().hipEventCreate(ctypes.byref(self.h))
-        if rc:
-            raise _lib.PesrHipError(f"hipEventCreate failed: {rc}")
-
-    def record(self):
-        rc = self.hip().hipEventRecordWithFlags(self.h, _stream(), 1)      # hipEventRecordExternal
-        if rc:
-            raise _lib.PesrHipError(f"hipEventRecordWithFlags(external) failed: {rc}")
-
-    def elapsed_time(self, other) -> float:
-        import ctypes
-        ms = ctypes.c_float()
-        rc = self.hip().hipEventElapsedTime(ctypes.byref(ms), self.h, other.h)
-        if rc:
-            raise _lib.PesrHipError(f"hipEventElapsedTime failed: {rc}")
-        return float(ms.value)
-
-    def __del__(self):
-        try:
-            self.hip().hipEventDestroy(self.h)
-        except Exception:
-            pass
-
-
 class _KernelEvents:
     """Optional HIP-event bracket around every launch of ONE conv shape (bench.py's live roofline figures), kept per kind
     ("fwd", "dgrad", "wgrad").  Events are recorded on the stream the kernel is launched on (torch's current stream).
-    external = True: raw HIP events recorded with hipEventRecordExternal - usable INSIDE a captured step (one pair per sampled
-    launch becomes part of the graph; after a replay they hold that replay's times)."""
+    Not inside a captured step: an event recorded under capture is only a dependency and cannot be timed, and recording it as an
+    external event node (hipEventRecordWithFlags(hipEventRecordExternal)) is refused under capture by this ROCm runtime
+    (hipErrorInvalidValue; tried in round 3) - bench.py --hip-graph takes its kernel times from eager steps."""
 
     def __init__(self):
-        self.shape, self.pairs, self.every, self._n, self.external = None, {}, 1, {}, False
+        self.shape, self.pairs, self.every, self._n = None, {}, 1, {}
 
-    def enable(self, shape, every=1, external=False):
+    def enable(self, shape, every=1):
         """Watch launches of `shape`; bracket every `every`-th launch of each kind (two event records per bracket are not free:
         bracketing all ~200 watched launches of a GAN step cost 2 % of the step)."""
-        self.shape, self.pairs, self.every, self._n, self.external = tuple(shape), {}, max(1, int(every)), {}, bool(external)
+        self.shape, self.pairs, self.every, self._n = tuple(shape), {}, max(1, int(every)), {}
 
     def begin(self, kind, N, H, W, Cin, Cout, stride):
         """-> an open bracket (or None when this launch is not the watched shape / not sampled); close it with end()."""
@@ -103,29 +56,23 @@ class _KernelEvents:
         self._n[kind] = n + 1
         if n % self.every:
             return None
-        e0 = _HipEvent() if self.external else torch.cuda.Event(enable_timing=True)
+        e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
         return (kind, e0)
 
     def end(self, br):
         if br is not None:
-            e1 = _HipEvent() if self.external else torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             self.pairs.setdefault(br[0], []).append((br[1], e1))
 
-    def read(self):
-        """-> {kind: (average milliseconds per launch, launches)} of the recorded pairs (synchronises); keeps them (events that
-        live inside a captured step are re-recorded by every replay)."""
-        if not self.pairs:
+    def drain(self):
+        """-> {kind: (average milliseconds per launch, launches)}; disables recording."""
+        pairs, self.pairs, self.shape = self.pairs, {}, None
+        if not pairs:
             return {}
         torch.cuda.synchronize()
-        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self.pairs.items()}
-
-    def drain(self):
-        """read(), then forget the pairs and disable recording."""
-        out = self.read()
-        self.pairs, self.shape = {}, None
-        return out
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in pairs.items()}
 
 
 KERNEL_EVENTS = _KernelEvents()

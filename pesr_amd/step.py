@@ -206,10 +206,7 @@ class Trainer:
             o.use_device_state()
         st = {"lr": lr.clone(), "hr": hr.clone(), "optims": optims, "gp_u": gp_u}
         steps = [o.steps for o in optims]
-        # timing events inside a graph only in their external form (ops._HipEvent): plain torch events cannot be timed there
-        watched = ops.KERNEL_EVENTS.shape
-        if not ops.KERNEL_EVENTS.external:
-            ops.KERNEL_EVENTS.shape = None
+        watched, ops.KERNEL_EVENTS.shape = ops.KERNEL_EVENTS.shape, None       # no timing events inside a graph
         torch.cuda.synchronize()
         self._quiesce_process_group()
         st["graph"] = torch.cuda.CUDAGraph()
