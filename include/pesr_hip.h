@@ -79,6 +79,7 @@ int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float
 #define PESR_WGRAD_AUTO 0
 #define PESR_WGRAD_DIRECT 1
 #define PESR_WGRAD_WINO23 2
+#define PESR_WGRAD_WINO4X 3 /* as AUTO, with the F(4,3) kernel in its v_mfma_f32_32x32x2_f32 form (12 waves; same results up to rounding) */
 size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo);
 int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                        int stride, float alpha, int ps_in, int algo, int accumulate, void* workspace, size_t ws_bytes, void* stream);

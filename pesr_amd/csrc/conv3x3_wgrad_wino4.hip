@@ -340,6 +340,267 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round-3 variant on v_mfma_f32_32x32x2_f32 (PESR_WGRAD_WINO4X): same transform, same 64(co) x 32(ci) x 18 block, same segment
+// sweep, ring, split-K slab and reduce.  What changes is who owns what: TWELVE waves = 2 co halves (32 channels each) x the 6 xi
+// planes; a wave keeps dU_xi[ky = 0..2] of its 32 x 32 tile (3 accumulator tiles = 48 VGPRs) and, per k-step (TWO x-tiles),
+// reads 2 dM fragments (the segment's two rows) and 4 V fragments (input rows r-1 .. r+2) for SIX 64-cycle MFMAs - one
+// ds_read_b32 per MFMA where the 16x16x4 form above needs 15 per 18 32-cycle MFMAs, i.e. 0.4 of the LDS read bytes per flop.
+// The LDS planes are plain [x-tile][channel] arrays: a fragment read touches 2 x 32 consecutive floats, an item's staging store
+// 8 lanes x 16 bytes contiguous - conflict-free without any swizzle.  Three waves per SIMD hide what two could not.
+// G^T needs all six xi of a tap: the waves park their accumulators in LDS (147 KB, the staging buffers are free by then) and all
+// 768 threads finish the nine taps of the block in the same order of additions as the kernel above.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int X4_NT = 768;
+constexpr int X4_VPLANE = G4_TXT * 32, X4_VROW = 6 * X4_VPLANE;       // floats: V row slot [6 xi][12 x-tiles][32 ci]
+constexpr int X4_DPLANE = G4_TXT * 64, X4_DROW = 6 * X4_DPLANE;       // floats: dM row     [6 xi][12 x-tiles][64 co]
+
+__global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const vring = lds;                             // [6 slots] V rows
+    float* const dmbuf = lds + G4_RING * X4_VROW;         // [2 buffers][2 rows] dM rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c32 = lane & 31, ks = lane >> 5;            // fragment lane: channel, k-slot (x-tile 2q + ks of k-step q)
+    const int cot2 = wave / 6, xi = wave - cot2 * 6;
+
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int cit = bid % a.ci_tiles;  bid /= a.ci_tiles;
+    const int cot = bid % a.co_tiles;
+    const int sp = bid / a.co_tiles;
+    const int ci0 = cit * 32, co0 = cot * 64;
+
+    const int seg_begin = sp * a.segs_per_split;
+    int seg_end = seg_begin + a.segs_per_split;
+    if (seg_end > a.total_segs) seg_end = a.total_segs;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    float bsum = 0.f;
+
+    // ---- staging roles: threads 0..191 (waves 0..2) the 192 V items (2 rows x 12 x-tiles x 8 ci groups, six input columns each),
+    //      threads 192..575 (waves 3..8) the 384 dM items (2 rows x 12 x-tiles x 16 co groups, four columns each); one register set
+    const bool v_thr = tid < 192, d_thr = tid >= 192 && tid < 576;
+    const int vi = v_thr ? tid : 0;
+    const int v_rr = vi / 96, vt = (vi % 96) >> 3, vc4 = vi & 7;
+    const int di = d_thr ? tid - 192 : 0;
+    const int d_rr = di / 192, dt = (di % 192) >> 4, dc4 = di & 15;
+    const int v_pos = vt * 32 + vc4 * 4;
+    const int d_pos = dt * 64 + dc4 * 4;
+    const int d_C = a.ps_in ? (a.Cout >> 2) : a.Cout;
+    int d_choff;
+    {
+        const int pch = co0 + dc4 * 4;
+        if (a.ps_in) { const int sub = pch / d_C, cc = pch - sub * d_C; d_choff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * d_C + cc; }
+        else d_choff = pch;
+    }
+    u32x4 st[6];                  // V thread: six input columns; dM thread: four gradient columns
+    unsigned off[6];
+    auto set_strip = [&](int xs) {
+        if (v_thr) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ix = xs * 48 + 4 * vt - 1 + j;
+                off[j] = (ix >= 0 && ix < a.W) ? (unsigned)((ix * a.Cin + ci0 + vc4 * 4) * 4) : 0x80000000u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ox = xs * 48 + 4 * dt + j;
+                off[j] = (d_thr && ox < a.W) ? (unsigned)(((a.ps_in ? 2 * ox * d_C : ox * a.Cout) + d_choff) * 4) : 0x80000000u;
+            }
+            off[4] = off[5] = 0x80000000u;
+        }
+    };
+    const unsigned x_row_bytes = (unsigned)a.W * a.Cin * 4;
+    const unsigned d_row_bytes = (unsigned)a.W * a.Cout * 4;
+    auto uniform_ptr = [](const float* p) -> const float* {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const float*)(((unsigned long long)hi << 32) | lo);
+    };
+    // (descriptors wave-uniform, as above: the V descriptor spans the two rows that mix inside wave 1, lanes add their row's
+    // pitch; the dM rows change at thread 384 = a wave boundary)
+    auto load_stage = [&](int img, int v_iy0, int d_oy0) {   // V rows v_iy0, v_iy0 + 1; dM rows d_oy0, d_oy0 + 1
+        if (wave < 3) {
+            const float* const rowp = a.x + ((long)img * a.H + v_iy0) * ((long)a.W * a.Cin);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0, 2 * x_row_bytes, 0x00020000);
+            const int iy = v_iy0 + v_rr;
+            const bool row_ok = iy >= 0 && iy < a.H;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                st[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? off[j] + (unsigned)v_rr * x_row_bytes : 0x80000000u, 0, 0);
+        } else if (wave < 9) {
+            const int oy = d_oy0 + d_rr;
+            const bool row_ok = oy < a.H;
+            const int ry = row_ok ? oy : 0;
+            const float* const rowp = a.ps_in ? a.dy + ((size_t)img * (2 * a.H) + 2 * ry) * (2 * a.W) * d_C
+                                              : a.dy + ((size_t)img * a.H + ry) * a.W * a.Cout;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0,
+                                                                                __builtin_amdgcn_readfirstlane(row_ok ? d_row_bytes : 0u), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, 0);
+        }
+    };
+    auto store_stage = [&](int v_slot0, int d_buf) {         // V rows -> ring slots v_slot0 + v_rr (mod 6); dM rows -> buffer d_buf
+        if (wave < 3) {
+            const f32x4 d0 = __builtin_bit_cast(f32x4, st[0]), d1 = __builtin_bit_cast(f32x4, st[1]), d2 = __builtin_bit_cast(f32x4, st[2]),
+                        d3 = __builtin_bit_cast(f32x4, st[3]), d4 = __builtin_bit_cast(f32x4, st[4]), d5 = __builtin_bit_cast(f32x4, st[5]);
+            int sl = v_slot0 + v_rr; if (sl >= G4_RING) sl -= G4_RING;
+            float* p = vring + sl * X4_VROW + v_pos;
+            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
+            *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
+            *(f32x4*)(p + X4_VPLANE) = t1 + t2;
+            *(f32x4*)(p + 2 * X4_VPLANE) = t1 - t2;
+            *(f32x4*)(p + 3 * X4_VPLANE) = t3 + 2.0f * t4;
+            *(f32x4*)(p + 4 * X4_VPLANE) = t3 - 2.0f * t4;
+            *(f32x4*)(p + 5 * X4_VPLANE) = 4.0f * d1 + (d5 - 5.0f * d3);
+        } else if (wave < 9) {
+            const f32x4 g0 = __builtin_bit_cast(f32x4, st[0]), g1 = __builtin_bit_cast(f32x4, st[1]), g2 = __builtin_bit_cast(f32x4, st[2]),
+                        g3 = __builtin_bit_cast(f32x4, st[3]);
+            float* p = dmbuf + (d_buf * 2 + d_rr) * X4_DROW + d_pos;
+            const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
+            *(f32x4*)(p) = g0;
+            *(f32x4*)(p + X4_DPLANE) = e02 + e13;
+            *(f32x4*)(p + 2 * X4_DPLANE) = e02 - e13;
+            *(f32x4*)(p + 3 * X4_DPLANE) = f02 + 2.0f * f13;
+            *(f32x4*)(p + 4 * X4_DPLANE) = f02 - 2.0f * f13;
+            *(f32x4*)(p + 5 * X4_DPLANE) = g3;
+        }
+    };
+    auto seg_coords = [&](int seg, int& img, int& xs, int& row) {
+        const int strip = seg / a.segs_y;
+        row = 2 * (seg - strip * a.segs_y);
+        img = strip / a.segs_x;
+        xs = strip - img * a.segs_x;
+    };
+    auto stage_strip_start = [&](int img, int row, int buf) {   // halo rows row-1 .. row+2 -> slots 0 .. 3; dM(row, row+1) -> buf
+        load_stage(img, row - 1, row); store_stage(0, buf);      // V rows row-1, row  + both dM rows
+        if (wave < 3) { load_stage(img, row + 1, 0); store_stage(2, buf); }   // V rows row+1, row+2
+    };
+
+    // ---- fragment addresses (floats): lane (c32, ks) reads x-tile 2q + ks, channel c32 of its tile ---------------------------
+    const int b_lane = xi * X4_VPLANE + ks * 32 + c32;
+    const int a_lane = xi * X4_DPLANE + ks * 64 + cot2 * 32 + c32;
+
+    if (seg_begin >= seg_end) return;
+    int img, xs, row;
+    seg_coords(seg_begin, img, xs, row);
+    set_strip(xs);
+    stage_strip_start(img, row, 0);
+    if (seg_begin + 1 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
+    __syncthreads();
+    int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
+    constexpr int KQ = G4_TXT / 2;                          // k-steps per row
+#ifndef X4_STORE_STEP
+#define X4_STORE_STEP 3
+#endif
+
+#pragma unroll 1
+    for (int seg = seg_begin; seg < seg_end; ++seg) {
+        const int par = (seg - seg_begin) & 1;
+        const bool more = seg + 1 < seg_end;
+        const bool cont = more && row + 2 < a.H;
+        const bool cont2 = cont && seg + 2 < seg_end && row + 4 < a.H;
+        const float* const db = dmbuf + (par * 2) * X4_DROW + a_lane;
+        const float* vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int sl = base + q; if (sl >= G4_RING) sl -= G4_RING;
+            vb[q] = vring + sl * X4_VROW + b_lane;
+        }
+        float fa0[2], fb0[4], fa1[2], fb1[4];
+#define X4_READ(FA, FB, Q)                                                                       \
+        {                                                                                        \
+            FA[0] = db[(Q) * 128]; FA[1] = db[X4_DROW + (Q) * 128];                              \
+            _Pragma("unroll") for (int rw = 0; rw < 4; ++rw) FB[rw] = vb[rw][(Q) * 64];          \
+        }
+#define X4_MFMA(FA, FB)                                                                          \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                       \
+            acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0);     \
+            acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
+        }                                                                                        \
+        if (xi == 1) bsum += FA[0] + FA[1];                 /* dM_1 = dy0+dy1+dy2+dy3 */
+        X4_READ(fa0, fb0, 0)
+#pragma unroll
+        for (int q = 0; q < KQ; q += 2) {
+            X4_READ(fa1, fb1, q + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            X4_MFMA(fa0, fb0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < KQ) X4_READ(fa0, fb0, q + 2)
+            if (q + 1 == X4_STORE_STEP || q == X4_STORE_STEP) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (cont) {
+                    store_stage(base + 4, par ^ 1);
+                    if (cont2) load_stage(img, row + 5, row + 4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            X4_MFMA(fa1, fb1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef X4_READ
+#undef X4_MFMA
+        if (cont) {
+            __syncthreads();
+            base += 2; if (base >= G4_RING) base -= G4_RING;
+            row += 2;
+        } else if (more) {
+            __syncthreads();
+            seg_coords(seg + 1, img, xs, row);
+            set_strip(xs);
+            stage_strip_start(img, row, par ^ 1);
+            if (seg + 2 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
+            __syncthreads();
+            base = 0;
+        }
+    }
+    __syncthreads();
+
+    if (a.bias_part && cit == 0) {     // the xi = 1 waves hold column sums of dy: lane pairs (c, c + 32) meet in LDS, fixed order
+        float* red = lds;
+        if (xi == 1) red[cot2 * 64 + lane] = bsum;
+        __syncthreads();
+        if (tid < 64 && co0 + tid < a.Cout) {
+            const int h = tid >> 5, c = tid & 31;
+            a.bias_part[(size_t)sp * a.Cout + co0 + tid] = red[h * 64 + c] + red[h * 64 + 32 + c];
+        }
+        __syncthreads();
+    }
+    // ---- G^T: park the accumulators as ob[cot2][xi][ky][row 32][col 32], then every thread finishes 8 (co, ci) positions ------
+    float* const ob = lds;
+    {
+        float* o = ob + ((cot2 * 6 + xi) * 3) * 1024 + c32;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rw = (j >> 2) * 8 + ks * 4 + (j & 3);          // D layout of the 32x32 tile: row = co, col = lane & 31 = ci
+                o[ky * 1024 + rw * 32] = acc[ky][j];
+            }
+    }
+    __syncthreads();
+    float* const out = a.slab + (size_t)sp * 9 * a.Cout * a.Cin;
+    const unsigned tap = (unsigned)a.Cout * a.Cin;
+    for (int e = tid; e < 2 * 3 * 1024; e += X4_NT) {
+        const int col = e & 31, rw = (e >> 5) & 31, ky = (e >> 10) % 3, h = e / 3072;
+        const float* u = ob + (h * 6 * 3 + ky) * 1024 + rw * 32 + col;       // + xi * 3 * 1024
+        const float u0 = u[0], u1 = u[3072], u2 = u[2 * 3072], u3 = u[3 * 3072], u4 = u[4 * 3072], u5 = u[5 * 3072];
+        const float s12 = u1 + u2, d12 = u1 - u2, s34 = u3 + u4, d34 = u3 - u4;
+        const float w0 = (0.25f * u0 - (1.0f / 6.0f) * s12) + (1.0f / 24.0f) * s34;
+        const float w1 = ((-1.0f / 6.0f) * d12) + (1.0f / 12.0f) * d34;
+        const float w2 = ((-1.0f / 6.0f) * s12) + ((1.0f / 6.0f) * s34 + u5);
+        const unsigned go = ((unsigned)(ky * 3) * a.Cout + co0 + h * 32 + rw) * a.Cin + ci0 + col;
+        out[go] = w0; out[go + tap] = w1; out[go + 2 * tap] = w2;
+    }
+}
+
 namespace {
 struct Wg4Plan { int co_tiles, ci_tiles, segs_x, segs_y, total_segs, split, segs_per_split; size_t slab_bytes, total_bytes; };
 
@@ -372,8 +633,9 @@ size_t pesr_conv3x3_wgrad_wino4_ws_bytes(int N, int H, int W, int Cin, int Cout)
 }
 
 // returns PESR_EINVAL when the shape is not covered (the caller then tries the F(2,3) form / the direct kernel)
+// variant 0: the 16x16x4 kernel (8 waves); 1: the 32x32x2 kernel (12 waves)
 int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                                    float alpha, int ps_in, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                    float alpha, int ps_in, int accumulate, int variant, void* ws, size_t ws_bytes, hipStream_t stream) {
     Wg4Plan p;
     if (!wg4_plan(N, H, W, Cin, Cout, &p)) return PESR_EINVAL;
     if (!ws || ws_bytes < p.total_bytes) return PESR_EWORKSPACE;
@@ -391,8 +653,15 @@ int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, 
     std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
+    constexpr size_t ldsx = (size_t)2 * 6 * 3 * 1024 * sizeof(float);      // the variant's G^T staging (147 KB) exceeds its ring (129 KB)
+    static_assert(ldsx >= (size_t)(G4_RING * X4_VROW + 4 * X4_DROW) * sizeof(float) && ldsx <= 160 * 1024, "wgrad-wino4x LDS budget");
+    static std::once_flag attr_once_x;
+    std::call_once(attr_once_x, [&] {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
     const int grid = p.split * p.co_tiles * p.ci_tiles;
-    hipLaunchKernelGGL(conv3x3_wgrad_wino4_kernel, dim3(grid), dim3(G4_NT), lds, stream, a);
+    if (variant == 1) hipLaunchKernelGGL(conv3x3_wgrad_wino4x_kernel, dim3(grid), dim3(X4_NT), ldsx, stream, a);
+    else hipLaunchKernelGGL(conv3x3_wgrad_wino4_kernel, dim3(grid), dim3(G4_NT), lds, stream, a);
     int rc = pesr_launch_status();
     if (rc) return rc;
     // the partial blocks already are dw in tap order: the direct kernel's fixed-order reduce finishes the job

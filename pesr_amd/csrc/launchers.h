@@ -76,7 +76,7 @@ int pesr_wgrad_reduce_launch(const float* slab, float* dw, int split, int Cout, 
 // transposed Winograd F(4,3) weight gradient (conv3x3_wgrad_wino4.hip); PESR_EINVAL for shapes it does not cover
 size_t pesr_conv3x3_wgrad_wino4_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                                    float alpha, int ps_in, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+                                    float alpha, int ps_in, int accumulate, int variant, void* ws, size_t ws_bytes, hipStream_t stream);
 // transposed Winograd weight gradient (conv3x3_wgrad_wino.hip); the launch returns PESR_EINVAL for shapes it does not cover
 size_t pesr_conv3x3_wgrad_wino_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int pesr_conv3x3_wgrad_wino_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,

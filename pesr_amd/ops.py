@@ -356,7 +356,9 @@ def _out(t, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23 = 0, 1, 2      # include/pesr_hip.h PESR_WGRAD_*
+WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23, WGRAD_WINO4X = 0, 1, 2, 3      # include/pesr_hip.h PESR_WGRAD_*
+# PESR_WGRAD_WINO4X=1: the 32x32x2-MFMA form of the F(4,3) weight gradient wherever auto would pick F(4,3) (round-3 A/B switch)
+USE_WGRAD_WINO4X = __import__("os").environ.get("PESR_WGRAD_WINO4X", "0") == "1"
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: float = 1.0, want_bias: bool = True,
@@ -371,7 +373,7 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
     cout = dy.shape[3] * (4 if ps_in else 1)
     L = _lib.lib()
     if algo is None:
-        algo = (0 if (USE_WINO4 and USE_WGRAD_WINO4) else 2) if USE_WGRAD_WINO else 1
+        algo = ((WGRAD_WINO4X if USE_WGRAD_WINO4X else WGRAD_AUTO) if (USE_WINO4 and USE_WGRAD_WINO4) else 2) if USE_WGRAD_WINO else 1
     nbytes = L.pesr_conv3x3_wgrad_workspace_bytes(N, H, W, Cin, cout, stride, algo)
     if nbytes == 0:
         raise _lib.PesrHipError(f"pesr_conv3x3_wgrad: unsupported shape Cin={Cin} Cout={cout} stride={stride}")
