@@ -443,7 +443,9 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     if (ws_bytes < p.total_bytes || !ws) return PESR_EWORKSPACE;
     if (ps_in && (stride != 1 || Cout % 16)) return PESR_EINVAL;
     if (stride == 1 && (algo == 0 || algo == 3)) {   // Winograd F(4,3) where it applies (width % 4 == 0 and >= 48, 64-multiple channels)
-        const int rc = pesr_conv3x3_wgrad_wino4_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, accumulate, algo == 3 ? 1 : 0, ws,
+        // auto: the 32x32x2-MFMA form (round 3: 207 vs 219 us at the G-body shape, 211 vs 233 us inside the train step);
+        // PESR_WGRAD_WINO4_16X16 (3): round 2's 16x16x4 form, kept as a cross-check of the same transform
+        const int rc = pesr_conv3x3_wgrad_wino4_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, accumulate, algo == 3 ? 0 : 1, ws,
                                                        ws_bytes, stream);
         if (rc != PESR_EINVAL && rc != PESR_EWORKSPACE) return rc;
     }

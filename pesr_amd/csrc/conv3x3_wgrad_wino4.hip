@@ -520,12 +520,21 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
             FA[0] = db[(Q) * 128]; FA[1] = db[X4_DROW + (Q) * 128];                              \
             _Pragma("unroll") for (int rw = 0; rw < 4; ++rw) FB[rw] = vb[rw][(Q) * 64];          \
         }
+#ifdef X4_INTERLEAVE                                        /* A/B: the three accumulators in turn instead of pairwise */
+#define X4_MFMA(FA, FB)                                                                          \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                         \
+            acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0);     \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                         \
+            acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
+        if (xi == 1) bsum += FA[0] + FA[1];
+#else
 #define X4_MFMA(FA, FB)                                                                          \
         _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                       \
             acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0);     \
             acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
         }                                                                                        \
         if (xi == 1) bsum += FA[0] + FA[1];                 /* dM_1 = dy0+dy1+dy2+dy3 */
+#endif
         X4_READ(fa0, fb0, 0)
 #pragma unroll
         for (int q = 0; q < KQ; q += 2) {

@@ -170,7 +170,7 @@ def wgrad_kernel_for(N, H, W, Cin, Cout):
     """(kernel name, fraction of the algorithmic flops it issues on the matrix pipe) of the stride-1 weight gradient."""
     if USE_WGRAD_WINO and Cin % 64 == 0 and Cout % 64 == 0 and W >= 48:
         if USE_WINO4 and USE_WGRAD_WINO4 and W % 4 == 0 and ((W // 4 + 11) // 12) * 12 * 8 <= (W // 4) * 9:
-            return "conv3x3_wgrad_wino4_kernel", 0.5
+            return ("conv3x3_wgrad_wino4_kernel" if USE_WGRAD_WINO4_16X16 else "conv3x3_wgrad_wino4x_kernel"), 0.5
         if W % 2 == 0 and ((W // 2 + 23) // 24) * 24 * 8 <= (W // 2) * 9:
             return "conv3x3_wgrad_wino_kernel", 2.0 / 3.0
     return "conv3x3_wgrad_kernel", 1.0
@@ -356,9 +356,9 @@ def _out(t, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23, WGRAD_WINO4X = 0, 1, 2, 3      # include/pesr_hip.h PESR_WGRAD_*
-# PESR_WGRAD_WINO4X=1: the 32x32x2-MFMA form of the F(4,3) weight gradient wherever auto would pick F(4,3) (round-3 A/B switch)
-USE_WGRAD_WINO4X = __import__("os").environ.get("PESR_WGRAD_WINO4X", "0") == "1"
+WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23, WGRAD_WINO4_16X16 = 0, 1, 2, 3      # include/pesr_hip.h PESR_WGRAD_*
+# PESR_WGRAD_WINO4_16X16=1: round 2's 16x16x4-MFMA form of the F(4,3) weight gradient instead of the 32x32x2 form (A/B switch)
+USE_WGRAD_WINO4_16X16 = __import__("os").environ.get("PESR_WGRAD_WINO4_16X16", "0") == "1"
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: float = 1.0, want_bias: bool = True,
@@ -373,7 +373,7 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
     cout = dy.shape[3] * (4 if ps_in else 1)
     L = _lib.lib()
     if algo is None:
-        algo = ((WGRAD_WINO4X if USE_WGRAD_WINO4X else WGRAD_AUTO) if (USE_WINO4 and USE_WGRAD_WINO4) else 2) if USE_WGRAD_WINO else 1
+        algo = ((WGRAD_WINO4_16X16 if USE_WGRAD_WINO4_16X16 else WGRAD_AUTO) if (USE_WINO4 and USE_WGRAD_WINO4) else 2) if USE_WGRAD_WINO else 1
     nbytes = L.pesr_conv3x3_wgrad_workspace_bytes(N, H, W, Cin, cout, stride, algo)
     if nbytes == 0:
         raise _lib.PesrHipError(f"pesr_conv3x3_wgrad: unsupported shape Cin={Cin} Cout={cout} stride={stride}")
