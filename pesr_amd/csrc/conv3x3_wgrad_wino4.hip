@@ -497,6 +497,11 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     __syncthreads();
     int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
     constexpr int KQ = G4_TXT / 2;                          // k-steps per row
+    // Static priority for the second-dispatched half (waves 6..11), set once: the two halves run the same program in lockstep
+    // behind one barrier per segment, and the younger half loses every arbitration; raised, it pulls ahead and the halves'
+    // LDS read bursts and MFMA blocks de-phase (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): 209.6 -> 206.2 us; three
+    // levels (w, w + 4, w + 8 share a SIMD) 206.9, the first half raised instead 208.8 (profiles/r03_wgrad_variants.txt).
+    if (cot2) __builtin_amdgcn_s_setprio(1);
 #ifndef X4_STORE_STEP
 #define X4_STORE_STEP 3
 #endif
@@ -515,33 +520,25 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
             vb[q] = vring + sl * X4_VROW + b_lane;
         }
         float fa0[2], fb0[4], fa1[2], fb1[4];
+#define X4_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define X4_READ(FA, FB, Q)                                                                       \
         {                                                                                        \
             FA[0] = db[(Q) * 128]; FA[1] = db[X4_DROW + (Q) * 128];                              \
             _Pragma("unroll") for (int rw = 0; rw < 4; ++rw) FB[rw] = vb[rw][(Q) * 64];          \
         }
-#ifdef X4_INTERLEAVE                                        /* A/B: the three accumulators in turn instead of pairwise */
-#define X4_MFMA(FA, FB)                                                                          \
-        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                         \
-            acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0);     \
-        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                         \
-            acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
-        if (xi == 1) bsum += FA[0] + FA[1];
-#else
 #define X4_MFMA(FA, FB)                                                                          \
         _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                       \
             acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0);     \
             acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
         }                                                                                        \
         if (xi == 1) bsum += FA[0] + FA[1];                 /* dM_1 = dy0+dy1+dy2+dy3 */
-#endif
         X4_READ(fa0, fb0, 0)
 #pragma unroll
         for (int q = 0; q < KQ; q += 2) {
             X4_READ(fa1, fb1, q + 1)
-            __builtin_amdgcn_sched_barrier(0);
+            X4_FENCE();
             X4_MFMA(fa0, fb0)
-            __builtin_amdgcn_sched_barrier(0);
+            X4_FENCE();
             if (q + 2 < KQ) X4_READ(fa0, fb0, q + 2)
             if (q + 1 == X4_STORE_STEP || q == X4_STORE_STEP) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -550,12 +547,13 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
                     if (cont2) load_stage(img, row + 5, row + 4);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            X4_FENCE();
             X4_MFMA(fa1, fb1)
-            __builtin_amdgcn_sched_barrier(0);
+            X4_FENCE();
         }
 #undef X4_READ
 #undef X4_MFMA
+#undef X4_FENCE
         if (cont) {
             __syncthreads();
             base += 2; if (base >= G4_RING) base -= G4_RING;
