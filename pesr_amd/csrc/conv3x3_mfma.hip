@@ -509,8 +509,9 @@ static bool choose_tile(int MT, int S, int hext, int wext, int GH, int GW, int m
     return best >= 0;
 }
 
+// target_wgs: the workgroup count the split-K rule aims at (256 = one per CU; 768 for the 48-pixel tiles, three per CU)
 template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL>
-static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
+static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int target_wgs = 256) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int MT = WAVES_M * WM * 16;
     constexpr int BN = WAVES_N * WN * 16;
@@ -535,8 +536,8 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream) {
     const int C16T = a.Cin / 16;
     a.ksplit = 1; a.chunks_per_split = C16T;
     const size_t out_bytes = (size_t)a.N * a.OH * a.OW * a.cout_store * sizeof(float);
-    if (a.slab && tiles < 160 && a.out_my == 1 && a.out_mx == 1 && !a.ps && C16T >= 8) {
-        int want = (int)((256 + tiles - 1) / tiles);
+    if (a.slab && tiles < (long)target_wgs * 5 / 8 && a.out_my == 1 && a.out_mx == 1 && !a.ps && C16T >= 8) {
+        int want = (int)((target_wgs + tiles - 1) / tiles);
         if (want > 8) want = 8;
         if (want > C16T / 4) want = C16T / 4;
         while (want > 1 && (size_t)want * out_bytes > a.slab_bytes) --want;
@@ -571,6 +572,12 @@ static int dispatch(ConvArgs& a, int hext, int wext, hipStream_t stream) {
     // stride-2 conv to 64 channels (D features.1): the 144-pixel tile's halo (2x2 input pixels per output) leaves room for one
     // 4-wave workgroup per CU only; 64-pixel tiles fit three (141 vs 185 us on 16x192x192x64)
     if (S == 2 && a.ntaps == 9 && a.Cout == 64 && M >= 64 * 512) return launch_cfg<1, 4, 4, 1, S, 5>(a, hext, wext, stream);
+    // Layers whose 144-pixel x 64-channel tiles give at most ~one 4-wave workgroup per CU (D features.5 / .7: 48^2 -> 24^2 x 256,
+    // 24^2 -> 12^2 x 512, and the parity classes of the small stride-2 input gradients): 48-pixel tiles instead - three workgroups
+    // = 12 waves per CU, split-K towards 768 workgroups where a slab is available (round 3: 148 -> 130 us and 151 -> 134 us on
+    // the two forward layers, 161 -> 147 us and 287 -> 199 us on their input gradients, same bits; profiles/r03_stride2_tiles.txt)
+    if (a.Cout % 64 == 0 && a.Cout >= 128 && (long)pesr_cdiv(M, 144) * (a.Cout / 64) <= 320)
+        return launch_cfg<1, 4, 3, 1, S, (S == 1 ? 2 : 4)>(a, hext, wext, stream, 768);
     if (a.Cout % 256 == 0) {
         // enough tiles to fill 256 CUs with the big tile?
         const long tiles_big = (M / 144) * (a.Cout / 256);
