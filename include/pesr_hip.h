@@ -221,6 +221,14 @@ int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* o
 int pesr_psnr_y(const float* a, const float* b, double* out2, int H, int W, int a_nhwc, int b_nhwc, void* workspace,
                 size_t ws_bytes, void* stream);
 
+/* ---- GAN losses on the [B][1] logits (reference train.py:132-133,210-213,244-253; model/focal_loss.py:9-13), value and both
+ * gradients in one launch.  gan_type 0 SGAN, 1 RSGAN, 2 RaSGAN (an extension: batch means over the B samples given);
+ * side 0 = discriminator loss (BCE), 1 = generator loss (BCE, or the reference's FocalLoss when focal = 1, with the torch-0.4
+ * gradient through its weight AND the BCE term).  out[0] = scale * loss; d_real / d_fake [B] = scale * dloss/dlogit, may be NULL.
+ * B <= 1024. */
+int pesr_gan_loss_fwd_bwd(const float* pred_real, const float* pred_fake, int B, int gan_type, int side, int focal, float gamma,
+                          float scale, float* out, float* d_real, float* d_fake, void* stream);
+
 /* ---- fused Adam on one flat buffer (reference train.py:124-125; torch.optim.Adam) ---------------- */
 /* g is multiplied by grad_scale first (1/world_size after a sum all-reduce). step is 1-based. */
 int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

@@ -228,3 +228,8 @@ PESR_API int pesr_conv_kxk_wgrad(const float* x, const float* dy, float* dw, flo
                                  int stride, void* stream) {
     return pesr_conv_kxk_wgrad_launch(x, dy, dw, db, N, H, W, Cin, Cout, k, stride, (hipStream_t)stream);
 }
+
+PESR_API int pesr_gan_loss_fwd_bwd(const float* pred_real, const float* pred_fake, int B, int gan_type, int side, int focal, float gamma,
+                                   float scale, float* out, float* d_real, float* d_fake, void* stream) {
+    return pesr_gan_loss_launch(pred_real, pred_fake, B, gan_type, side, focal, gamma, scale, out, d_real, d_fake, (hipStream_t)stream);
+}

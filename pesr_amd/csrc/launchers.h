@@ -62,6 +62,8 @@ int pesr_loss_l1_tv_launch(const float* sr, const float* hr, float* grad, float*
                            void* ws, size_t ws_bytes, hipStream_t stream);
 int pesr_loss_mse_launch(const float* a, const float* b, float* grad, float* out1, long n, float gscale, void* ws, size_t ws_bytes,
                          hipStream_t stream);
+int pesr_gan_loss_launch(const float* pred_real, const float* pred_fake, int B, int gan, int side, int focal, float gamma, float scale,
+                         float* out, float* d_real, float* d_fake, hipStream_t stream);
 int pesr_adam_dev_launch(float* p, const float* g, float* m, float* v, long n, float* state, float b1, float b2, float eps, float gscale,
                          hipStream_t stream);
 int pesr_adam_launch(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,

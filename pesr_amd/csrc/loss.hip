@@ -134,3 +134,90 @@ int pesr_psnr_y_launch(const float* a, const float* b, double* out2, int H, int 
     hipLaunchKernelGGL(psnr_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)ws, out2, nb, 1.0 / (double)P);
     return pesr_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// GAN losses on the [B, 1] logits (reference train.py:132-133,210-213,244-253 and model/focal_loss.py:9-13): value and the
+// gradients w.r.t. both logit vectors in ONE launch instead of ~25 scalar-sized ATen kernels per loss (sigmoid, log_sigmoid, sub,
+// mul, mean, their backward ...).  B <= 1024, one block.
+//   side 0 (discriminator): SGAN  BCE(r, 1) + BCE(f, 0)            RSGAN  BCE(r - f, 1)      RaSGAN [BCE(r - mean f, 1) + BCE(f - mean r, 0)] / 2
+//   side 1 (generator):     SGAN  L(f, 1)                          RSGAN  L(f - r, 1)        RaSGAN [L(r - mean f, 0) + L(f - mean r, 1)] / 2
+//   L = BCE-with-logits, or (focal = 1) the reference's FocalLoss with the torch-0.4 gradient through w = (1 - pt)^gamma AND the
+//   BCE term: dL/dx = [dw/dx * bce + w * (p - t)] / B,  dw/dx = -gamma (1 - pt)^(gamma - 1) (2t - 1) p (1 - p).
+// All means are over the B samples given (the data-parallel RaSGAN, whose batch means span the ranks, stays on the torch path).
+// out[0] = scale * loss;  d_real / d_fake [B] = scale * dloss/dlogit (either may be NULL).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ float bce_logits(float x, float t) {              // as ATen: (1 - t) x + max(-x, 0) + log(exp(-m) + exp(-x - m))
+    const float m = fmaxf(-x, 0.f);
+    return (1.f - t) * x + m + logf(expf(-m) + expf(-x - m));
+}
+__device__ __forceinline__ void loss_term(float x, float t, int focal, float gamma, float* val, float* dx) {
+    const float p = 1.f / (1.f + expf(-x));
+    const float bce = bce_logits(x, t);
+    if (!focal) { *val = bce; *dx = p - t; return; }
+    const float pt = p * t + (1.f - p) * (1.f - t);
+    const float w = powf(1.f - pt, gamma);
+    const float dw = gamma == 0.f ? 0.f : -gamma * powf(1.f - pt, gamma - 1.f) * (2.f * t - 1.f) * p * (1.f - p);
+    *val = w * bce;
+    *dx = dw * bce + w * (p - t);
+}
+__device__ __forceinline__ double block_sum1024(double v, double* red) {     // fixed order over the 16 waves
+    const double w = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    double s = 0.0;
+    for (int k = 0; k < 16; ++k) s += red[k];
+    return s;
+}
+}  // namespace
+
+__global__ __launch_bounds__(1024) void gan_loss_kernel(const float* __restrict__ pr, const float* __restrict__ pf, int B, int gan, int side,
+                                                        int focal, float gamma, float scale, float* __restrict__ out,
+                                                        float* __restrict__ d_real, float* __restrict__ d_fake) {
+    __shared__ double red[16];
+    const int i = threadIdx.x;
+    const bool on = i < B;
+    const float r = on ? pr[i] : 0.f, f = on ? pf[i] : 0.f;
+    const float invB = 1.0f / (float)B;
+    float val = 0.f, gr = 0.f, gf = 0.f;                   // per-sample loss term(s) and d(sum of terms)/d(r_i), d/d(f_i) before the 1/B
+    const int fo = side == 1 ? focal : 0;                  // the discriminator side is plain BCE in the reference
+    if (gan == 0) {                                        // SGAN
+        if (side == 0) {
+            float v1, g1, v2, g2;
+            loss_term(r, 1.f, 0, 0.f, &v1, &g1); loss_term(f, 0.f, 0, 0.f, &v2, &g2);
+            val = v1 + v2; gr = g1; gf = g2;
+        } else { loss_term(f, 1.f, fo, gamma, &val, &gf); }
+    } else if (gan == 1) {                                 // RSGAN
+        float g;
+        if (side == 0) { loss_term(r - f, 1.f, 0, 0.f, &val, &g); gr = g; gf = -g; }
+        else { loss_term(f - r, 1.f, fo, gamma, &val, &g); gf = g; gr = -g; }
+    }
+    if (gan == 2) {                                        // RaSGAN: two passes (the means first)
+        const float mr = (float)(block_sum1024(on ? (double)r : 0.0, red)) * invB;
+        const float mf = (float)(block_sum1024(on ? (double)f : 0.0, red)) * invB;
+        float va, ga, vb, gb;
+        loss_term(r - mf, side == 0 ? 1.f : 0.f, fo, gamma, &va, &ga);
+        loss_term(f - mr, side == 0 ? 0.f : 1.f, fo, gamma, &vb, &gb);
+        if (!on) { va = vb = ga = gb = 0.f; }
+        const float sa = (float)block_sum1024((double)ga, red), sb = (float)block_sum1024((double)gb, red);
+        val = 0.5f * (va + vb);
+        gr = 0.5f * (ga - sb * invB);                      // r_i also moves every b_j through mean r
+        gf = 0.5f * (gb - sa * invB);
+    }
+    if (!on) val = 0.f;
+    const double tot = block_sum1024((double)val, red);
+    if (i == 0) out[0] = scale * (float)(tot * (double)invB);
+    if (on) {
+        if (d_real) d_real[i] = scale * gr * invB;
+        if (d_fake) d_fake[i] = scale * gf * invB;
+    }
+}
+
+int pesr_gan_loss_launch(const float* pred_real, const float* pred_fake, int B, int gan, int side, int focal, float gamma, float scale,
+                         float* out, float* d_real, float* d_fake, hipStream_t stream) {
+    if (B < 1 || B > 1024 || gan < 0 || gan > 2 || side < 0 || side > 1) return PESR_EINVAL;
+    hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, stream, pred_real, pred_fake, B, gan, side, focal, gamma, scale, out, d_real,
+                       d_fake);
+    return pesr_launch_status();
+}

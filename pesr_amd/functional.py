@@ -988,6 +988,28 @@ class MSELossFn(Function):
         return grad * g, None
 
 
+class GanLossFn(Function):
+    """The discriminator (side 0) or generator (side 1) loss of reference train.py:210-213 / :244-253 on the [B, 1] logits, scaled
+    (alpha_gan): one kernel computes the value and both gradients (ops.gan_loss); backward only scales them."""
+
+    @staticmethod
+    def forward(ctx, pred_real, pred_fake, gan_type, side, focal, gamma, scale):
+        pr, pf = _c(pred_real), _c(pred_fake)
+        out, d_r, d_f = ops.gan_loss(pr, pf, gan_type, side, focal, gamma, scale, need_real=pred_real.requires_grad,
+                                     need_fake=pred_fake.requires_grad)
+        ctx.save_for_backward(d_r, d_f)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d_r, d_f = ctx.saved_tensors
+        return (None if d_r is None else d_r * g), (None if d_f is None else d_f * g), None, None, None, None, None
+
+
+def gan_loss(pred_real, pred_fake, gan_type, side, focal=False, gamma=1.0, scale=1.0):
+    return GanLossFn.apply(pred_real, pred_fake, gan_type, side, bool(focal), float(gamma), float(scale))
+
+
 def l1_loss(sr, hr):
     return L1LossFn.apply(sr, hr)
 

@@ -743,3 +743,24 @@ def conv_kxk_wgrad(x: torch.Tensor, dy: torch.Tensor, k: int, stride: int = 1, w
     db = _out(db_out, (Cout,), x.device) if want_bias else None
     _lib.check(_lib.lib().pesr_conv_kxk_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, H, W, Cin, Cout, k, stride, _stream()), f"pesr_conv_kxk_wgrad[k={k}]")
     return dw, db
+
+
+# ------------------------------------------------------------------------------------------------
+# GAN losses on the logits (reference train.py:210-213,244-253; model/focal_loss.py)
+# ------------------------------------------------------------------------------------------------
+GAN_TYPES = {"SGAN": 0, "RSGAN": 1, "RaSGAN": 2}
+
+
+def gan_loss(pred_real: torch.Tensor, pred_fake: torch.Tensor, gan_type: str, side: int, focal: bool, gamma: float, scale: float = 1.0,
+             need_real: bool = True, need_fake: bool = True):
+    """-> (out [1] = scale * loss, d_real [B,1] | None, d_fake [B,1] | None): value and gradients in one launch."""
+    _chk(pred_real, "gan_loss.pred_real"); _chk(pred_fake, "gan_loss.pred_fake")
+    B = pred_real.numel()
+    assert pred_fake.numel() == B
+    out = torch.empty(1, dtype=torch.float32, device=pred_real.device)
+    d_r = torch.empty_like(pred_real) if need_real else None
+    d_f = torch.empty_like(pred_fake) if need_fake else None
+    rc = _lib.lib().pesr_gan_loss_fwd_bwd(_p(pred_real), _p(pred_fake), B, GAN_TYPES[gan_type], side, int(focal), float(gamma), float(scale),
+                                          _p(out), _p(d_r), _p(d_f), _stream())
+    _lib.check(rc, f"pesr_gan_loss_fwd_bwd[{gan_type}, side {side}]")
+    return out, d_r, d_f

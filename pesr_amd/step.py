@@ -123,15 +123,18 @@ class Trainer:
         pred_real = D(hr_cl)
         sr = G(lr)
         pred_fake = D(sr.detach())
-        if self.gan_type == "SGAN":
+        if self.gan_type not in ("SGAN", "RSGAN", "RaSGAN"):
+            raise ValueError(f"unknown gan_type {self.gan_type}")
+        fused = pred_real.is_cuda and B <= 1024 and not (self.gan_type == "RaSGAN" and self.world_size > 1)
+        if fused:        # value and both gradients in one kernel (ops.gan_loss) instead of ~25 scalar-sized torch kernels
+            total_D_loss = PF.gan_loss(pred_real, pred_fake, self.gan_type, 0)
+        elif self.gan_type == "SGAN":
             total_D_loss = F.binary_cross_entropy_with_logits(pred_real, target_real) + \
                 F.binary_cross_entropy_with_logits(pred_fake, target_fake)
         elif self.gan_type == "RSGAN":
             total_D_loss = F.binary_cross_entropy_with_logits(pred_real - pred_fake, target_real)
-        elif self.gan_type == "RaSGAN":
+        else:            # RaSGAN under data parallelism: the batch means span the ranks (differentiable all-reduce)
             total_D_loss = rasgan_d_loss(pred_real, pred_fake, target_real, target_fake, self.world_size)
-        else:
-            raise ValueError(f"unknown gan_type {self.gan_type}")
         gp = None
         if self.gradient_penalty:
             gp = self._gradient_penalty(hr_cl, sr, gp_u)
@@ -161,11 +164,14 @@ class Trainer:
         with torch.no_grad():          # D's parameters are frozen and hr needs no grad: a pure forward, as in the reference
             pred_real = D(hr_cl)
         loss_fn = self.f_loss_fn if self.use_focal else F.binary_cross_entropy_with_logits
-        if self.gan_type == "RaSGAN":
-            G_loss = rasgan_g_loss(pred_real, pred_fake, target_real, target_fake, loss_fn, self.world_size)
+        if fused:
+            G_loss = PF.gan_loss(pred_real, pred_fake, self.gan_type, 1, self.use_focal, self.f_loss_fn.gamma, self.alpha_gan)
         else:
-            G_loss = loss_fn(pred_fake if self.gan_type == "SGAN" else pred_fake - pred_real, target_real)
-        G_loss = G_loss * self.alpha_gan
+            if self.gan_type == "RaSGAN":
+                G_loss = rasgan_g_loss(pred_real, pred_fake, target_real, target_fake, loss_fn, self.world_size)
+            else:
+                G_loss = loss_fn(pred_fake if self.gan_type == "SGAN" else pred_fake - pred_real, target_real)
+            G_loss = G_loss * self.alpha_gan
         total_G_loss = l1_loss + vgg_loss + G_loss + tv_local * float(self.world_size)
         total_G_loss.backward()
         self.optim_G.step()

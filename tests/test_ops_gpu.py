@@ -257,3 +257,37 @@ def test_spectral_norm_kernels_vs_oracle(Co, Ci):
         ops.spectral_norm_bwd(g.cuda(), w_hat, ud, vd, sigma, dw_out=acc, accumulate=True)
         _close(acc.cpu(), wr.grad + 1.0, 5e-6, what="dw accumulate")
         u, v = ur, vr                              # carry the oracle's buffers into the next round
+
+
+@pytest.mark.parametrize("gan_type", ["SGAN", "RSGAN", "RaSGAN"])
+@pytest.mark.parametrize("side,focal,gamma", [(0, False, 1.0), (1, False, 1.0), (1, True, 1.0), (1, True, 2.0), (1, True, 0.0)])
+def test_gan_loss_kernel_vs_oracle(gan_type, side, focal, gamma):
+    """pesr_gan_loss_fwd_bwd - the discriminator / generator losses of reference train.py:210-213,244-253 with the reference's
+    FocalLoss (model/focal_loss.py:9-13, torch-0.4 gradient) - against the oracle's expressions (oracle/step.py) under
+    torch autograd on the CPU: value and the gradients w.r.t. both logit vectors, incl. saturated logits."""
+    from oracle import step as OS
+    from pesr_amd import ops
+    gen = torch.Generator().manual_seed(7)
+    B = 16
+    r = (torch.randn(B, 1, generator=gen) * 4).requires_grad_(True)
+    f = (torch.randn(B, 1, generator=gen) * 4).requires_grad_(True)
+    with torch.no_grad():
+        r[0] = 30.0; f[1] = -40.0; r[2] = -25.0
+    ones, zeros = torch.ones(B, 1), torch.zeros(B, 1)
+    bce = F.binary_cross_entropy_with_logits
+    lf = (lambda z, t: OS.focal_loss(z, t, gamma)) if focal else bce
+    if side == 0:
+        ref = {"SGAN": lambda: bce(r, ones) + bce(f, zeros), "RSGAN": lambda: bce(r - f, ones),
+               "RaSGAN": lambda: 0.5 * (bce(r - f.mean(), ones) + bce(f - r.mean(), zeros))}[gan_type]()
+    else:
+        ref = {"SGAN": lambda: lf(f, ones), "RSGAN": lambda: lf(f - r, ones),
+               "RaSGAN": lambda: 0.5 * (lf(r - f.mean(), zeros) + lf(f - r.mean(), ones))}[gan_type]()
+    (ref * 0.7).backward()
+    out, d_r, d_f = ops.gan_loss(r.detach().cuda(), f.detach().cuda(), gan_type, side, focal, gamma, 0.7)
+    assert float(out[0]) == pytest.approx(0.7 * float(ref), rel=2e-6, abs=1e-9)
+    gr = r.grad if r.grad is not None else torch.zeros_like(r)
+    _close(d_f.cpu(), f.grad, 5e-6, "d_fake")
+    if float(gr.abs().max()) > 0:
+        _close(d_r.cpu(), gr, 5e-6, "d_real")
+    else:
+        assert float(d_r.abs().max()) == 0.0
