@@ -23,7 +23,7 @@ timeout 600 python3 scripts/layer_times.py 2>&1 | grep -v amdgpu.ids > $O/layer_
 timeout 300 python3 scripts/linear_time.py 2>&1 | grep -v amdgpu.ids > $O/linear_time.txt
 timeout 300 python3 scripts/rgb_layer_time.py 2>&1 | grep -v amdgpu.ids > $O/rgb_layer_time.txt
 timeout 300 python3 scripts/host_profile.py 2>&1 | grep -v amdgpu.ids | head -40 > $O/host_profile.txt
-python3 scripts/summarize_profiles.py trace $(find $O/single -name "*kernel_trace.csv") 3 $O/kernel_trace_by_grid.csv 2
+python3 scripts/summarize_profiles.py trace $(find $O/single -name "*kernel_trace.csv") 6 $O/kernel_trace_by_grid.csv 2   # 2 warm-up + 3 timed + 3 host-enqueue steps
 python3 scripts/summarize_profiles.py pmc $O/k1_pmc_summary.csv $(find $O/pmc_* -name "*counter_collection.csv")
 python3 scripts/summarize_profiles.py pmc $O/hbm_pmc_summary.csv $(find $O/hbm_* -name "*counter_collection.csv")
 cp $(find $O/stats -name "*kernel_stats.csv") $O/kernel_stats.csv 2>/dev/null
