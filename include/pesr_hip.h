@@ -111,6 +111,21 @@ int pesr_conv3x3_wino4(const float* x, const float* w_packed, const float* bias,
                        int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in,
                        void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- OPTIONAL bf16-operand mode (never the default) ---------------------------------------------------------------
+ * Stride-1 3x3 conv (pad 1) on v_mfma_f32_16x16x32_bf16: same tensors (fp32 NHWC in HBM), same fused epilogue and PixelShuffle
+ * options as pesr_conv3x3_wino4, but BOTH operands of every product are rounded to bf16 (round to nearest even) and summed in
+ * fp32.  Not the reference's arithmetic (model/basic.py:4-7 runs nn.Conv2d in fp32): checked against its own oracle
+ * (oracle/ops.py conv3x3_bf16: the same rounding, float64 sums) with its own tolerance.  Cin % 32 == 0, Cout % 128 == 0
+ * (Cout % 512 == 0 [1024 with 256-channel n-tiles] with ps_out; Cin % 128 == 0 with ps_in).
+ * w_packed: 9 * Cin * Cout bf16 (2 bytes each) from pesr_pack_conv3x3_bf16 (mode 0 forward / mode 1 input gradient - then call
+ * with Cin / Cout of the gradient problem swapped).  pesr_conv3x3_bf16_score: per-mille of the kernel's 144-pixel tiles inside
+ * the image, 0 for unsupported shapes or fewer than 128 workgroups. */
+int pesr_conv3x3_bf16_score(int N, int H, int W, int Cin, int Cout);
+int pesr_pack_conv3x3_bf16(const float* w, void* w_packed, int Cout, int Cin, int mode, int ps, void* stream);
+int pesr_conv3x3_bf16(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask, float* y,
+                      int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in,
+                      void* stream);
+
 /* Forward 3x3 conv from a 3-channel input, stride 1 (reference `embed` model/pesr.py:23, Discriminator features.0
  * model/pesr.py:53, vgg19 features.0): x [N][H][W][3], w OIHW [Cout][3][3][3] (NOT packed), y [N][H][W][Cout]. */
 int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,

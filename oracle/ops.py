@@ -28,3 +28,25 @@ def pixel_shuffle(x, r=2):
 
 def pixel_unshuffle(x, r=2):
     return F.pixel_unshuffle(x, r)
+
+
+# ---- the OPTIONAL bf16-operand mode of the build (no counterpart in the reference, which is fp32 only) ---------------
+def round_bf16(t):
+    """Round to the nearest bfloat16 (ties to even), returned in t's dtype: what v_cvt_pk_bf16_f32 does to an MFMA operand."""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+def conv3x3_bf16(x, w, b=None):
+    """model/basic.py:4-7 `Conv` (stride 1) as the bf16 mode computes it: BOTH operands of every product rounded to bf16, the
+    products (exact in fp32) summed - here in float64, so the kernel is checked to fp32-accumulation accuracy - bias in fp32."""
+    y = F.conv2d(round_bf16(x).double(), round_bf16(w).double(), None, padding=1).float()
+    return y if b is None else y + b.view(1, -1, 1, 1)
+
+
+def conv3x3_bf16_grads(x, w, dy, need_bias=True):
+    """(dx, dw, db) of the bf16 mode: dx from round(dy) and round(w), dw from round(x) and round(dy), both summed in float64;
+    db = sum of the UN-rounded dy (the kernel adds it up in fp32 on the vector unit)."""
+    xr = round_bf16(x).double().requires_grad_(True)
+    wr = round_bf16(w).double().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=1).backward(round_bf16(dy).double())
+    return xr.grad.float(), wr.grad.float(), (dy.double().sum(dim=(0, 2, 3)).float() if need_bias else None)

@@ -34,12 +34,32 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
 }
 
 // Batched form: one launch packs many convs (all of a network's, right after its optimizer step).  desc[d] (8 int64):
-// {src ptr, dst ptr, O, I, mode, ps, R, Nn}; blockIdx.y = d.  mode 2 / 3: the Winograd packing of mode 0 / 1.
+// {src ptr, dst ptr, O, I, mode, ps, R, Nn}; blockIdx.y = d.  mode 2 / 3: the Winograd F(2,3) packing of mode 0 / 1, 4 / 5: F(4,3),
+// 7 / 8: bf16.
 __global__ void pack_conv3x3_batched_kernel(const long long* __restrict__ desc) {
     const long long* d = desc + (size_t)blockIdx.y * 8;
     const float* __restrict__ w = (const float*)d[0];
     float* __restrict__ out = (float*)d[1];
     const int O = (int)d[2], I = (int)d[3], mode = (int)d[4], ps = (int)d[5], R = (int)d[6], Nn = (int)d[7];
+    if (mode >= 7) {   // bf16 packing (conv3x3_bf16.hip): mode 7 = forward, 8 = dgrad; out[t][c][n][k], 32-channel chunks
+        const int m = mode - 7;
+        const int Rr = m == 0 ? I : O, Nr = m == 0 ? O : I;
+        __bf16* const ob = (__bf16*)out;
+        const long total_b = 9L * Rr * Nr;
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total_b; e += (long)gridDim.x * blockDim.x) {
+            const int k = (int)(e & 31);
+            long rest = e >> 5;
+            const int n = (int)(rest % Nr); rest /= Nr;
+            const int c = (int)(rest % (Rr >> 5));
+            const int t = (int)(rest / (Rr >> 5));
+            const int red = c * 32 + k;
+            int o = m == 0 ? n : red;
+            const int i = m == 0 ? red : n;
+            if (ps) { const int C = O >> 2; const int sub = o / C, cc = o - sub * C; o = 4 * cc + sub; }
+            ob[e] = (__bf16)w[((long)o * I + i) * 9 + (m == 0 ? t : 8 - t)];
+        }
+        return;
+    }
     if (mode >= 4) {   // Winograd F(4,3) packing (conv3x3_wino4.hip): mode 4 = forward, 5 = dgrad
         // One thread per (n, k) of a 16 x 16 tile of (output row n, reduction channel 16c + k): it reads the nine taps of its
         // (o, i) pair once (36 contiguous bytes; a tile row is 576 contiguous bytes) and writes all 18 transformed values, each

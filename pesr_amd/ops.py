@@ -106,6 +106,8 @@ FLOPS = _FlopCount()
 
 
 def _conv_family(wp):
+    if isinstance(wp, Bf16Packed):
+        return 1.0, "bf16"
     if isinstance(wp, Wino4Packed):
         return 0.5, "F(4,3)"
     if isinstance(wp, WinoPacked):
@@ -237,9 +239,60 @@ def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacke
     return WinoPacked(out)
 
 
+# ---- the OPTIONAL bf16-operand mode --------------------------------------------------------------------------------
+# PRECISION = "bf16" (set_precision / PESR_PRECISION / train.py --precision): the stride-1 convs with 32-multiple input and
+# 128-multiple output channels run on v_mfma_f32_16x16x32_bf16 - operands rounded to bf16, fp32 accumulation, fp32 tensors in HBM.
+# Everything else (and everything by default) stays on the fp32 kernels.
+PRECISION = __import__("os").environ.get("PESR_PRECISION", "fp32")
+_B16_SCORE = {}
+
+
+def set_precision(p: str) -> None:
+    global PRECISION
+    if p not in ("fp32", "bf16"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}")
+    PRECISION = p
+
+
+class Bf16Packed:
+    """Weights rounded to bf16 and packed for conv3x3_bf16_kernel (pesr_pack_conv3x3_bf16)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
+def bf16_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps_out: bool = False, ps_in: bool = False) -> bool:
+    """PRECISION is "bf16" and the bf16 kernel covers the shape with at least 78 % of its tile area inside the image.
+    Cin / Cout are those of the problem the kernel runs."""
+    if PRECISION != "bf16" or stride != 1 or Cin % 32 or Cout % 128 or (ps_out and Cout % 1024) or (ps_in and Cin % 128):
+        return False
+    key = (N, H, W, Cin, Cout)
+    sc = _B16_SCORE.get(key)
+    if sc is None:
+        sc = _B16_SCORE[key] = _lib.lib().pesr_conv3x3_bf16_score(N, H, W, Cin, Cout)
+    return sc >= 780
+
+
+def pack_conv3x3_bf16(w: torch.Tensor, mode: int, ps: bool = False) -> Bf16Packed:
+    """OIHW [O, I, 3, 3] fp32 -> [9, R/32, Nn, 32] bf16 (mode 0: forward, mode 1: dgrad with flipped taps; ps: sub-pixel-major O)."""
+    _chk(w, "pack_conv3x3_bf16.w")
+    O, I = w.shape[0], w.shape[1]
+    out = torch.empty(9 * O * I, dtype=torch.bfloat16, device=w.device)
+    rc = _lib.lib().pesr_pack_conv3x3_bf16(_p(w), _p(out), O, I, mode, int(ps), _stream())
+    _lib.check(rc, f"pesr_pack_conv3x3_bf16[{O}x{I},mode{mode}]")
+    return Bf16Packed(out)
+
+
 def _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, what, ps_out=False, ps_in=False):
-    """Both Winograd kernels (WinoPacked -> F(2,3), Wino4Packed -> F(4,3)): same arguments, same fused epilogue."""
+    """Both Winograd kernels (WinoPacked -> F(2,3), Wino4Packed -> F(4,3)) and the bf16 kernel (Bf16Packed): same arguments,
+    same fused epilogue."""
     L = _lib.lib()
+    if isinstance(wp, Bf16Packed):
+        rc = L.pesr_conv3x3_bf16(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope,
+                                 int(ps_out), int(ps_in), _stream())
+        _lib.check(rc, f"pesr_conv3x3_bf16[{what} {N}x{H}x{W}x{Cin}->{cout}]")
+        return
     nws = L.pesr_conv3x3_workspace_bytes(N, H, W, cout) if not ps_out else 0     # split-K scratch for layers with few tiles
     ws = workspace(nws, x.device) if nws else None
     four = isinstance(wp, Wino4Packed)
@@ -292,7 +345,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         FLOPS.add(18.0 * N * OH * OW * Cin * cout, *_conv_family(wp))
     br = KERNEL_EVENTS.begin("fwd", N, H, W, Cin, cout, stride)
     L = _lib.lib()
-    if isinstance(wp, (WinoPacked, Wino4Packed)):
+    if isinstance(wp, (WinoPacked, Wino4Packed, Bf16Packed)):
         assert stride == 1
         _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, "fwd", ps_out=ps_out)
         rc = 0
@@ -322,7 +375,7 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
     if FLOPS.on:
         FLOPS.add(18.0 * N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * Cin * cout, *_conv_family(wpd))
     br = KERNEL_EVENTS.begin("dgrad", N, H, W, Cin, cout, stride)
-    if isinstance(wpd, (WinoPacked, Wino4Packed)):     # the input gradient is the conv of dy with the flipped, transposed kernel
+    if isinstance(wpd, (WinoPacked, Wino4Packed, Bf16Packed)):     # the input gradient is the conv of dy with the flipped, transposed kernel
         assert stride == 1
         _conv3x3_wino(dy, wpd, None, skip, mask, dx, N, H, W, cout, Cin, alpha, ACT_NONE, 0.0, "dgrad", ps_in=ps_in)
         KERNEL_EVENTS.end(br)
