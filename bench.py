@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32-input MFMA
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (the denominator of the optional --precision bf16 row)
 GFLOP_PER_PATCH = {"gan": 844.10, "pretrain": 694.69}   # SURVEY.md 8(d), necessary work per HR patch
 K1_GFLOP = 2.0 * 16 * 48 * 48 * 256 * 256 * 9 / 1e9     # body conv 256->256 @48x48, batch 16: 43.487 GFLOP per launch
 
@@ -138,7 +139,9 @@ def cpu_baseline(args, state, batch):
     cfg = {"depth": args.num_blocks, "res_scale": 0.1, "learning_rate": args.lr}
     st = OS.TrainState(g_sd, d_sd, v_sd, cfg)
     step = OS.gan_step if args.workload == "gan" else OS.pretrain_step
-    first = step(st, lr, hr)                       # warm-up = parity step
+    from oracle import bf16 as OB
+    with OB.enabled(args.precision == "bf16"):     # (bf16 row: the parity step restates the bf16 mode; the timed steps below are
+        first = step(st, lr, hr)                   #  the reference's fp32 arithmetic either way)  warm-up = parity step
     times = []
     for _ in range(args.cpu_steps):
         t0 = time.perf_counter()
@@ -212,6 +215,9 @@ def main():
                     help="capture the step into a hipGraph after the warm-up and time replays (bit-identical results; with N > 1 the "
                          "RCCL all-reduces are captured with it; the roofline kernel events are then taken from two extra eager steps "
                          "outside the timed region)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 (default, the headline): the reference's arithmetic.  bf16: the OPTIONAL bf16-operand mode (SURVEY 8 f4) - "
+                         "a separate row with its own oracle, tolerance and 2.5 PFLOP/s roofline denominator")
     ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--lr", type=float, default=5e-7,
                     help="Adam learning rate of both optimizers.  The reference's 5e-5 (SURVEY 8d) lets the Discriminator separate "
@@ -243,6 +249,7 @@ def main():
             raise SystemExit(f"bench.py --gpus {args.gpus}: the RCCL group spans {n_seen} rank(s)")
 
     from pesr_amd import ops
+    ops.set_precision(args.precision)
     if args.workload == "infer512":
         return bench_infer512(args, device)
     trainer, G, D, vgg = build(args, device, world)
@@ -324,11 +331,16 @@ def main():
     global_batch = args.batch * world
     value = args.steps * global_batch / elapsed
     flop_patch = GFLOP_PER_PATCH[args.workload] * 1e9
+    bf16 = args.precision == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     out = {
-        "metric": "HR-patches/sec (x4 SR GAN train step, 48->192)",
+        "metric": "HR-patches/sec (x4 SR GAN train step, 48->192)" + (" [OPTIONAL bf16-operand mode, not the headline]" if bf16 else ""),
         "value": round(value, 3), "unit": "patches/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "data": "synthetic",
+        "dtype": ("bf16 operands / f32 accumulation in the 3x3 convs the bf16 kernels cover (G body, upsamplers, the larger D / VGG layers); "
+                  "f32 tensors, optimizer and every other op") if bf16 else "f32",
+        "precision": args.precision,
         "config": {"workload": ("full GAN phase (G + D + VGG + RSGAN focal loss), " if args.workload == "gan"
                                 else "pretrain phase (L1 only), ") +
                                f"per-GPU batch {args.batch}, LR {args.patch_size}x{args.patch_size} -> HR "
@@ -336,10 +348,11 @@ def main():
                    "global_batch": global_batch, "parallelism": f"dp{world}"},
         "step_tflops_per_gpu": round(value / world * flop_patch / 1e12, 2),
         # ALGORITHMIC flops / time / peak: may exceed 1 because the Winograd kernels issue 1/2 .. 2/3 of them
-        "step_frac_of_mfma_peak": round(value / world * flop_patch / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+        "step_frac_of_mfma_peak": round(value / world * flop_patch / (peak * 1e12), 4),
+        "mfma_peak_tflops": peak,
         # flops the step's kernels really ISSUE on the matrix pipe (tallied per launch during step 0) / time / peak: the honest
         # whole-step hardware fraction
-        "step_issued_frac": round(flops["issued"] / (1e3 * elapsed / args.steps) / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+        "step_issued_frac": round(flops["issued"] / (1e3 * elapsed / args.steps) / 1e9 / peak, 4),
         "step_flops": {"algorithmic_tflop_counted": round(flops["algorithmic"] / 1e12, 3), "issued_tflop": round(flops["issued"] / 1e12, 3),
                        "by_kernel_family_tflop": {k: [round(a / 1e12, 3), round(b / 1e12, 3)] for k, (a, b) in flops["by_kernel_family"].items()},
                        "note": "per family: [algorithmic, issued on the matrix pipe]; counted from the launches of step 0"},
@@ -367,9 +380,10 @@ def main():
         got0 = first_log
         rel = {k: abs(got0[k] - ref0[k]) / max(abs(ref0[k]), 1e-12) for k in ref0 if abs(ref0[k]) > 0 or abs(got0[k]) > 0}
         worst = max(rel.values()) if rel else 0.0
+        ptol = 5e-4 if bf16 else 5e-5      # bf16 row: against the oracle's restatement of the bf16 mode (oracle/bf16.py)
         out["parity_check"] = {"what": "losses of GPU step 0 vs the CPU oracle's step from the same initial weights and batch "
                                        "(benchmarked configuration and kernel dispatch)",
-                               "max_rel_loss_err": worst, "tol": 5e-5, "ok": bool(worst <= 5e-5),
+                               "max_rel_loss_err": worst, "tol": ptol, "ok": bool(worst <= ptol),
                                "gpu": got0, "cpu_oracle": ref0}
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
@@ -385,7 +399,11 @@ def roofline_objects(args, kern):
     scale = (args.batch / 16) * (args.patch_size / 48) ** 2 * (args.num_channels / 256) ** 2
     bs = (args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels)
     # (kernel name, fraction of the conv's algorithmic flops the kernel issues on the matrix pipe)
-    if _ops.wino4_eligible(*bs):
+    bf16 = getattr(args, "precision", "fp32") == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    if _ops.bf16_eligible(*bs):
+        conv_k = ("conv3x3_bf16_kernel", 1.0)
+    elif _ops.wino4_eligible(*bs):
         conv_k = ("conv3x3_wino4_kernel", 0.5)
     elif _ops.wino_eligible(*bs):
         conv_k = ("conv3x3_wino_kernel", 2.0 / 3.0)
@@ -394,6 +412,8 @@ def roofline_objects(args, kern):
     wg_wino = _ops.USE_WGRAD_WINO and args.patch_size % 2 == 0 and args.patch_size >= 48 and args.num_channels % 64 == 0
     wg_k = _ops.wgrad_kernel_for(*bs) if hasattr(_ops, "wgrad_kernel_for") else \
         (("conv3x3_wgrad_wino_kernel", 2.0 / 3.0) if wg_wino else ("conv3x3_wgrad_kernel", 1.0))
+    if _ops.wgrad_bf16_eligible(*bs):
+        wg_k = ("conv3x3_wgrad_bf16_kernel", 1.0)
     shape = f"G body {args.num_channels}->{args.num_channels} @{args.patch_size}x{args.patch_size}, batch {args.batch}"
     names = {"fwd": conv_k + (f"forward ({shape}: 65 G launches + the 6 same-shaped VGG conv3_2..3_4 launches per GAN step)",),
              "dgrad": conv_k + (f"input gradient ({shape}: 65 G + 3 VGG launches per GAN step)",),
@@ -404,9 +424,9 @@ def roofline_objects(args, kern):
         ach = K1_GFLOP * scale / ms                                  # algorithmic TFLOP/s
         issued = ach * issue_frac
         traffic, src = k1_hbm_traffic_bytes(kname)
-        o = {"kernel": f"{kname} {label}", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-             "unit": "TFLOP/s", "frac": round(issued / PEAK_F32_MFMA_TFLOPS, 4),
-             "algorithmic_frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "issued_tflops": round(issued, 2),
+        o = {"kernel": f"{kname} {label}", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+             "unit": "TFLOP/s", "frac": round(issued / peak, 4),
+             "algorithmic_frac": round(ach / peak, 4), "issued_tflops": round(issued, 2),
              "traffic": traffic,
              "traffic_note": (f"HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes in profiles/{src}"
                               if src else "no committed PMC summary found"),

@@ -119,12 +119,19 @@ int pesr_conv3x3_wino4(const float* x, const float* w_packed, const float* bias,
  * (Cout % 512 == 0 [1024 with 256-channel n-tiles] with ps_out; Cin % 128 == 0 with ps_in).
  * w_packed: 9 * Cin * Cout bf16 (2 bytes each) from pesr_pack_conv3x3_bf16 (mode 0 forward / mode 1 input gradient - then call
  * with Cin / Cout of the gradient problem swapped).  pesr_conv3x3_bf16_score: per-mille of the kernel's 144-pixel tiles inside
- * the image, 0 for unsupported shapes or fewer than 128 workgroups. */
-int pesr_conv3x3_bf16_score(int N, int H, int W, int Cin, int Cout);
+ * the image, 0 for unsupported shapes or fewer than min_wgs workgroups (the host-side dispatch passes 128). */
+int pesr_conv3x3_bf16_score(int N, int H, int W, int Cin, int Cout, int min_wgs);
 int pesr_pack_conv3x3_bf16(const float* w, void* w_packed, int Cout, int Cin, int mode, int ps, void* stream);
 int pesr_conv3x3_bf16(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask, float* y,
                       int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in,
                       void* stream);
+/* Weight / bias gradient of the same conv in the bf16 mode: dw = alpha * sum bf16(dy) * bf16(x) (fp32 sums; fixed-order split-K
+ * reduce, bit-reproducible), db = alpha * sum dy (fp32, un-rounded).  Same tensors and ps_in / accumulate meaning as
+ * pesr_conv3x3_wgrad.  Stride 1, W % 48 == 0, Cin % 64 == 0, Cout % 128 == 0 (Cout % 512 == 0 with ps_in); workspace_bytes
+ * returns 0 for shapes it does not cover. */
+size_t pesr_conv3x3_wgrad_bf16_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int pesr_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                            float alpha, int ps_in, int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
 /* Forward 3x3 conv from a 3-channel input, stride 1 (reference `embed` model/pesr.py:23, Discriminator features.0
  * model/pesr.py:53, vgg19 features.0): x [N][H][W][3], w OIHW [Cout][3][3][3] (NOT packed), y [N][H][W][Cout]. */

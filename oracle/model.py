@@ -115,23 +115,33 @@ def set_meanshift(sd, which):
 # ------------------------------------------------------------------------------------------------
 # forwards
 # ------------------------------------------------------------------------------------------------
+def _conv3(x, w, b, stride=1, ps=False):
+    """nn.Conv2d(k=3, padding=1) of model/basic.py:4-7.  (With oracle.bf16.enabled() - the build's optional bf16 mode, no
+    counterpart in the reference - the convs that mode covers round their operands to bf16; `ps` marks the convs in front of
+    nn.PixelShuffle, whose fused kernels have their own shape rules.)"""
+    from . import bf16
+    if bf16.ON:
+        return bf16.conv3x3(x, w, b, stride, ps)
+    return F.conv2d(x, w, b, stride=stride, padding=1)
+
+
 def generator_forward(sd, x, depth, res_scale):
     """model/pesr.py:28-38 with ResBlock model/basic.py:48-52 and Upsampler model/basic.py:54-60."""
     x = F.conv2d(x, sd["sub_mean.weight"], sd["sub_mean.bias"])
-    x = F.conv2d(x, sd["embed.weight"], sd["embed.bias"], padding=1)
+    x = _conv3(x, sd["embed.weight"], sd["embed.bias"])
     h = x
     for i in range(depth):
-        r = F.conv2d(h, sd[f"body.{i}.body.0.weight"], sd[f"body.{i}.body.0.bias"], padding=1)
+        r = _conv3(h, sd[f"body.{i}.body.0.weight"], sd[f"body.{i}.body.0.bias"])
         r = F.relu(r)
-        r = F.conv2d(r, sd[f"body.{i}.body.2.weight"], sd[f"body.{i}.body.2.bias"], padding=1)
+        r = _conv3(r, sd[f"body.{i}.body.2.weight"], sd[f"body.{i}.body.2.bias"])
         h = r.mul(res_scale) + h                     # basic.py:49-50
-    h = F.conv2d(h, sd[f"body.{depth}.weight"], sd[f"body.{depth}.bias"], padding=1)
+    h = _conv3(h, sd[f"body.{depth}.weight"], sd[f"body.{depth}.bias"])
     h = h + x                                        # pesr.py:33
-    h = F.conv2d(h, sd["upsample.0.weight"], sd["upsample.0.bias"], padding=1)
+    h = _conv3(h, sd["upsample.0.weight"], sd["upsample.0.bias"], ps=True)
     h = F.pixel_shuffle(h, 2)
-    h = F.conv2d(h, sd["upsample.2.weight"], sd["upsample.2.bias"], padding=1)
+    h = _conv3(h, sd["upsample.2.weight"], sd["upsample.2.bias"], ps=True)
     h = F.pixel_shuffle(h, 2)
-    h = F.conv2d(h, sd["upsample.4.weight"], sd["upsample.4.bias"], padding=1)
+    h = _conv3(h, sd["upsample.4.weight"], sd["upsample.4.bias"])
     return F.conv2d(h, sd["add_mean.weight"], sd["add_mean.bias"])
 
 
@@ -160,7 +170,7 @@ def discriminator_forward(sd, x, update_running_stats=True):
             w = spectral_normalize(sd[f"features.{i}.0.weight_orig"], sd[f"features.{i}.0.weight_u"], sd[f"features.{i}.0.weight_v"], True)
         else:
             w = sd[f"features.{i}.0.weight"]
-        h = F.conv2d(h, w, None, stride=stride, padding=1)
+        h = _conv3(h, w, None, stride=stride)
         rm, rv = sd[f"features.{i}.1.running_mean"], sd[f"features.{i}.1.running_var"]
         if update_running_stats:
             h = F.batch_norm(h, rm, rv, sd[f"features.{i}.1.weight"], sd[f"features.{i}.1.bias"], True, 0.1, 1e-5)
@@ -184,7 +194,7 @@ def vgg_features(sd, x):
             h = F.max_pool2d(h, 2, 2)
             idx += 1
         else:
-            h = F.conv2d(h, sd[f"vgg.{idx}.weight"], sd[f"vgg.{idx}.bias"], padding=1)
+            h = _conv3(h, sd[f"vgg.{idx}.weight"], sd[f"vgg.{idx}.bias"])
             idx += 1
             if idx < 35:
                 h = F.relu(h)

@@ -197,7 +197,9 @@ PESR_API int pesr_conv3x3_wino4(const float* x, const float* w_packed, const flo
                                      workspace, ws_bytes, (hipStream_t)stream);
 }
 
-PESR_API int pesr_conv3x3_bf16_score(int N, int H, int W, int Cin, int Cout) { return pesr_conv3x3_bf16_score_impl(N, H, W, Cin, Cout); }
+PESR_API int pesr_conv3x3_bf16_score(int N, int H, int W, int Cin, int Cout, int min_wgs) {
+    return pesr_conv3x3_bf16_score_impl(N, H, W, Cin, Cout, min_wgs);
+}
 PESR_API int pesr_pack_conv3x3_bf16(const float* w, void* w_packed, int Cout, int Cin, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_bf16_launch(w, w_packed, Cout, Cin, mode, ps, (hipStream_t)stream);
 }
@@ -206,6 +208,14 @@ PESR_API int pesr_conv3x3_bf16(const float* x, const void* w_packed, const float
                                int ps_in, void* stream) {
     return pesr_conv3x3_bf16_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, ps_out, ps_in,
                                     (hipStream_t)stream);
+}
+PESR_API size_t pesr_conv3x3_wgrad_bf16_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    return pesr_conv3x3_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout);
+}
+PESR_API int pesr_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                                     float alpha, int ps_in, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_conv3x3_wgrad_bf16_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, accumulate, workspace, ws_bytes,
+                                          (hipStream_t)stream);
 }
 
 PESR_API int pesr_crop_augment(const unsigned char* pool, const long long* desc, float* out, int B, int P, int nhwc, void* stream) {

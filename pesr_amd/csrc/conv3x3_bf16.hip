@@ -279,7 +279,7 @@ namespace {
 struct B16Plan { int TR, TW, HT, WT, tiles_x, tiles_y, n_tiles, ntw; long tiles; size_t lds; int score; };
 
 // Tile shape TR x TW == 144 pixels with the least out-of-image area whose halo fits the four staging items per thread.
-static bool b16_plan(int N, int H, int W, int Cin, int Cout, B16Plan* p) {
+static bool b16_plan(int N, int H, int W, int Cin, int Cout, B16Plan* p, int min_wgs = 128) {
     if (N < 1 || H < 1 || W < 1 || Cin % 32 || Cin < 32 || Cout % 128) return false;
     if ((size_t)H * W * Cin * 4 >= ((size_t)1 << 31)) return false;   // one image per buffer descriptor, offsets below 2^31
     long best = -1;
@@ -299,15 +299,15 @@ static bool b16_plan(int N, int H, int W, int Cin, int Cout, B16Plan* p) {
     p->tiles = (long)N * p->tiles_y * p->tiles_x * p->n_tiles;
     p->lds = (size_t)2 * (p->HT * p->WT + 1) * B16_PX;
     const double cover_eff = (double)H * W / ((double)p->tiles_y * p->TR * p->tiles_x * p->TW);
-    p->score = p->tiles >= 128 ? (int)(1000.0 * cover_eff) : 0;
+    p->score = p->tiles >= min_wgs ? (int)(1000.0 * cover_eff) : 0;
     return true;
 }
 }  // namespace
 
-// per-mille of tile area inside the image (0: unsupported shape or too few workgroups to be worth leaving the fp32 kernels)
-int pesr_conv3x3_bf16_score_impl(int N, int H, int W, int Cin, int Cout) {
+// per-mille of tile area inside the image (0: unsupported shape, or fewer than min_wgs workgroups: not worth leaving the fp32 kernels)
+int pesr_conv3x3_bf16_score_impl(int N, int H, int W, int Cin, int Cout, int min_wgs) {
     B16Plan p;
-    if (!b16_plan(N, H, W, Cin, Cout, &p)) return 0;
+    if (!b16_plan(N, H, W, Cin, Cout, &p, min_wgs)) return 0;
     return p.score;
 }
 

@@ -90,11 +90,14 @@ int pesr_conv3x3_wino_launch(const float* x, const float* wp, const float* bias,
                              int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
                              void* ws, size_t ws_bytes, hipStream_t stream);
 // bf16-operand mode (conv3x3_bf16.hip, conv3x3_wgrad_bf16.hip): operands rounded to bf16, fp32 accumulation
-int pesr_conv3x3_bf16_score_impl(int N, int H, int W, int Cin, int Cout);
+int pesr_conv3x3_bf16_score_impl(int N, int H, int W, int Cin, int Cout, int min_wgs);
 int pesr_pack_conv3x3_bf16_launch(const float* w, void* out, int O, int I, int mode, int ps, hipStream_t stream);
 int pesr_conv3x3_bf16_launch(const float* x, const void* wp, const float* bias, const float* skip, const float* mask, float* y,
                              int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
                              hipStream_t stream);
+size_t pesr_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int pesr_conv3x3_wgrad_bf16_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                                   float alpha, int ps_in, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // 1-D Winograd F(4,3) variant (conv3x3_wino4.hip): half of the direct conv's multiplies
 int pesr_conv3x3_wino4_score_impl(int N, int H, int W, int Cin, int Cout, int allow_split);

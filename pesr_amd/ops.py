@@ -245,6 +245,7 @@ def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacke
 # Everything else (and everything by default) stays on the fp32 kernels.
 PRECISION = __import__("os").environ.get("PESR_PRECISION", "fp32")
 _B16_SCORE = {}
+BF16_MIN_WGS = 128        # layers whose bf16 launch would have fewer workgroups stay on the fp32 kernels (tests lower it)
 
 
 def set_precision(p: str) -> None:
@@ -267,10 +268,10 @@ def bf16_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, 
     Cin / Cout are those of the problem the kernel runs."""
     if PRECISION != "bf16" or stride != 1 or Cin % 32 or Cout % 128 or (ps_out and Cout % 1024) or (ps_in and Cin % 128):
         return False
-    key = (N, H, W, Cin, Cout)
+    key = (N, H, W, Cin, Cout, BF16_MIN_WGS)
     sc = _B16_SCORE.get(key)
     if sc is None:
-        sc = _B16_SCORE[key] = _lib.lib().pesr_conv3x3_bf16_score(N, H, W, Cin, Cout)
+        sc = _B16_SCORE[key] = _lib.lib().pesr_conv3x3_bf16_score(N, H, W, Cin, Cout, BF16_MIN_WGS)
     return sc >= 780
 
 
@@ -414,6 +415,39 @@ WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23, WGRAD_WINO4_16X16 = 0, 1, 2, 3      # in
 USE_WGRAD_WINO4_16X16 = __import__("os").environ.get("PESR_WGRAD_WINO4_16X16", "0") == "1"
 
 
+def wgrad_bf16_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps_in: bool = False) -> bool:
+    """PRECISION is "bf16" and the bf16 weight-gradient kernel covers the shape (and has at least ~one round of workgroups)."""
+    if PRECISION != "bf16" or stride != 1 or W % 48 or Cin % 64 or Cout % 128 or (ps_in and Cout % 512):
+        return False
+    if _lib.lib().pesr_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, Cin, Cout) == 0:
+        return False
+    return N * ((H + 1) // 2) * (W // 48) >= (96 if BF16_MIN_WGS >= 128 else 1)
+
+
+def conv3x3_wgrad_bf16(x: torch.Tensor, dy: torch.Tensor, alpha: float = 1.0, want_bias: bool = True, ps_in: bool = False,
+                       dw_out=None, db_out=None, accumulate: bool = False):
+    """(dw, db) on the bf16 MFMA: operands rounded to bf16, fp32 sums; db from the un-rounded dy."""
+    assert not accumulate or (dw_out is not None and (db_out is not None or not want_bias))
+    _chk(x, "conv3x3_wgrad_bf16.x"); _chk(dy, "conv3x3_wgrad_bf16.dy")
+    N, H, W, Cin = x.shape
+    cout = dy.shape[3] * (4 if ps_in else 1)
+    L = _lib.lib()
+    nbytes = L.pesr_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, Cin, cout)
+    if nbytes == 0:
+        raise _lib.PesrHipError(f"pesr_conv3x3_wgrad_bf16: unsupported shape {N}x{H}x{W} Cin={Cin} Cout={cout}")
+    ws = workspace(nbytes, x.device)
+    dw = _out(dw_out, (cout, Cin, 3, 3), x.device)
+    db = _out(db_out, (cout,), x.device) if want_bias else None
+    if FLOPS.on:
+        FLOPS.add(18.0 * N * H * W * Cin * cout, 1.0, "bf16")
+    br = KERNEL_EVENTS.begin("wgrad", N, H, W, Cin, cout, 1)
+    rc = L.pesr_conv3x3_wgrad_bf16(_p(x), _p(dy), _p(dw), _p(db), N, H, W, Cin, cout, alpha, int(ps_in), int(accumulate), _p(ws),
+                                   ws.numel(), _stream())
+    KERNEL_EVENTS.end(br)
+    _lib.check(rc, f"pesr_conv3x3_wgrad_bf16[{N}x{H}x{W}x{Cin}->{cout}]")
+    return dw, db
+
+
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: float = 1.0, want_bias: bool = True,
                   ps_in: bool = False, dw_out=None, db_out=None, algo=None, accumulate: bool = False):
     """(dw [O, I, 3, 3], db [O] | None).  algo: None = by the PESR_* switches (default: auto = F(4,3) where it applies, else
@@ -424,6 +458,8 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
     _chk(dy, "conv3x3_wgrad.dy")
     N, H, W, Cin = x.shape
     cout = dy.shape[3] * (4 if ps_in else 1)
+    if algo is None and wgrad_bf16_eligible(N, H, W, Cin, cout, stride, ps_in):
+        return conv3x3_wgrad_bf16(x, dy, alpha, want_bias, ps_in, dw_out, db_out, accumulate)
     L = _lib.lib()
     if algo is None:
         algo = ((WGRAD_WINO4_16X16 if USE_WGRAD_WINO4_16X16 else WGRAD_AUTO) if (USE_WINO4 and USE_WGRAD_WINO4) else 2) if USE_WGRAD_WINO else 1

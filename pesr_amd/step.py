@@ -78,6 +78,10 @@ class Trainer:
         self.alpha_vgg, self.alpha_gan, self.alpha_tv, self.alpha_l1 = alpha_vgg, alpha_gan, alpha_tv, alpha_l1
         self.world_size = world_size
         self.gradient_penalty = gradient_penalty       # reference --GP (train.py:216-226), default off
+        from . import ops
+        if gradient_penalty and ops.PRECISION != "fp32":
+            raise ValueError("the gradient penalty (--GP true) is only built for the fp32 arithmetic: the optional bf16 mode has "
+                             "no second-order oracle (use --precision fp32)")
         self._targets = {}
         self._graph = None
 

@@ -54,6 +54,26 @@ def main():
         print(f"dgrad+mask+skip body {name}: {med:7.1f} us (min {mn:7.1f})", flush=True)
 
 
+def wgrad_part():
+    from pesr_amd import ops
+    for N, H, W, Cin, Cout, ps in [(16, 48, 48, 256, 256, False), (16, 48, 48, 256, 1024, True), (16, 96, 96, 256, 1024, True), (16, 96, 96, 128, 128, False)]:
+        xs = [torch.randn(N, H, W, Cin, device="cuda") for _ in range(3)]
+        dys = [torch.randn(N, 2 * H, 2 * W, Cout // 4, device="cuda") if ps else torch.randn(N, H, W, Cout, device="cuda") for _ in range(3)]
+        flops = 18.0 * N * H * W * Cin * Cout
+        res = []
+        i = [0]
+        def f32():
+            i[0] += 1
+            ops.conv3x3_wgrad(xs[i[0] % 3], dys[i[0] % 3], 1, ps_in=ps, algo=ops.WGRAD_AUTO)
+        def b16():
+            i[0] += 1
+            ops.conv3x3_wgrad_bf16(xs[i[0] % 3], dys[i[0] % 3], ps_in=ps)
+        for name, f in (("fp32 F(4,3)", f32), ("bf16", b16)):
+            med, mn = timed(f)
+            res.append(f"{name}: {med:7.1f} us (min {mn:7.1f}) {flops / med / 1e6:7.1f} TF/s")
+        print(f"wgrad {N}x{H}x{W} {Cin}->{Cout}{' ps' if ps else ''}:  " + "  |  ".join(res), flush=True)
+
+
 if __name__ == "__main__":
     libs = sys.argv[1:] or [None]
     for lib in libs:
@@ -65,3 +85,4 @@ if __name__ == "__main__":
             subprocess.run([sys.executable, __file__], env=dict(os.environ), check=False)
         else:
             main()
+            wgrad_part()

@@ -73,3 +73,142 @@ def test_conv3x3_bf16_pixel_shuffle_fused():
     dx_ref, _, _ = O.conv3x3_bf16_grads(x, w, F.pixel_unshuffle(dys, 2))
     dx = ops.conv3x3_dgrad(_nhwc(dys), ops.pack_conv3x3_bf16(w.cuda(), 1, ps=True), (N, H, W, C), ps_in=True)
     _close(_nchw(dx), dx_ref, 1e-5)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 48, 48, 256, 256), (1, 5, 48, 64, 128), (2, 7, 96, 64, 128), (1, 12, 48, 128, 384),
+                                             (3, 2, 144, 64, 128)])
+def test_conv3x3_wgrad_bf16_kernel(N, H, W, Cin, Cout):
+    """Weight + bias gradient on the bf16 kernel (transposed LDS reads) against its oracle, overwrite and accumulate forms;
+    bit-reproducible (fixed-order split-K reduce)."""
+    from pesr_amd import ops
+    x = _rand(N, Cin, H, W, seed=900); w = _rand(Cout, Cin, 3, 3, seed=910, scale=0.1); dy = _rand(N, Cout, H, W, seed=920)
+    _, dw_ref, db_ref = O.conv3x3_bf16_grads(x, w, dy)
+    dw, db = ops.conv3x3_wgrad_bf16(_nhwc(x), _nhwc(dy), alpha=0.5)
+    _close(dw.cpu(), 0.5 * dw_ref, 1e-5); _close(db.cpu(), 0.5 * db_ref, 1e-5)
+    _, dw32, _ = O.conv3x3_grads(x, w, dy)
+    _close(dw.cpu(), 0.5 * dw32, 1e-2)                                  # and it IS the weight gradient, to bf16-operand accuracy
+    dw2, db2 = ops.conv3x3_wgrad_bf16(_nhwc(x), _nhwc(dy), alpha=0.5)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    ops.conv3x3_wgrad_bf16(_nhwc(x), _nhwc(dy), alpha=0.5, dw_out=dw2, db_out=db2, accumulate=True)
+    _close(dw2.cpu(), dw_ref, 1e-5); _close(db2.cpu(), db_ref, 1e-5)
+
+
+def test_conv3x3_wgrad_bf16_pixel_shuffle_fused():
+    """Weight gradient of an upsampler conv (its output gradient arrives pixel-shuffled) on the bf16 kernel."""
+    import torch.nn.functional as F
+    from pesr_amd import ops
+    N, H, W, C = 2, 6, 48, 128
+    x = _rand(N, C, H, W, seed=1); w = _rand(4 * C, C, 3, 3, seed=2, scale=0.1)
+    dys = _rand(N, C, 2 * H, 2 * W, seed=4)
+    _, dw_ref, db_ref = O.conv3x3_bf16_grads(x, w, F.pixel_unshuffle(dys, 2))
+    dw, db = ops.conv3x3_wgrad_bf16(_nhwc(x), _nhwc(dys), ps_in=True)
+    _close(dw.cpu(), dw_ref, 1e-5); _close(db.cpu(), db_ref, 1e-5)
+
+
+@pytest.fixture
+def bf16_mode():
+    """ops.PRECISION = "bf16" with the workgroup-count floor lowered, so that the small test networks take the bf16 kernels."""
+    from pesr_amd import ops
+    old = (ops.PRECISION, ops.BF16_MIN_WGS)
+    ops.set_precision("bf16"); ops.BF16_MIN_WGS = 1
+    yield
+    ops.PRECISION, ops.BF16_MIN_WGS = old
+
+
+def test_gan_step_in_bf16_mode_vs_its_oracle(bf16_mode):
+    """One full GAN step (256-channel Generator with 2 blocks, Discriminator, VGG, 48 -> 192 patches) with --precision bf16
+    against the oracle's restatement of that mode (oracle/bf16.py: the same convs round the same operands): losses, every
+    Generator gradient through the post-Adam parameters, Discriminator parameters.  Also: the step is NOT the fp32 step
+    (the bf16 kernels really ran), and the dispatch put the expected layers on them."""
+    import sys, os, warnings
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import adam_close, dis_sd, gen_sd, vgg_sd
+    from model import Discriminator, Generator, VGG
+    from oracle import bf16 as OB, detrand, step as OS
+    from pesr_amd import ops
+    from pesr_amd.optim import FlatAdam
+    from pesr_amd.step import Trainer
+    warnings.filterwarnings("ignore", message=".*pretrained vgg19.*")
+    C, depth, ps, B = 256, 2, 48, 2
+    g_sd, d_sd, v_sd = gen_sd(C, depth), dis_sd(ps), vgg_sd()
+    G = Generator({"num_channels": C, "depth": depth, "res_scale": 0.1}); G.load_state_dict(g_sd); G.cuda()
+    D = Discriminator({"patch_size": ps, "spectral_norm": False}); D.load_state_dict(d_sd); D.cuda()
+    V = VGG(); V.load_state_dict(v_sd); V.cuda()
+    tr = Trainer(G, D, V, FlatAdam(G.parameters(), lr=5e-5), FlatAdam(D.parameters(), lr=5e-5))
+    lr = detrand.image_batch((B, 3, ps, ps), 700); hr = detrand.image_batch((B, 3, 4 * ps, 4 * ps), 701)
+    cfg = {"depth": depth, "res_scale": 0.1, "learning_rate": 5e-5}
+    def oracle(b16, dtype):
+        cv = lambda sd: {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        st_ = OS.TrainState(cv(g_sd), cv(d_sd), cv(v_sd), cfg)
+        with OB.enabled(b16, 1):
+            return st_, OS.gan_step(st_, lr.to(dtype), hr.to(dtype))
+    st, ref = oracle(True, torch.float32)
+    _, ref64 = oracle(True, torch.float64)           # the same rounding, float64 sums: the truth the mode defines
+    _, ref32 = oracle(False, torch.float32)          # the reference's fp32 arithmetic
+    ops.FLOPS.start()
+    log = tr.gan_step(lr.cuda(), hr.cuda())
+    fl = ops.FLOPS.stop()
+    fam = fl["by_kernel_family"]
+    assert fam["bf16"][0] > 0.6 * fl["algorithmic"], fam          # the bulk of the conv flops ran on the bf16 kernels
+    # Rounding to bf16 turns an fp32-summation-order difference in an activation that sits on a rounding boundary into a 2^-8
+    # relative jump of that operand, so the mode's OWN restatements (fp32 vs float64 sums) differ by up to ~1.5e-3 on the losses
+    # that go through the Discriminator (measured: g 1.45e-3, d 4e-4, vgg 3e-5, tv 1e-6).  The bound is therefore the one of
+    # helpers.grads_vs_fp64: our error against the float64-sum truth <= 3 x the fp32-sum oracle's own, never tighter than 2e-5.
+    for k in ("vgg", "g", "tv", "d"):
+        own = abs(ref[k] - ref64[k]) / abs(ref64[k])
+        err = abs(float(log[k]) - ref64[k]) / abs(ref64[k])
+        assert err <= max(3.0 * own, 2e-5), (k, float(log[k]), ref[k], ref64[k], err, own)
+    # the mode is visibly not fp32 where the bf16 rounding dominates that noise: the perceptual and TV losses sit on the bf16
+    # oracle's values, several times closer than the fp32 oracle's are
+    for k in ("vgg", "tv"):
+        assert abs(float(log[k]) - ref64[k]) < 0.3 * abs(ref32[k] - ref64[k]), (k, float(log[k]), ref64[k], ref32[k])
+    # Post-Adam parameters: the first Adam step moves every element by lr * sign(gradient), and the mode's noise floor (above) flips
+    # the sign of more near-zero gradients than fp32's does (3.6 % of embed.weight here), so helpers.adam_close's 3 % flip budget
+    # does not apply; what must hold: no element off by more than the sign-flip bound, and a mean error far below lr (a tensor
+    # trained with a wrong gradient, or not at all, is off by >= lr on average).
+    def params_close(got, want, what):
+        err = (got.detach().cpu().double() - want.detach().double()).abs()
+        assert err.max().item() <= 2.2 * 5e-5 + 2e-5 * want.abs().max().item(), (what, err.max().item() / 5e-5)
+        assert err.mean().item() <= 0.25 * 5e-5, (what, err.mean().item() / 5e-5)
+    for k, v in G.state_dict().items():
+        params_close(v, st.g[k], "G." + k)
+    for k, v in D.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            continue
+        params_close(v, st.d[k], "D." + k)
+
+
+def test_generator_gradients_in_bf16_mode_vs_its_oracle(bf16_mode):
+    """Generator forward + L1 backward (256 channels, 2 blocks, 48 -> 192) in the bf16 mode: output and every parameter gradient
+    against the oracle's restatement with float64 sums; per tensor the error may be 3 x the error of the restatement with fp32
+    sums (the mode's own noise floor, see the step test) or twice the worst such error in the network, never tighter than 2e-4
+    of the gradient's maximum."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import gen_sd
+    from model import Generator
+    from oracle import bf16 as OB, detrand, model as OM
+    from pesr_amd import functional as PF
+    from pesr_amd.model.basic import nhwc
+    C, depth, ps, B = 256, 2, 48, 2
+    g_sd = gen_sd(C, depth)
+    lr = detrand.image_batch((B, 3, ps, ps), 710); hr = detrand.image_batch((B, 3, 4 * ps, 4 * ps), 711)
+
+    def oracle(dtype):
+        sd = {k: v.clone().to(dtype).requires_grad_(True) for k, v in g_sd.items()}
+        with OB.enabled(True, 1):
+            sr = OM.generator_forward(sd, lr.to(dtype), depth, 0.1)
+            (sr - hr.to(dtype)).abs().mean().backward()
+        return sr.detach(), {k: v.grad for k, v in sd.items()}
+    sr32, g32 = oracle(torch.float32)
+    sr64, g64 = oracle(torch.float64)
+    G = Generator({"num_channels": C, "depth": depth, "res_scale": 0.1}); G.load_state_dict(g_sd); G.cuda()
+    sr = G(lr.cuda())
+    own = (sr32.double() - sr64).abs().max().item()
+    assert (sr.cpu().double() - sr64).abs().max().item() <= max(3.0 * own, 2e-3), own          # 0 .. 255 scale
+    PF.l1_loss(nhwc(sr), nhwc(hr.cuda().contiguous(memory_format=torch.channels_last))).backward()
+    owns = {k: (g32[k].double() - g64[k]).abs().max().item() / g64[k].abs().max().item() for k in g64}
+    floor = max(owns.values())           # a tensor's own error is a one-sample estimate of noise: never demand better than twice
+    for k, p in G.named_parameters():    # the worst error the restatement itself shows anywhere in the network (helpers.grads_vs_fp64)
+        err = (p.grad.cpu().double() - g64[k]).abs().max().item() / g64[k].abs().max().item()
+        assert err <= max(3.0 * owns[k], 2.0 * floor, 2e-4), (k, err, owns[k], floor)

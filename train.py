@@ -63,6 +63,10 @@ def build_parser():
                    help="capture the train step into a hipGraph after two eager iterations and replay it (same results bit for "
                         "bit; the host no longer issues ~1000 launches per step).  auto = on for a single-GPU run, off under "
                         "torch.distributed (there the RCCL all-reduces are captured with the step: opt in with true)")
+    p.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16"],
+                   help="fp32 (default): the reference's arithmetic.  bf16: OPTIONAL mixed-precision mode - the stride-1 3x3 convs with "
+                        "32-multiple input / 128-multiple output channels run on the bf16 MFMA (both operands rounded to bf16, fp32 "
+                        "accumulation, fp32 tensors and optimizer): ~1.8x the step rate, NOT the reference's numerics")
     p.add_argument("--gpu_pipeline", type=str2bool, default=False,
                    help="keep the uint8 training images in HBM and crop/augment on the GPU (pesr_amd.input_pipeline)")
     return p
@@ -205,6 +209,8 @@ def main(argv=None):
             print("%20s: %s" % (k, v))
 
     from model import Discriminator, Generator, VGG
+    from pesr_amd import ops as _ops
+    _ops.set_precision(args.precision)
     from pesr_amd.optim import FlatAdam
     from pesr_amd.step import Trainer
     from utils import compute_PSNR
