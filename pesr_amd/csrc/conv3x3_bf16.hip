@@ -43,14 +43,27 @@ struct Bf16Args {
     int ps_in;                 // 1: x is a pixel-shuffled tensor [N][2H][2W][Cin/4] read as its sub-pixel-major [N][H][W][Cin] view
 };
 
+#ifndef B16_STAGE_T
+#define B16_STAGE_T 6
+#endif
+#ifndef B16_FXD
+#define B16_FXD 3
+#endif
+#ifndef B16_PRIO
+#define B16_PRIO 0
+#endif
 constexpr int B16_MG = 9;      // m-tiles of 16 pixels per workgroup
 constexpr int B16_PX = 96;     // LDS bytes per halo pixel: 64 of data + 32 of padding
 
-template <int NTW>
+// WTC: the halo width TW + 2 as a compile-time constant (the tile shapes of the networks' layers), or 0 = a.WT at run time.  With it
+// a tap's LDS offset is an immediate of the ds_read, and the fragment reads need no address arithmetic inside the loop: with two
+// waves per SIMD on 16-cycle MFMAs every other vector instruction competes with the matrix pipe for issue slots.
+template <int NTW, int WTC>
 __global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
     constexpr int NT = 512, NU = 4, BN = 128 * NTW;
+    const int WT = WTC ? WTC : a.WT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int v_bytes = (a.HT * a.WT + 1) * B16_PX;                       // + the dump pixel
+    const int v_bytes = (a.HT * WT + 1) * B16_PX;                       // + the dump pixel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -74,20 +87,27 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
     for (int i = 0; i < B16_MG; ++i) {
         const int m = i * 16 + r;
         const int trow = m / a.TW, tcol = m - trow * a.TW;
-        a_off[i] = (trow * a.WT + tcol) * B16_PX + g * 16;
+        a_off[i] = (trow * WT + tcol) * B16_PX + g * 16;
     }
 
-    // ---- weight operand: this lane's 16 bytes of slab (tap, chunk), n-tile j: wave-uniform base + per-lane offset --------------
-    const size_t slab_bytes = (size_t)a.Cout * 64;
+    // ---- weight operand: this lane's 16 bytes of slab (tap, chunk), n-tile j.  A buffer load: the slab's offset is a SCALAR offset
+    // and j a 1-KiB immediate, so a weight fetch costs the vector unit nothing but its issue slot (the packed weights are < 4 GB).
+    const int slab_bytes = a.Cout * 64;
     const unsigned b_lane = (unsigned)(((n0 + wave * NTW * 16 + r) * 32 + g * 8) * 2);
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (unsigned)((size_t)9 * a.Cin * a.Cout * 2), 0x00020000);
     auto ldw = [&](int t, int j, int cc) -> bf16x8 {
-        const char* const base = a.wp + (size_t)(t * C32 + cc) * slab_bytes;
-        return *(const bf16x8*)(base + b_lane + j * 1024);
+#ifdef B16_FAKE_W   // timing experiment only (wrong results): every wave re-reads ONE KiB of weights - is the L2 -> CU weight stream the limit?
+        const int so = 0 * (t + cc);
+#else
+        const int so = (t * C32 + cc) * slab_bytes;
+#endif
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_lane + j * 1024, so, 0));
     };
 
     // ---- staging items: (halo pixel, 4-channel group q of 8) ---------------------------------------------------------------------
     const float* const x_img = a.x + (size_t)img * a.H * a.W * a.Cin;
-    const int n_items = a.HT * a.WT * 8;
+    const int n_items = a.HT * WT * 8;
     const int Cq = a.Cin >> 2;
     unsigned st_off[NU];
     int st_dst[NU];
@@ -95,13 +115,13 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
     for (int u = 0; u < NU; ++u) {
         const int it = tid + u * NT;
         const int q = it & 7, px = it >> 3;
-        const int hrow = px / a.WT, hcol = px - hrow * a.WT;
+        const int hrow = px / WT, hcol = px - hrow * WT;
         const int iy = gy0 - 1 + hrow, ix = gx0 - 1 + hcol;
         const bool ok = it < n_items && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
         // out-of-image pixels are fetched beyond the buffer descriptor's range: the load returns zeros (images are < 2 GB)
         st_off[u] = ok ? (unsigned)((pix + q * 4) * 4) : 0x80000000u;
-        st_dst[u] = (it < n_items ? px : a.HT * a.WT) * B16_PX + q * 8;     // items past the halo land in a dump pixel behind it
+        st_dst[u] = (it < n_items ? px : a.HT * WT) * B16_PX + q * 8;     // items past the halo land in a dump pixel behind it
     }
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)x_img, 0, (unsigned)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
@@ -117,7 +137,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
     auto stage_load = [&](int cc) {
         const int so = __builtin_amdgcn_readfirstlane(chunk_off(cc));
 #pragma unroll
+#ifdef B16_FAKE_X   // timing experiment only: the halo is fetched once (chunk 0's bytes every time, L1 / L2 hits)
+        for (int u = 0; u < NU; ++u) sx[u] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_off[u], so & 0, 0);
+#else
         for (int u = 0; u < NU; ++u) sx[u] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_off[u], so, 0);
+#endif
     };
     auto stage_store = [&](char* vdst) {
 #pragma unroll
@@ -137,13 +161,13 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
         for (int i = 0; i < B16_MG; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     bf16x8 fw[9][NTW];         // the wave's weight fragments, one chunk ahead
-    bf16x8 fx[2][3];           // pixel fragments: groups of three m-tiles, double buffered
+    bf16x8 fx[B16_FXD][3];     // pixel fragments: groups of three m-tiles in a ring of B16_FXD register sets
 
 #define B16_READ_X(FX, VB, T, GRP)                                                                       \
     {                                                                                                    \
-        const char* const vb_ = (VB) + (((T) / 3) * a.WT + (T) % 3) * B16_PX;                            \
+        const int to_ = (((T) / 3) * WT + (T) % 3) * B16_PX;                                             \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
-            FX[i] = *(const bf16x8*)(vb_ + a_off[(GRP) * 3 + i]);                                        \
+            FX[i] = *(const bf16x8*)((VB) + a_cur[(GRP) * 3 + i] + to_);                                 \
     }
 #define B16_MFMA(FX, T, GRP)                                                                             \
     _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                        \
@@ -165,28 +189,47 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
 
 #pragma unroll 1
     for (int c = 0; c < C32; ++c) {
-        char* const vcur = smem + (c & 1) * v_bytes;
+        const int cur_off = (c & 1) * v_bytes;
+        int a_cur[B16_MG];                                 // this chunk's image folded into the per-lane offsets: 9 adds per chunk, not 81
+#pragma unroll
+        for (int i = 0; i < B16_MG; ++i) a_cur[i] = a_off[i] + cur_off;
         char* const vnext = smem + ((c & 1) ^ 1) * v_bytes;
         // The last chunk "prefetches" itself again (loads and LDS stores nobody consumes): with no branch in the loop the
         // compiler counts the outstanding loads exactly instead of draining the queue (vmcnt(0)) at every use.
         const int cn = c + 1 < C32 ? c + 1 : c;
         stage_load(cn);                                    // lands while this chunk computes
-        B16_READ_X(fx[0], vcur, 0, 0)
+        // fragment groups G = 3 t + grp (27 per chunk) go through a ring of B16_FXD register sets: the reads of group G + B16_FXD - 1
+        // are issued in front of the MFMAs of group G, i.e. B16_FXD - 1 groups (6 MFMAs each) ahead of their use
+#pragma unroll
+        for (int G0 = 0; G0 < B16_FXD - 1; ++G0) B16_READ_X(fx[G0], smem, G0 / 3, G0 % 3)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
 #pragma unroll
             for (int grp = 0; grp < 3; ++grp) {
-                const int cur = (t * 3 + grp) & 1;
-                if (grp < 2) B16_READ_X(fx[cur ^ 1], vcur, t, grp + 1)
-                else if (t + 1 < 9) B16_READ_X(fx[cur ^ 1], vcur, t + 1, 0)
+                const int G = t * 3 + grp, Gn = G + B16_FXD - 1;
+#ifndef B16_ABL_NOREAD
+                if (Gn < 27) B16_READ_X(fx[Gn % B16_FXD], smem, Gn / 3, Gn % 3)
+#endif
                 __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of the MFMA group
-                B16_MFMA(fx[cur], t, grp)
+#if B16_PRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
+#ifndef B16_ABL_NOMFMA
+                B16_MFMA(fx[G % B16_FXD], t, grp)
+#else
+                _Pragma("unroll") for (int i = 0; i < 3; ++i) asm volatile("" :: "v"(fx[G % B16_FXD][i]));
+#endif
+#if B16_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             // this tap's weights are consumed: fetch the same tap of the next chunk into their registers
+#ifndef B16_ABL_NOW
 #pragma unroll
             for (int j = 0; j < NTW; ++j) fw[t][j] = ldw(t, j, cn);
-            if (t == 6) { stage_store(vnext); __builtin_amdgcn_sched_barrier(0); }
+#endif
+            if (t == B16_STAGE_T) { stage_store(vnext); __builtin_amdgcn_sched_barrier(0); }
         }
         __syncthreads();                                   // the next image is complete and visible; everyone is done with this one
     }
@@ -324,7 +367,16 @@ int pesr_conv3x3_bf16_launch(const float* x, const void* wp, const float* bias, 
     a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
     a.TR = p.TR; a.TW = p.TW; a.HT = p.HT; a.WT = p.WT;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
-    if (p.ntw == 2) hipLaunchKernelGGL(conv3x3_bf16_kernel<2>, dim3((unsigned)p.tiles), dim3(512), p.lds, stream, a);
-    else hipLaunchKernelGGL(conv3x3_bf16_kernel<1>, dim3((unsigned)p.tiles), dim3(512), p.lds, stream, a);
+#define B16_LAUNCH(NTW_, WT_) hipLaunchKernelGGL((conv3x3_bf16_kernel<NTW_, WT_>), dim3((unsigned)p.tiles), dim3(512), p.lds, stream, a)
+#define B16_BY_WT(NTW_)                                      \
+    switch (p.WT) {                                          \
+        case 50: B16_LAUNCH(NTW_, 50); break;                \
+        case 26: B16_LAUNCH(NTW_, 26); break;                \
+        case 14: B16_LAUNCH(NTW_, 14); break;                \
+        default: B16_LAUNCH(NTW_, 0); break;                 \
+    }
+    if (p.ntw == 2) { B16_BY_WT(2) } else { B16_BY_WT(1) }
+#undef B16_BY_WT
+#undef B16_LAUNCH
     return pesr_launch_status();
 }
