@@ -1,3 +1,6 @@
+// DIAGNOSTIC copy of pesr_amd/csrc/conv3x3_bf16.hip with its timing-experiment switches (scripts/README.md): -DB16_FAKE_W / -DB16_FAKE_X (weights / halo re-read
+// from one hot KiB: WRONG results), -DB16_ABL_NOREAD / _NOMFMA / _NOW (no LDS fragment reads / MFMAs / weight loads: WRONG results), -DB16_FXD=2|3, -DB16_PRIO=1,
+// -DB16_STAGE_T=n.  Built only by scripts/build_variant.sh <name> conv3x3_bf16_diag.hip ... into exp/; profiles/r03_bf16_kernel_times.txt has what they measured.
 // 3x3 stride-1 convolution on the bf16 MFMA (v_mfma_f32_16x16x32_bf16), gfx950: the OPTIONAL reduced-precision mode.
 //
 // Same contract and fused epilogue as conv3x3_wino4.hip (reference nn.Conv2d(k=3, padding=1), model/basic.py:4-7, forward and -
@@ -43,8 +46,15 @@ struct Bf16Args {
     int ps_in;                 // 1: x is a pixel-shuffled tensor [N][2H][2W][Cin/4] read as its sub-pixel-major [N][H][W][Cin] view
 };
 
-constexpr int B16_STAGE_T = 6; // the staged halo is converted and stored after this tap (4 / 6 / 8 measured the same)
-constexpr int B16_FXD = 3;     // register sets of the pixel-fragment ring (2 measured the same)
+#ifndef B16_STAGE_T
+#define B16_STAGE_T 6
+#endif
+#ifndef B16_FXD
+#define B16_FXD 3
+#endif
+#ifndef B16_PRIO
+#define B16_PRIO 0
+#endif
 constexpr int B16_MG = 9;      // m-tiles of 16 pixels per workgroup
 constexpr int B16_PX = 96;     // LDS bytes per halo pixel: 64 of data + 32 of padding
 
@@ -90,7 +100,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
     const __amdgpu_buffer_rsrc_t w_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (unsigned)((size_t)9 * a.Cin * a.Cout * 2), 0x00020000);
     auto ldw = [&](int t, int j, int cc) -> bf16x8 {
+#ifdef B16_FAKE_W   // timing experiment only (wrong results): every wave re-reads ONE KiB of weights - is the L2 -> CU weight stream the limit?
+        const int so = 0 * (t + cc);
+#else
         const int so = (t * C32 + cc) * slab_bytes;
+#endif
         return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_lane + j * 1024, so, 0));
     };
 
@@ -126,7 +140,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
     auto stage_load = [&](int cc) {
         const int so = __builtin_amdgcn_readfirstlane(chunk_off(cc));
 #pragma unroll
+#ifdef B16_FAKE_X   // timing experiment only: the halo is fetched once (chunk 0's bytes every time, L1 / L2 hits)
+        for (int u = 0; u < NU; ++u) sx[u] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_off[u], so & 0, 0);
+#else
         for (int u = 0; u < NU; ++u) sx[u] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_off[u], so, 0);
+#endif
     };
     auto stage_store = [&](char* vdst) {
 #pragma unroll
@@ -192,14 +210,28 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
 #pragma unroll
             for (int grp = 0; grp < 3; ++grp) {
                 const int G = t * 3 + grp, Gn = G + B16_FXD - 1;
+#ifndef B16_ABL_NOREAD
                 if (Gn < 27) B16_READ_X(fx[Gn % B16_FXD], smem, Gn / 3, Gn % 3)
+#endif
                 __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of the MFMA group
+#if B16_PRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
+#ifndef B16_ABL_NOMFMA
                 B16_MFMA(fx[G % B16_FXD], t, grp)
+#else
+                _Pragma("unroll") for (int i = 0; i < 3; ++i) asm volatile("" :: "v"(fx[G % B16_FXD][i]));
+#endif
+#if B16_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             // this tap's weights are consumed: fetch the same tap of the next chunk into their registers
+#ifndef B16_ABL_NOW
 #pragma unroll
             for (int j = 0; j < NTW; ++j) fw[t][j] = ldw(t, j, cn);
+#endif
             if (t == B16_STAGE_T) { stage_store(vnext); __builtin_amdgcn_sched_barrier(0); }
         }
         __syncthreads();                                   // the next image is complete and visible; everyone is done with this one
