@@ -31,7 +31,7 @@ GFLOP_PER_PATCH = {"gan": 844.10, "pretrain": 694.69}   # SURVEY.md 8(d), necess
 K1_GFLOP = 2.0 * 16 * 48 * 48 * 256 * 256 * 9 / 1e9     # body conv 256->256 @48x48, batch 16: 43.487 GFLOP per launch
 
 
-PMC_SUMMARIES = ("r03_k1_pmc_summary.csv", "r02_k1_pmc_summary.csv", "r01_final3_k1_pmc_summary.csv")     # newest first
+PMC_SUMMARIES = ("r03_k1_pmc_summary.csv", "r03_bf16_pmc_summary.csv", "r02_k1_pmc_summary.csv", "r01_final3_k1_pmc_summary.csv")     # newest first
 
 
 def k1_hbm_traffic_bytes(kernel_substr):

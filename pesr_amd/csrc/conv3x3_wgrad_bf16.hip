@@ -66,7 +66,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(const WgB16Args
     const int r = lane & 15, g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int ci_tile = wave & 3, co_half = wave >> 2;
 
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch): give every XCD a contiguous range of logical blocks, tile index
+    // fastest, so that the co x ci tiles of one split-K slice - which read the SAME pixels - share an L2 (without it every XCD
+    // fetched every pixel: 225 MB of HBM / MALL reads per G-body launch for 75 MB of operands, profiles/r03_bf16_pmc_summary.csv).
     int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int cit = bid % a.ci_tiles;  bid /= a.ci_tiles;
     const int cot = bid % a.co_tiles;
     const int sp = bid / a.co_tiles;
