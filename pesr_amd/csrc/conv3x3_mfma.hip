@@ -85,9 +85,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int r = lane & 15, g = lane >> 4;
 
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch): give every XCD a contiguous range of logical tiles, n-tile
+    // fastest, so that the n-tiles of one pixel tile - which read the same halo - share an L2.
+    int lb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lb = (lb & 7) * (gridDim.x >> 3) + (lb >> 3);
     const int tiles_total = a.n_tiles * a.tiles_x * a.tiles_y * a.N;
-    const int ks = blockIdx.x / tiles_total;            // split-K slice (0 when ksplit == 1)
-    int bid = blockIdx.x - ks * tiles_total;
+    const int ks = lb / tiles_total;                    // split-K slice (0 when ksplit == 1)
+    int bid = lb - ks * tiles_total;
     const int nt = bid % a.n_tiles;  bid /= a.n_tiles;
     const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;

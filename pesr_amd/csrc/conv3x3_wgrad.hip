@@ -74,7 +74,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const WgradArgs a) {
     const int r = lane & 15, g = lane >> 4;
     const int ci_tile = wave & 3, co_half = wave >> 2;
 
+    // Workgroups b and b + 8 share an XCD: contiguous logical ranges per XCD, channel tiles fastest - the tiles of one split-K
+    // slice stream the same pixels and then share an L2.
     int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int cit = bid % a.ci_tiles;  bid /= a.ci_tiles;
     const int cot = bid % a.co_tiles;
     const int sp = bid / a.co_tiles;
