@@ -186,11 +186,16 @@ def bench_infer512(args, device):
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     tf = 105.3875 / dt
-    print(json.dumps({"metric": "LR tiles/sec (x4 SR generator forward, 512x512 LR tiles, batch 4)", "value": round(4 / dt, 3),
+    bf16 = args.precision == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    print(json.dumps({"metric": "LR tiles/sec (x4 SR generator forward, 512x512 LR tiles, batch 4)" + (" [OPTIONAL bf16-operand mode]" if bf16 else ""),
+                      "value": round(4 / dt, 3),
                       "unit": "tiles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2),
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "bf16 operands / f32 accumulation in the 3x3 convs, f32 tensors" if bf16 else "f32", "data": "synthetic",
+                      "precision": args.precision,
                       "config": {"workload": "BASELINE config 5: G forward no_grad, 4x3x512x512 -> 4x3x2048x2048, 256 ch x 32 blocks"},
-                      "step_tflops_per_gpu": round(tf, 2), "step_frac_of_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                      "step_tflops_per_gpu": round(tf, 2), "step_frac_of_mfma_peak": round(tf / peak, 4), "mfma_peak_tflops": peak,
                       "out_checksum": float(y.double().sum())}), flush=True)
 
 
