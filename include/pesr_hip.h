@@ -115,8 +115,8 @@ int pesr_conv3x3_wino4(const float* x, const float* w_packed, const float* bias,
  * Stride-1 3x3 conv (pad 1) on v_mfma_f32_16x16x32_bf16: same tensors (fp32 NHWC in HBM), same fused epilogue and PixelShuffle
  * options as pesr_conv3x3_wino4, but BOTH operands of every product are rounded to bf16 (round to nearest even) and summed in
  * fp32.  Not the reference's arithmetic (model/basic.py:4-7 runs nn.Conv2d in fp32): checked against its own oracle
- * (oracle/ops.py conv3x3_bf16: the same rounding, float64 sums) with its own tolerance.  Cin % 32 == 0, Cout % 128 == 0
- * (Cout % 512 == 0 [1024 with 256-channel n-tiles] with ps_out; Cin % 128 == 0 with ps_in).
+ * (oracle/ops.py conv3x3_bf16: the same rounding, float64 sums) with its own tolerance.  Cin % 32 == 0, Cout % 64 == 0
+ * (with ps_out: Cout a multiple of four workgroup widths - 256 / 128 / 64 channels for Cout % 256 / 128 / 64 == 0; Cin % 128 == 0 with ps_in).
  * w_packed: 9 * Cin * Cout bf16 (2 bytes each) from pesr_pack_conv3x3_bf16 (mode 0 forward / mode 1 input gradient - then call
  * with Cin / Cout of the gradient problem swapped).  pesr_conv3x3_bf16_score: per-mille of the kernel's 144-pixel tiles inside
  * the image, 0 for unsupported shapes or fewer than min_wgs workgroups (the host-side dispatch passes 128). */

@@ -40,7 +40,7 @@ def _cdiv(a, b):
 
 def conv_score(N, H, W, Cin, Cout, min_wgs):
     """conv3x3_bf16.hip b16_plan: per-mille of the 144-pixel tiles' area inside the image, 0 if unsupported / too few workgroups."""
-    if N < 1 or H < 1 or W < 1 or Cin % 32 or Cin < 32 or Cout % 128 or H * W * Cin * 4 >= 1 << 31:
+    if N < 1 or H < 1 or W < 1 or Cin % 32 or Cin < 32 or Cout % 64 or H * W * Cin * 4 >= 1 << 31:
         return 0
     best = None
     for TW in range(1, 145):
@@ -57,15 +57,16 @@ def conv_score(N, H, W, Cin, Cout, min_wgs):
     if best is None:
         return 0
     _, TR, TW = best
-    ntw = 2 if Cout % 256 == 0 else 1
-    tiles = N * _cdiv(H, TR) * _cdiv(W, TW) * (Cout // (128 * ntw))
+    bn = 256 if Cout % 256 == 0 else (128 if Cout % 128 == 0 else 64)
+    tiles = N * _cdiv(H, TR) * _cdiv(W, TW) * (Cout // bn)
     eff = H * W / (_cdiv(H, TR) * TR * _cdiv(W, TW) * TW)
     return int(1000.0 * eff) if tiles >= min_wgs else 0
 
 
 def conv_eligible(N, H, W, Cin, Cout, stride=1, ps_out=False, ps_in=False):
     """pesr_amd.ops.bf16_eligible for the problem the kernel runs (an input gradient: Cin / Cout swapped)."""
-    if stride != 1 or Cin % 32 or Cout % 128 or (ps_out and Cout % 1024) or (ps_in and Cin % 128):
+    bn = 256 if Cout % 256 == 0 else (128 if Cout % 128 == 0 else 64)
+    if stride != 1 or Cin % 32 or Cout % 64 or (ps_out and Cout % (4 * bn)) or (ps_in and Cin % 128):
         return False
     return conv_score(N, H, W, Cin, Cout, MIN_WGS) >= 780
 

@@ -7,8 +7,8 @@
 // reference's fp32 conv (relative error of a product 2^-8 instead of 2^-24): it has its own oracle (oracle/ops.py
 // conv3x3_bf16: the same rounding, float64 accumulation) and its own tolerance, and is never selected by default.
 //
-// One workgroup = 144 output pixels (TR rows x TW columns) x BN = 128 * NTW output channels, 8 waves; wave w owns the 16 * NTW
-// channels (w * NTW + j) * 16 .. for all nine 16-pixel m-tiles: 9 * NTW accumulator tiles.  Per 32-channel chunk:
+// One workgroup = 144 output pixels (TR rows x TW columns) x BN = 128 * NTW output channels, 8 waves (64-channel layers: 64 channels,
+// 4 waves); wave w owns the 16 * NTW channels (w * NTW + j) * 16 .. for all nine 16-pixel m-tiles: 9 * NTW accumulator tiles.  Per 32-channel chunk:
 //   * B operand (pixels): the tile's (TR + 2) x (TW + 2) input halo as bf16, [pixel][32 ch] = 64 B per pixel, double buffered in
 //     LDS.  Global fp32 -> registers (issued at the top of the previous chunk) -> v_cvt_pk_bf16_f32 -> ds_write_b64 two thirds
 //     into the previous chunk's MFMA stream; ONE barrier per chunk.  All nine taps read the same image at shifted pixel offsets
@@ -51,9 +51,11 @@ constexpr int B16_PX = 96;     // LDS bytes per halo pixel: 64 of data + 32 of p
 // WTC: the halo width TW + 2 as a compile-time constant (the tile shapes of the networks' layers), or 0 = a.WT at run time.  With it
 // a tap's LDS offset is an immediate of the ds_read, and the fragment reads need no address arithmetic inside the loop: with two
 // waves per SIMD on 16-cycle MFMAs every other vector instruction competes with the matrix pipe for issue slots.
-template <int NTW, int WTC>
-__global__ __launch_bounds__(512) void conv3x3_bf16_kernel(const Bf16Args a) {
-    constexpr int NT = 512, NU = 4, BN = 128 * NTW;
+// NW: waves per workgroup.  8 (x NTW = 2 / 1: 256 / 128 output channels per workgroup), or 4 with NTW = 1 for the 64-channel layers
+// (vgg19 conv1_2, the input gradients of the 64 -> 128 convs): 144 pixels x 64 channels, 256 threads, several workgroups per CU.
+template <int NTW, int WTC, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a) {
+    constexpr int NT = NW * 64, NU = 2048 / NT, BN = NW * 16 * NTW;
     const int WT = WTC ? WTC : a.WT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int v_bytes = (a.HT * WT + 1) * B16_PX;                       // + the dump pixel
@@ -290,17 +292,17 @@ int pesr_pack_conv3x3_bf16_launch(const float* w, void* out, int O, int I, int m
 }
 
 namespace {
-struct B16Plan { int TR, TW, HT, WT, tiles_x, tiles_y, n_tiles, ntw; long tiles; size_t lds; int score; };
+struct B16Plan { int TR, TW, HT, WT, tiles_x, tiles_y, n_tiles, ntw, bn; long tiles; size_t lds; int score; };
 
 // Tile shape TR x TW == 144 pixels with the least out-of-image area whose halo fits the four staging items per thread.
 static bool b16_plan(int N, int H, int W, int Cin, int Cout, B16Plan* p, int min_wgs = 128) {
-    if (N < 1 || H < 1 || W < 1 || Cin % 32 || Cin < 32 || Cout % 128) return false;
+    if (N < 1 || H < 1 || W < 1 || Cin % 32 || Cin < 32 || Cout % 64) return false;
     if ((size_t)H * W * Cin * 4 >= ((size_t)1 << 31)) return false;   // one image per buffer descriptor, offsets below 2^31
     long best = -1;
     for (int TW = 1; TW <= 144; ++TW) {
         if (144 % TW) continue;
         const int TR = 144 / TW, HT = TR + 2, WT = TW + 2;
-        if (HT * WT * 8 > 4 * 512) continue;
+        if (HT * WT * 8 > 2048) continue;                    // NU * NT staging items
         const long cover = (long)pesr_cdiv(H, TR) * TR * pesr_cdiv(W, TW) * TW;
         // least waste first; then m-tiles that stay inside one row (conflict-free fragment reads); then the smallest halo
         const long score = cover * 8192 + (TW % 16 ? 4096 : 0) + (long)HT * WT;
@@ -309,7 +311,8 @@ static bool b16_plan(int N, int H, int W, int Cin, int Cout, B16Plan* p, int min
     if (best < 0) return false;
     p->HT = p->TR + 2; p->WT = p->TW + 2;
     p->ntw = Cout % 256 == 0 ? 2 : 1;
-    p->tiles_y = pesr_cdiv(H, p->TR); p->tiles_x = pesr_cdiv(W, p->TW); p->n_tiles = Cout / (128 * p->ntw);
+    p->bn = Cout % 128 == 0 ? 128 * p->ntw : 64;              // 64: the four-wave workgroups
+    p->tiles_y = pesr_cdiv(H, p->TR); p->tiles_x = pesr_cdiv(W, p->TW); p->n_tiles = Cout / p->bn;
     p->tiles = (long)N * p->tiles_y * p->tiles_x * p->n_tiles;
     p->lds = (size_t)2 * (p->HT * p->WT + 1) * B16_PX;
     const double cover_eff = (double)H * W / ((double)p->tiles_y * p->TR * p->tiles_x * p->TW);
@@ -330,7 +333,7 @@ int pesr_conv3x3_bf16_launch(const float* x, const void* wp, const float* bias, 
                              hipStream_t stream) {
     B16Plan p;
     if (!b16_plan(N, H, W, Cin, Cout, &p)) return PESR_EINVAL;
-    if (ps && (Cout % (4 * 128 * p.ntw) || skip || mask)) return PESR_EINVAL;   // an n-tile must stay inside one sub-pixel plane
+    if (ps && (Cout % (4 * p.bn) || skip || mask)) return PESR_EINVAL;          // an n-tile must stay inside one sub-pixel plane
     if (ps_in && Cin % 128) return PESR_EINVAL;                                 // a 32-channel chunk must stay inside one sub-pixel
     Bf16Args a{};
     a.x = x; a.wp = (const char*)wp; a.bias = bias; a.skip = skip; a.mask = mask; a.y = y;
@@ -338,15 +341,16 @@ int pesr_conv3x3_bf16_launch(const float* x, const void* wp, const float* bias, 
     a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
     a.TR = p.TR; a.TW = p.TW; a.HT = p.HT; a.WT = p.WT;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
-#define B16_LAUNCH(NTW_, WT_) hipLaunchKernelGGL((conv3x3_bf16_kernel<NTW_, WT_>), dim3((unsigned)p.tiles), dim3(512), p.lds, stream, a)
-#define B16_BY_WT(NTW_)                                      \
+#define B16_LAUNCH(NTW_, WT_, NW_) \
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<NTW_, WT_, NW_>), dim3((unsigned)p.tiles), dim3(NW_ * 64), p.lds, stream, a)
+#define B16_BY_WT(NTW_, NW_)                                 \
     switch (p.WT) {                                          \
-        case 50: B16_LAUNCH(NTW_, 50); break;                \
-        case 26: B16_LAUNCH(NTW_, 26); break;                \
-        case 14: B16_LAUNCH(NTW_, 14); break;                \
-        default: B16_LAUNCH(NTW_, 0); break;                 \
+        case 50: B16_LAUNCH(NTW_, 50, NW_); break;           \
+        case 26: B16_LAUNCH(NTW_, 26, NW_); break;           \
+        case 14: B16_LAUNCH(NTW_, 14, NW_); break;           \
+        default: B16_LAUNCH(NTW_, 0, NW_); break;            \
     }
-    if (p.ntw == 2) { B16_BY_WT(2) } else { B16_BY_WT(1) }
+    if (p.bn == 64) { B16_BY_WT(1, 4) } else if (p.ntw == 2) { B16_BY_WT(2, 8) } else { B16_BY_WT(1, 8) }
 #undef B16_BY_WT
 #undef B16_LAUNCH
     return pesr_launch_status();

@@ -241,7 +241,7 @@ def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacke
 
 # ---- the OPTIONAL bf16-operand mode --------------------------------------------------------------------------------
 # PRECISION = "bf16" (set_precision / PESR_PRECISION / train.py --precision): the stride-1 convs with 32-multiple input and
-# 128-multiple output channels run on v_mfma_f32_16x16x32_bf16 - operands rounded to bf16, fp32 accumulation, fp32 tensors in HBM.
+# 64-multiple output channels run on v_mfma_f32_16x16x32_bf16 - operands rounded to bf16, fp32 accumulation, fp32 tensors in HBM.
 # Everything else (and everything by default) stays on the fp32 kernels.
 PRECISION = __import__("os").environ.get("PESR_PRECISION", "fp32")
 _B16_SCORE = {}
@@ -266,7 +266,8 @@ class Bf16Packed:
 def bf16_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps_out: bool = False, ps_in: bool = False) -> bool:
     """PRECISION is "bf16" and the bf16 kernel covers the shape with at least 78 % of its tile area inside the image.
     Cin / Cout are those of the problem the kernel runs."""
-    if PRECISION != "bf16" or stride != 1 or Cin % 32 or Cout % 128 or (ps_out and Cout % 1024) or (ps_in and Cin % 128):
+    bn = 256 if Cout % 256 == 0 else (128 if Cout % 128 == 0 else 64)        # output channels per workgroup (conv3x3_bf16.hip)
+    if PRECISION != "bf16" or stride != 1 or Cin % 32 or Cout % 64 or (ps_out and Cout % (4 * bn)) or (ps_in and Cin % 128):
         return False
     key = (N, H, W, Cin, Cout, BF16_MIN_WGS)
     sc = _B16_SCORE.get(key)
