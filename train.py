@@ -65,8 +65,8 @@ def build_parser():
                         "torch.distributed (there the RCCL all-reduces are captured with the step: opt in with true)")
     p.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16"],
                    help="fp32 (default): the reference's arithmetic.  bf16: OPTIONAL mixed-precision mode - the stride-1 3x3 convs with "
-                        "32-multiple input / 128-multiple output channels run on the bf16 MFMA (both operands rounded to bf16, fp32 "
-                        "accumulation, fp32 tensors and optimizer): ~1.8x the step rate, NOT the reference's numerics")
+                        "32-multiple input / 64-multiple output channels run on the bf16 MFMA (both operands rounded to bf16, fp32 "
+                        "accumulation, fp32 tensors and optimizer): ~2.4x the step rate, NOT the reference's numerics")
     p.add_argument("--gpu_pipeline", type=str2bool, default=False,
                    help="keep the uint8 training images in HBM and crop/augment on the GPU (pesr_amd.input_pipeline)")
     return p
