@@ -108,8 +108,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     for (int i = 0; i < WM; ++i) {
         const int m = (wave_m * WM + i) * 16 + r;
         const int py = m / a.TW, px = m - py * a.TW;
-        a_off[i] = ((py * S) * a.WT + px * S) * 64 + g * 16;
+        // stride 2: a halo row is stored de-interleaved - its even columns first, then the odd ones (see h_src) - so that the 16
+        // pixels of a fragment read are 16 CONSECUTIVE 64-byte entries, as for stride 1 (interleaved, their 128-byte stride put 71 %
+        // of the LDS cycles of these layers into bank conflicts: 17.9 M of 25.1 M per launch, SQ_LDS_BANK_CONFLICT)
+        a_off[i] = ((py * S) * a.WT + (S == 2 ? px : px * S)) * 64 + g * 16;
     }
+    const int WE = (a.WT + 1) >> 1;                      // even columns of a halo row (stride 2)
 #pragma unroll
     for (int j = 0; j < WN; ++j) b_off[j] = ((wave_n * WN + j) * 16 + r) * 64 + g * 16;
 
@@ -122,7 +126,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
         const int hp = e >> 2, q = e & 3;
         int off = -2;
         if (hp < halo_pix) {
-            const int hy = hp / a.WT, hx = hp - hy * a.WT;
+            const int hy = hp / a.WT, sc = hp - hy * a.WT;
+            const int hx = S == 2 ? (sc < WE ? 2 * sc : 2 * (sc - WE) + 1) : sc;      // LDS slot sc of the row holds halo column hx
             const int iy = gy0 * S + a.in_oy + hy, ix = gx0 * S + a.in_ox + hx;
             if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
                 off = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * (a.Cin >> 2) + q * 4 : (iy * a.W + ix) * a.cin_real + q * 4;
@@ -222,7 +227,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     {                                                                                          \
         const char* const hb_ = ((C_) & 1) ? halo1 : halo0;                                    \
         const unsigned tc_ = tap_code(a, T_);                                                  \
-        const int toff_ = ((int)(tc_ & 3u) * a.WT + (int)((tc_ >> 2) & 3u)) * 64;              \
+        const int dx_ = (int)((tc_ >> 2) & 3u);                                                \
+        const int toff_ = ((int)(tc_ & 3u) * a.WT + (S == 2 ? (dx_ == 1 ? WE : dx_ >> 1) : dx_)) * 64; \
         _Pragma("unroll") for (int i = 0; i < WM; ++i) FA[i] = *(const f32x4*)(hb_ + a_off[i] + toff_); \
         _Pragma("unroll") for (int j = 0; j < WN; ++j) FB[j] = *(const f32x4*)((WB_) + b_off[j]); \
     }
