@@ -55,6 +55,9 @@ struct Wino4Args {
 };
 
 constexpr int W4_BN = 64, W4_MG = 9;
+#ifndef W4_NO_TXTC
+#define W4_NO_TXTC 0
+#endif
 
 // Wave w owns the 16 channels w & 3 and HALF of the xi planes (w >> 2: xi 0..2 / 3..5): 27 accumulator tiles, 2 waves per SIMD.
 // (A 12-wave variant - a third of the xi planes per wave, 3 waves per SIMD in the 168-VGPR budget - measured 2 % slower.)
@@ -64,15 +67,20 @@ constexpr int W4_BN = 64, W4_MG = 9;
 // xi plane fall into 64-byte slots m mod 4 of the 256-byte bank window, and the 16-byte sub-slot is rotated by (m >> 2) & 3:
 // the 16 lanes of a fragment read (16 consecutive m) then touch every bank once.  The key of the row ky below is a different
 // function of the lane, so its XOR with the ky = 0 key comes from two packed per-lane tables (2 bits per m-tile and ky).
-template <bool DENSE>
+// TXTC: the row length in x-tiles as a compile-time constant (12 / 24: the 48- and 96-wide layers, i.e. the G body and upsample.2),
+// or 0 = a.TXT at run time.  With it the (ky, xi) part of a fragment read's address is an immediate of the ds_read and "this
+// chunk's V buffer" is one add per fragment offset and chunk: the loop loses its per-read address add (87 -> 38 v_add_u32 per
+// chunk and wave; G body forward 185.1 -> 182.6 us, 227.7 -> 229.4 patches/s).
+template <bool DENSE, int TXTC>
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
+    static_assert(!(DENSE && TXTC), "the constant-row-length form is for the non-dense layout");
     constexpr int NT = 512;                                // threads of the workgroup
     constexpr int NXL = 3;                                 // xi planes per wave
     constexpr int NSLAB = 3 * NXL;                         // weight slabs per wave and chunk: (ky, xl)
     constexpr int NU = 2;                                  // staging items per thread (HT * TXT * 4 <= NU * NT)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int plane = a.TXT * 64;                          // bytes of one xi plane of a V row
-    const int v_row = a.v_row;
+    const int plane = TXTC ? TXTC * 64 : a.TXT * 64;       // bytes of one xi plane of a V row
+    const int v_row = TXTC ? 6 * TXTC * 64 : a.v_row;
     const int v_bytes = a.HT * v_row;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,6 +120,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             ktab2 |= (unsigned)((((m + 2 * a.TXT) >> 2) & 3) ^ k0) << (2 * i + 4);
         } else {
             a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
+            if (TXTC) a_off[i] += xt * 3 * plane;          // the wave's xi half: the rest of (ky, xi) is an immediate
         }
     }
     const int kxor = a.row_key * 16;                       // the key's row term flips with the parity of ky
@@ -209,7 +218,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     };
 #define W4_READ_A(FA, VB, KY, XL, GRP)                                                                   \
     {                                                                                                    \
-        const char* const vb_ = (VB) + (KY) * v_row + xi_of(XL) * plane;                                 \
+        const char* const vb_ = TXTC ? smem + ((KY) * v_row + (XL) * plane)                              \
+                                     : (VB) + (KY) * v_row + xi_of(XL) * plane;                          \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
             FA[i] = *(const f32x4*)(vb_ + a_key((GRP) * 3 + i, KY));                                      \
     }
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
 
 #pragma unroll 1
     for (int c = 0; c < C16; ++c) {
-        char* const vcur = smem + (c & 1) * v_bytes;
+        char* const vcur = smem + (c & 1) * v_bytes;      // (TXTC: the fragment offsets carry the buffer, moved below)
         char* const vnext = smem + ((c & 1) ^ 1) * v_bytes;
         const bool more = c + 1 < C16;
         if (more) stage_load(0, CB + c + 1);               // lands while this chunk computes
@@ -261,6 +271,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             // A third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs.
             if (s == 2 && more) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
             if (s == 6 && more) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
+        }
+        if (TXTC) {
+            const int dv = (c & 1) ? -v_bytes : v_bytes;
+#pragma unroll
+            for (int i = 0; i < W4_MG; ++i) a_off[i] += dv;
         }
         __syncthreads();                                   // V[next] complete and visible; everyone is done with V[cur]
     }
@@ -473,11 +488,16 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     if (p.stack) a.N = 1;
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    if (p.dense) hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
-    else hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
+    const dim3 grid((unsigned)(p.tiles * p.ksplit));
+    if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0>), grid, dim3(512), p.lds, stream, a);
+    else if (p.TXT == 12 && !W4_NO_TXTC) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12>), grid, dim3(512), p.lds, stream, a);
+    else if (p.TXT == 24 && !W4_NO_TXTC) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24>), grid, dim3(512), p.lds, stream, a);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0>), grid, dim3(512), p.lds, stream, a);
     if (p.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, act,
                                               slope, stream);
