@@ -126,11 +126,15 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     const int kxor = a.row_key * 16;                       // the key's row term flips with the parity of ky
 
     // ---- B: this lane's 16 bytes of slab (ky, xi, chunk): wave-uniform slab base (SGPRs) + one per-lane 32-bit byte offset ----
-    const size_t slab_stride = (size_t)a.Cout * 16;        // floats between consecutive chunks of one (ky, xi)
+    // (a buffer load: the slab offset is a scalar operand, so a weight fetch needs no 64-bit vector address arithmetic; the packed
+    // weights are < 4 GB: 18 * Cin * Cout floats)
+    const unsigned slab_bytes = (unsigned)a.Cout * 64;     // bytes between consecutive chunks of one (ky, xi)
     const unsigned b_lane = (unsigned)(((n0 + cb * 16 + r) * 16 + g * 4) * 4);
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (unsigned)((size_t)18 * a.Cin * a.Cout * 4), 0x00020000);
     auto ldb = [&](int ky, int xl, int cc) -> f32x4 {      // cc = absolute chunk
-        const char* const base = (const char*)(a.wp + ((size_t)((ky * 6 + xi_of(xl)) * C16T + cc)) * slab_stride);
-        return *(const f32x4*)(base + b_lane);
+        const unsigned so = (unsigned)((ky * 6 + xi_of(xl)) * C16T + cc) * slab_bytes;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_lane, so, 0));
     };
 
     // ---- staging items: (halo row, x-tile, 4-channel group); six input columns each; NU items per thread --------------------
