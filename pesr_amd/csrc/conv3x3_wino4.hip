@@ -107,6 +107,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     const int C16 = (C16T - CB) < a.chunks_per_split ? (C16T - CB) : a.chunks_per_split;
 
     // ---- A fragment offsets: lane (r, g) reads k-group g of x-tile m = 16 i + r (for an even ky; odd ky: ^ kxor) -------------
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of the dynamic segment (a multiple of 256)
     int a_off[W4_MG];
     unsigned ktab1 = 0, ktab2 = 0;                         // DENSE: (key(ky) ^ key(0)) << 4 for m-tile i at bits [2i + 4, 2i + 6)
 #pragma unroll
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
             if (TXTC) a_off[i] += xt * 3 * plane;          // the wave's xi half: the rest of (ky, xi) is an immediate
         }
+        a_off[i] += (int)lds0;
     }
     const int kxor = a.row_key * 16;                       // the key's row term flips with the parity of ky
 
@@ -220,12 +222,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         }
         return (ky & 1) ? (a_off[i] ^ opaque(kxor)) : a_off[i];
     };
+    // Fragment reads through 32-bit LDS addresses (a_off carries the dynamic-LDS base, added once): written as `smem + offset`
+    // every read paid a v_add_u32 of the base's relocation - a literal 0 hipcc cannot fold (36 per chunk and wave).
 #define W4_READ_A(FA, VB, KY, XL, GRP)                                                                   \
     {                                                                                                    \
-        const char* const vb_ = TXTC ? smem + ((KY) * v_row + (XL) * plane)                              \
-                                     : (VB) + (KY) * v_row + xi_of(XL) * plane;                          \
+        const unsigned vb_ = TXTC ? (unsigned)((KY) * v_row + (XL) * plane)                              \
+                                  : (unsigned)((VB) - smem) + (unsigned)((KY) * v_row + xi_of(XL) * plane); \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
-            FA[i] = *(const f32x4*)(vb_ + a_key((GRP) * 3 + i, KY));                                      \
+            FA[i] = *(const __attribute__((address_space(3))) f32x4*)(size_t)((unsigned)a_key((GRP) * 3 + i, KY) + vb_); \
     }
 #define W4_MFMA(FA, FB, XL, GRP)                                                                         \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
