@@ -53,8 +53,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in _sources():
         obj = os.path.join(build_dir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden",
-               "-Wno-unused-result", "-c", src, "-o", obj]
+        # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs.  Left to its heuristic hipcc parks the accumulators of the smaller
+        # kernels (the 256-thread direct-conv configurations above all) in AGPRs and moves them out and back around every loop
+        # iteration: v_accvgpr_read / _write for each accumulator register, each write waiting for the MFMAs it follows.
+        cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden", "-mllvm",
+               "-amdgpu-mfma-vgpr-form=1", "-Wno-unused-result", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
