@@ -506,8 +506,15 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
 #define X4_STORE_STEP 3
 #endif
 
+    // Two nested loops - strips outside, a strip's segments inside - instead of one loop over segments with a cold "next strip"
+    // branch: the staging registers' value for the next iteration then has ONE definition inside the hot loop (the load_stage
+    // below, issued unconditionally), where it had two merging at the loop header - hipcc resolved that merge with s_waitcnt
+    // vmcnt(0) + 30 register copies at the end of every segment, i.e. the loads had half a segment to arrive, not a whole one.
+    int seg = seg_begin;
 #pragma unroll 1
-    for (int seg = seg_begin; seg < seg_end; ++seg) {
+    for (;;) {
+#pragma unroll 1
+      for (;;) {
         const int par = (seg - seg_begin) & 1;
         const bool more = seg + 1 < seg_end;
         const bool cont = more && row + 2 < a.H;
@@ -544,7 +551,8 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
                 __builtin_amdgcn_sched_barrier(0);
                 if (cont) {
                     store_stage(base + 4, par ^ 1);
-                    if (cont2) load_stage(img, row + 5, row + 4);
+                    (void)cont2;
+                    load_stage(img, row + 5, row + 4);      // (rows past the image or the slice read zeros through a zero-size descriptor)
                 }
             }
             X4_FENCE();
@@ -554,19 +562,25 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
 #undef X4_READ
 #undef X4_MFMA
 #undef X4_FENCE
-        if (cont) {
-            __syncthreads();
-            base += 2; if (base >= G4_RING) base -= G4_RING;
-            row += 2;
-        } else if (more) {
-            __syncthreads();
-            seg_coords(seg + 1, img, xs, row);
-            set_strip(xs);
-            stage_strip_start(img, row, par ^ 1);
-            if (seg + 2 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
-            __syncthreads();
-            base = 0;
-        }
+        if (!cont) break;
+        __syncthreads();
+        base += 2; if (base >= G4_RING) base -= G4_RING;
+        row += 2;
+        ++seg;
+      }
+      if (seg + 1 >= seg_end) break;
+      // the slice continues in the next strip: its first segment is staged synchronously
+      {
+        const int par = (seg - seg_begin) & 1;
+        __syncthreads();
+        seg_coords(seg + 1, img, xs, row);
+        set_strip(xs);
+        stage_strip_start(img, row, par ^ 1);
+        if (seg + 2 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
+        __syncthreads();
+        base = 0;
+        ++seg;
+      }
     }
     __syncthreads();
 
