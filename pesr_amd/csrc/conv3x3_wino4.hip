@@ -256,8 +256,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     for (int c = 0; c < C16; ++c) {
         char* const vcur = smem + (c & 1) * v_bytes;      // (TXTC: the fragment offsets carry the buffer, moved below)
         char* const vnext = smem + ((c & 1) ^ 1) * v_bytes;
-        const bool more = c + 1 < C16;
-        if (more) stage_load(0, CB + c + 1);               // lands while this chunk computes
+        // No branch in the loop: the last chunk "prefetches" itself again (loads, transforms and LDS stores nobody consumes).  With
+        // the prefetch under `if (more)` the staging registers and weight fragments had two definitions merging at the loop header,
+        // and hipcc could not count the outstanding loads exactly.
+        const int cn = CB + (c + 1 < C16 ? c + 1 : c);
+        stage_load(0, cn);                                 // lands while this chunk computes
         W4_READ_A(fa[0], vcur, 0, 0, 0)
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {                  // slab s = (ky, xl)
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             // weight slab s + 2 (of this chunk, or the first ones of the next)
             {
                 if (s + 2 < NSLAB) fb[(s + 2) % 3] = ldb((s + 2) / NXL, (s + 2) % NXL, CB + c);
-                else if (c + 1 < C16) fb[(s + 2) % 3] = ldb(0, s + 2 - NSLAB, CB + c + 1);
+                else fb[(s + 2) % 3] = ldb(0, s + 2 - NSLAB, cn);
             }
 #pragma unroll
             for (int grp = 0; grp < 3; ++grp) {
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             // A third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs.
-            if (s == 2 && more) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
-            if (s == 6 && more) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
+            if (s == 2) { stage_store(0, vnext); stage_load(1, cn); __builtin_amdgcn_sched_barrier(0); }
+            if (s == 6) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
         }
         if (TXTC) {
             const int dv = (c & 1) ? -v_bytes : v_bytes;
