@@ -411,8 +411,60 @@ static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
 }
 }  // namespace
 
+// The same reduction with coalesced output (round 3): one workgroup = one output channel x up to 256 input channels, NINE waves -
+// wave t sums tap t's partial rows (lane = 4 consecutive ci: one KiB per slab and wave, `split` loads in slab order, 8 in flight) and
+// parks its 4 sums in LDS at [ci][t]; then the 576 threads write the block's 9 * CIB floats of dw[o][ci0 ..][0 .. 8] - ONE contiguous
+// run of the OIHW tensor - as 16-byte stores.  (The kernel above writes four scattered 4-byte values per thread: 8.4 us per G-body
+// layer for 21 MB, 2.5 TB/s.)  Same summation order, bit-identical results.
+__global__ __launch_bounds__(576) void wgrad_reduce_rows_kernel(const float* __restrict__ slab, float* __restrict__ dw, int split, int Cout,
+                                                                int Cin, int CIB, float alpha, int ps, const float* __restrict__ bias_part,
+                                                                int bias_rows, float* __restrict__ db, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float ob[256 * 9];
+    const int tid = threadIdx.x, lane = tid & 63, t = tid >> 6;            // wave = tap
+    const int blocks_ci = Cin / CIB;
+    const int p = blockIdx.x / blocks_ci, ci0 = (blockIdx.x - p * blocks_ci) * CIB;
+    const int C = Cout >> 2;
+    int o = p;
+    if (ps) { const int sub = p / C, cc = p - sub * C; o = 4 * cc + sub; }
+    if (bias_part && ci0 == 0 && tid == 0) {
+        double sb = 0.0;
+        for (int k = 0; k < bias_rows; ++k) sb += (double)bias_part[(size_t)k * Cout + p];
+        db[o] = alpha * (float)sb + (accumulate ? db[o] : 0.f);
+    }
+    if (lane * 4 < CIB) {
+        const size_t total4 = (size_t)9 * Cout * Cin / 4;
+        const f32x4* src = (const f32x4*)slab + (((size_t)t * Cout + p) * Cin + ci0) / 4 + lane;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= split; k += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * total4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < split; ++k) s += src[(size_t)k * total4];
+        float* q = ob + (lane * 4) * 9 + t;
+        q[0] = alpha * s.x; q[9] = alpha * s.y; q[18] = alpha * s.z; q[27] = alpha * s.w;
+    }
+    __syncthreads();
+    const int n4 = CIB * 9 / 4;                                            // 16-byte pieces of the block's contiguous output run
+    f32x4* dst = (f32x4*)(dw + ((size_t)o * Cin + ci0) * 9);
+    for (int j = tid; j < n4; j += 576) {
+        f32x4 v = ((const f32x4*)ob)[j];
+        if (accumulate) v += dst[j];
+        dst[j] = v;
+    }
+}
+
 int pesr_wgrad_reduce_launch(const float* slab, float* dw, int split, int Cout, int Cin, float alpha, int ps, const float* bias_part,
                              int bias_rows, float* db, int accumulate, hipStream_t stream) {
+    if (Cin % 4 == 0 && (Cin % 256 == 0 || Cin <= 256)) {      // coalesced-output form: blocks of CIB = min(Cin, 256) input channels
+        const int CIB = Cin < 256 ? Cin : 256;
+        hipLaunchKernelGGL(wgrad_reduce_rows_kernel, dim3((unsigned)(Cout * (Cin / CIB))), dim3(576), 0, stream, slab, dw, split, Cout, Cin, CIB,
+                           alpha, ps, bias_part, bias_rows, db, accumulate);
+        return pesr_launch_status();
+    }
     const long total = 9L * Cout * Cin;
     const int rgrid = (int)((total / 4 + 255) / 256 < 2048 ? (total / 4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, slab, dw, split, Cout, Cin, alpha, ps, bias_part, bias_rows, db,
@@ -475,11 +527,8 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     else rc = p.rows == 2 ? PESR_WG(2, 24, 2) : PESR_WG(2, 24, 1);
 #undef PESR_WG
     if (rc) return rc;
-    const long total = 9L * Cout * Cin;
-    const int rgrid = (int)((total / 4 + 255) / 256 < 2048 ? (total / 4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in,
-                       fuse_bias ? (const float*)a.bias_part : (const float*)nullptr, (int)bias_rows, db, accumulate);
-    rc = pesr_launch_status();
+    rc = pesr_wgrad_reduce_launch((const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in,
+                                  fuse_bias ? (const float*)a.bias_part : (const float*)nullptr, (int)bias_rows, db, accumulate, stream);
     if (rc || !db || fuse_bias) return rc;
     float* part = (float*)((char*)ws + p.slab_bytes);
     return pesr_bias_grad_launch(dy, db, (long)N * a.OH * a.OW, Cout, a.OW, alpha, ps_in, part, ws_bytes - p.slab_bytes, stream);
