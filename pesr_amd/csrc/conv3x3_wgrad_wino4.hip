@@ -385,8 +385,10 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
 
     // ---- staging roles: threads 0..191 (waves 0..2) the 192 V items (2 rows x 12 x-tiles x 8 ci groups, six input columns each),
     //      threads 192..575 (waves 3..8) the 384 dM items (2 rows x 12 x-tiles x 16 co groups, four columns each); one register set
-    const bool v_thr = tid < 192, d_thr = tid >= 192 && tid < 576;
-    const int vi = v_thr ? tid : 0;
+    //      waves 9..11 idle in the loop; at a strip start they take the V role for the strip's SECOND pair of halo rows, so that its
+    //      four halo rows arrive in one load round instead of two dependent ones
+    const bool v_thr = tid < 192 || tid >= 576, d_thr = tid >= 192 && tid < 576;
+    const int vi = tid < 192 ? tid : (tid >= 576 ? tid - 576 : 0);
     const int v_rr = vi / 96, vt = (vi % 96) >> 3, vc4 = vi & 7;
     const int di = d_thr ? tid - 192 : 0;
     const int d_rr = di / 192, dt = (di % 192) >> 4, dc4 = di & 15;
@@ -426,8 +428,8 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     };
     // (descriptors wave-uniform, as above: the V descriptor spans the two rows that mix inside wave 1, lanes add their row's
     // pitch; the dM rows change at thread 384 = a wave boundary)
-    auto load_stage = [&](int img, int v_iy0, int d_oy0) {   // V rows v_iy0, v_iy0 + 1; dM rows d_oy0, d_oy0 + 1
-        if (wave < 3) {
+    auto load_stage = [&](int img, int v_iy0, int d_oy0, const bool hi = false) {   // V rows v_iy0, v_iy0 + 1; dM rows d_oy0, d_oy0 + 1
+        if (hi ? wave >= 9 : wave < 3) {                                              // (hi: the V role on waves 9..11, no dM role)
             const float* const rowp = a.x + ((long)img * a.H + v_iy0) * ((long)a.W * a.Cin);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0, 2 * x_row_bytes, 0x00020000);
             const int iy = v_iy0 + v_rr;
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
 #pragma unroll
             for (int j = 0; j < 6; ++j)
                 st[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? off[j] + (unsigned)v_rr * x_row_bytes : 0x80000000u, 0, 0);
-        } else if (wave < 9) {
+        } else if (!hi && wave >= 3 && wave < 9) {
             const int oy = d_oy0 + d_rr;
             const bool row_ok = oy < a.H;
             const int ry = row_ok ? oy : 0;
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
             for (int j = 0; j < 4; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, 0);
         }
     };
-    auto store_stage = [&](int v_slot0, int d_buf) {         // V rows -> ring slots v_slot0 + v_rr (mod 6); dM rows -> buffer d_buf
-        if (wave < 3) {
+    auto store_stage = [&](int v_slot0, int d_buf, const bool hi = false) {   // V rows -> ring slots v_slot0 + v_rr (mod 6); dM rows -> buffer d_buf
+        if (hi ? wave >= 9 : wave < 3) {
             const f32x4 d0 = __builtin_bit_cast(f32x4, st[0]), d1 = __builtin_bit_cast(f32x4, st[1]), d2 = __builtin_bit_cast(f32x4, st[2]),
                         d3 = __builtin_bit_cast(f32x4, st[3]), d4 = __builtin_bit_cast(f32x4, st[4]), d5 = __builtin_bit_cast(f32x4, st[5]);
             int sl = v_slot0 + v_rr; if (sl >= G4_RING) sl -= G4_RING;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
             *(f32x4*)(p + 3 * X4_VPLANE) = t3 + 2.0f * t4;
             *(f32x4*)(p + 4 * X4_VPLANE) = t3 - 2.0f * t4;
             *(f32x4*)(p + 5 * X4_VPLANE) = 4.0f * d1 + (d5 - 5.0f * d3);
-        } else if (wave < 9) {
+        } else if (!hi && wave >= 3 && wave < 9) {
             const f32x4 g0 = __builtin_bit_cast(f32x4, st[0]), g1 = __builtin_bit_cast(f32x4, st[1]), g2 = __builtin_bit_cast(f32x4, st[2]),
                         g3 = __builtin_bit_cast(f32x4, st[3]);
             float* p = dmbuf + (d_buf * 2 + d_rr) * X4_DROW + d_pos;
@@ -480,8 +482,9 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
         xs = strip - img * a.segs_x;
     };
     auto stage_strip_start = [&](int img, int row, int buf) {   // halo rows row-1 .. row+2 -> slots 0 .. 3; dM(row, row+1) -> buf
-        load_stage(img, row - 1, row); store_stage(0, buf);      // V rows row-1, row  + both dM rows
-        if (wave < 3) { load_stage(img, row + 1, 0); store_stage(2, buf); }   // V rows row+1, row+2
+        load_stage(img, row - 1, row);                            // waves 0..2: V rows row-1, row; waves 3..8: both dM rows
+        load_stage(img, row + 1, 0, true);                        // waves 9..11: V rows row+1, row+2 - the same load round
+        store_stage(0, buf); store_stage(2, buf, true);
     };
 
     // ---- fragment addresses (floats): lane (c32, ks) reads x-tile 2q + ks, channel c32 of its tile ---------------------------
