@@ -52,7 +52,7 @@ struct Wino4Args {
     int stack;          // 0, or H + 1: the N images are tiled as ONE image of N * (H + 1) - 1 rows, a zero row between neighbours
     int stack_n;        //   (that row is the bottom halo of one image and the top halo of the next); N above is then 1
     int v_row;          // bytes of one V row: 6 * TXT * 64, plus the pad of the dense layout
-};
+    };
 
 constexpr int W4_BN = 64, W4_MG = 9;
 #ifndef W4_NO_TXTC
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     constexpr int NSLAB = 3 * NXL;                         // weight slabs per wave and chunk: (ky, xl)
     constexpr int NU = 2;                                  // staging items per thread (HT * TXT * 4 <= NU * NT)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int plane = TXTC ? TXTC * 64 : a.TXT * 64;       // bytes of one xi plane of a V row
+    const int TXTv = TXTC ? TXTC : a.TXT;                   // (a compile-time row length also turns the index divisions below into multiplies)
+    const int plane = TXTv * 64;       // bytes of one xi plane of a V row
     const int v_row = TXTC ? 6 * TXTC * 64 : a.v_row;
     const int v_bytes = a.HT * v_row;
 
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
-    const int gy0 = ty * a.TR, gt0 = tx * a.TXT;          // first output row / first x-tile of the tile
+    const int gy0 = ty * a.TR, gt0 = tx * TXTv;          // first output row / first x-tile of the tile
     const int n0 = nt * W4_BN;
     const int C16T = a.Cin >> 4;
     const int CB = ks * a.chunks_per_split;                // this workgroup's chunk range [CB, CB + C16)
@@ -110,21 +111,25 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of the dynamic segment (a multiple of 256)
     int a_off[W4_MG];
     unsigned ktab1 = 0, ktab2 = 0;                         // DENSE: (key(ky) ^ key(0)) << 4 for m-tile i at bits [2i + 4, 2i + 6)
+    // (filled in behind the prologue's loads: nothing needs the offsets before the first fragment read, and the index arithmetic
+    // then runs under the first chunk's load latency instead of in front of it)
+    auto compute_a_off = [&]() {
 #pragma unroll
-    for (int i = 0; i < W4_MG; ++i) {
-        const int m = i * 16 + r;
-        const int trow = m / a.TXT, txt = m - trow * a.TXT;
-        if (DENSE) {
-            const int k0 = (m >> 2) & 3;
-            a_off[i] = trow * v_row + txt * 64 + ((g ^ k0) & 3) * 16;
-            ktab1 |= (unsigned)((((m + a.TXT) >> 2) & 3) ^ k0) << (2 * i + 4);
-            ktab2 |= (unsigned)((((m + 2 * a.TXT) >> 2) & 3) ^ k0) << (2 * i + 4);
-        } else {
-            a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
-            if (TXTC) a_off[i] += xt * 3 * plane;          // the wave's xi half: the rest of (ky, xi) is an immediate
+        for (int i = 0; i < W4_MG; ++i) {
+            const int m = i * 16 + r;
+            const int trow = m / TXTv, txt = m - trow * TXTv;
+            if (DENSE) {
+                const int k0 = (m >> 2) & 3;
+                a_off[i] = trow * v_row + txt * 64 + ((g ^ k0) & 3) * 16;
+                ktab1 |= (unsigned)((((m + TXTv) >> 2) & 3) ^ k0) << (2 * i + 4);
+                ktab2 |= (unsigned)((((m + 2 * TXTv) >> 2) & 3) ^ k0) << (2 * i + 4);
+            } else {
+                a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
+                if (TXTC) a_off[i] += xt * 3 * plane;          // the wave's xi half: the rest of (ky, xi) is an immediate
+            }
+            a_off[i] += (int)lds0;
         }
-        a_off[i] += (int)lds0;
-    }
+    };
     const int kxor = a.row_key * 16;                       // the key's row term flips with the parity of ky
 
     // ---- B: this lane's 16 bytes of slab (ky, xi, chunk): wave-uniform slab base (SGPRs) + one per-lane 32-bit byte offset ----
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
 
     // ---- staging items: (halo row, x-tile, 4-channel group); six input columns each; NU items per thread --------------------
     const float* const x_img = a.x + (size_t)img * a.H * a.W * a.Cin;    // stacked: img == 0, rows run over all images
-    const int n_items = a.HT * a.TXT * 4;
+    const int n_items = a.HT * TXTv * 4;
     const int Cq = a.Cin >> 2;
     // Out-of-image columns (and whole halo rows) are fetched at offset 2^31, beyond the buffer descriptor's range: the load
     // returns zeros, no masking afterwards.  (Raw buffer: the range check is on the VGPR offset; images are < 2 GB - w4_plan.)
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     for (int u = 0; u < NU; ++u) {
         const int it = tid + u * NT;
         const int q = it & 3, rest = it >> 2;
-        const int hrow = rest / a.TXT, txt = rest - hrow * a.TXT;
+        const int hrow = rest / TXTv, txt = rest - hrow * TXTv;
         int iy = gy0 - 1 + hrow;
         const int ix0 = 4 * (gt0 + txt) - 1;
         bool item_ok = it < n_items && iy >= 0 && iy < a.H;
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
             st_off[u][j] = ok ? (unsigned)((pix + q * 4) * 4) : 0x80000000u;
         }
-        const int skey = DENSE ? ((hrow * a.TXT + txt) >> 2) : ((txt >> 1) ^ (a.row_key * (hrow & 1)));
+        const int skey = DENSE ? ((hrow * TXTv + txt) >> 2) : ((txt >> 1) ^ (a.row_key * (hrow & 1)));
         st_dst[u] = it < n_items ? hrow * v_row + txt * 64 + ((q ^ skey) & 3) * 16 : -1;
     }
     const __amdgpu_buffer_rsrc_t x_rsrc =
@@ -245,6 +250,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         for (int j = 0; j < 6; ++j) sy[j] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_off[1][j], so, 0);
         fb[0] = ldb(0, 0, CB);
         fb[1] = ldb(0, 1, CB);
+        compute_a_off();
         stage_store(0, smem);
 #pragma unroll
         for (int j = 0; j < 6; ++j) sx[j] = sy[j];
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         for (int e = 0; e < 6; ++e) {
             const int i = ib + (e >> 1), k = e & 1;
             const int m = i * 16 + r;
-            const int trow = m / a.TXT, txt = m - trow * a.TXT;
+            const int trow = m / TXTv, txt = m - trow * TXTv;
             int oy = gy0 + trow;
             const int ox = 4 * (gt0 + txt) + 2 * xt + k;
             ok[e] = oy < a.H && ox < a.W;
