@@ -214,6 +214,8 @@ WINO4_CASES = [
     (3, 12, 12, 128, 64),     # stacked, no split-K, odd image count
     (5, 6, 8, 64, 64),        # stacked, 2 x-tiles per row
     (4, 9, 20, 64, 128),      # stacked candidate with 5-x-tile rows (tile rows of 4 / 6 x-tiles: ragged in x as well)
+    (2, 6, 96, 64, 64),       # 24-x-tile rows, 6 rows per tile: the kernel's compile-time-row-length form for 96-wide layers
+    (1, 12, 192, 64, 64),     # 48-x-tile rows (dense layout), 3 rows per tile
 ]
 
 
