@@ -247,3 +247,26 @@ def test_test_entrypoint_in_bf16_mode(tmp_path, monkeypatch, bf16_mode):
         want = OI.tensor_to_img(OM.generator_forward(sd, x, 2, 0.1)).astype(np.int32)
     assert got.shape == want.shape == (96, 144, 3)
     assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01, (np.abs(got - want).max(), (got != want).mean())
+
+
+def test_bf16_random_shape_sweep():
+    """Random shapes through the bf16 forward / input-gradient / weight-gradient kernels (every tile shape the planner can pick,
+    ragged rows and columns, 64- / 128- / 256-channel workgroups) against the rounded-operand oracle."""
+    import random
+    from pesr_amd import ops
+    rng = random.Random(29)
+    for it in range(12):
+        N = rng.choice([1, 2, 3]); H = rng.randint(1, 40); W = rng.choice([4, 12, 16, 20, 24, 36, 48, 50, 72, 96])
+        Cin = rng.choice([32, 64, 96, 128]); Cout = rng.choice([64, 128, 192, 256])
+        x = _rand(N, Cin, H, W, seed=1500 + it); w = _rand(Cout, Cin, 3, 3, seed=1600 + it, scale=0.1); b = _rand(Cout, seed=1700 + it)
+        ref = O.conv3x3_bf16(x, w, b)
+        y = ops.conv3x3_fwd(_nhwc(x), ops.pack_conv3x3_bf16(w.cuda(), 0), b.cuda(), Cout)
+        _close(_nchw(y), ref, 1e-5)
+        dy = _rand(N, Cout, H, W, seed=1800 + it)
+        dx_ref, dw_ref, db_ref = O.conv3x3_bf16_grads(x, w, dy)
+        if Cout % 32 == 0 and Cin % 64 == 0:
+            dx = ops.conv3x3_dgrad(_nhwc(dy), ops.pack_conv3x3_bf16(w.cuda(), 1), (N, H, W, Cin))
+            _close(_nchw(dx), dx_ref, 1e-5)
+        if W % 48 == 0 and Cin % 64 == 0 and Cout % 128 == 0:
+            dw, db = ops.conv3x3_wgrad_bf16(_nhwc(x), _nhwc(dy))
+            _close(dw.cpu(), dw_ref, 1e-5); _close(db.cpu(), db_ref, 1e-5)
