@@ -270,3 +270,25 @@ def test_bf16_random_shape_sweep():
         if W % 48 == 0 and Cin % 64 == 0 and Cout % 128 == 0:
             dw, db = ops.conv3x3_wgrad_bf16(_nhwc(x), _nhwc(dy))
             _close(dw.cpu(), dw_ref, 1e-5); _close(db.cpu(), db_ref, 1e-5)
+
+
+def test_bf16_determinism_race_screen():
+    """The bf16 kernels hand staged data between waves by counted waits and barriers only, like the fp32 ones: a misplaced wait
+    shows up as rare run-to-run differences.  Every sum has a fixed order, so repeated launches must give identical bits - the
+    256- / 128- / 64-channel workgroups of the forward kernel, a fused-PixelShuffle shape and the weight gradient's split-K."""
+    from pesr_amd import ops
+    shapes = [(16, 48, 48, 256, 256, False), (2, 24, 24, 256, 1024, True), (4, 48, 48, 128, 128, False), (4, 96, 96, 64, 64, False)]
+    for (N, H, W, Cin, Cout, ps) in shapes:
+        x = _nhwc(_rand(N, Cin, H, W, seed=21)); w = _rand(Cout, Cin, 3, 3, seed=22, scale=0.05).cuda()
+        dy = _nhwc(_rand(N, Cout // 4 if ps else Cout, 2 * H if ps else H, 2 * W if ps else W, seed=23))
+        wf, wd = ops.pack_conv3x3_bf16(w, 0, ps=ps), ops.pack_conv3x3_bf16(w, 1, ps=ps)
+        fwd = lambda: ops.conv3x3_fwd(x, wf, None, Cout, act=ops.ACT_RELU, ps_out=ps)
+        dgr = lambda: ops.conv3x3_dgrad(dy, wd, (N, H, W, Cin), mask=x, ps_in=ps)
+        wgr = (lambda: ops.conv3x3_wgrad_bf16(x, dy, ps_in=ps)) if (Cout % 128 == 0 and W % 48 == 0) else None
+        y0, d0 = fwd(), dgr()
+        g0 = wgr() if wgr else None
+        for _ in range(12):
+            assert torch.equal(fwd(), y0) and torch.equal(dgr(), d0)
+            if wgr:
+                g, b = wgr()
+                assert torch.equal(g, g0[0]) and torch.equal(b, g0[1])
