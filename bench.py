@@ -142,6 +142,18 @@ def cpu_baseline(args, state, batch):
     from oracle import bf16 as OB
     with OB.enabled(args.precision == "bf16"):     # (bf16 row: the parity step restates the bf16 mode; the timed steps below are
         first = step(st, lr, hr)                   #  the reference's fp32 arithmetic either way)  warm-up = parity step
+        first = {k: float(v) for k, v in first.items()}
+        if args.precision == "bf16":
+            # The bf16 mode's own noise floor at this configuration: a difference of one fp32 ulp upstream can flip a bf16 rounding
+            # downstream (2^-8 of that operand), so two exact-arithmetic-equivalent evaluations differ by far more than fp32
+            # rounding.  Measured, not assumed: the same step with every weight moved one ulp up / one ulp down.
+            floor = 0.0
+            for direction in (float("inf"), -float("inf")):
+                mv = lambda sd: {k: (torch.nextafter(v, torch.full_like(v, direction)) if v.is_floating_point() else v.clone())
+                                 for k, v in sd.items()}
+                alt = step(OS.TrainState(mv(g_sd), mv(d_sd) if d_sd else None, v_sd, cfg), lr, hr)
+                floor = max([floor] + [abs(float(alt[k]) - first[k]) / max(abs(first[k]), 1e-12) for k in first])
+            first["_noise_floor"] = floor
     times = []
     for _ in range(args.cpu_steps):
         t0 = time.perf_counter()
@@ -383,13 +395,18 @@ def main():
     if want_cpu:
         out["cpu_baseline"], ref0 = cpu_baseline(args, state0, (batches[0][0].cpu(), batches[0][1].cpu()))
         got0 = first_log
+        floor = ref0.pop("_noise_floor", None)
         rel = {k: abs(got0[k] - ref0[k]) / max(abs(ref0[k]), 1e-12) for k in ref0 if abs(ref0[k]) > 0 or abs(got0[k]) > 0}
         worst = max(rel.values()) if rel else 0.0
-        ptol = 5e-4 if bf16 else 5e-5      # bf16 row: against the oracle's restatement of the bf16 mode (oracle/bf16.py)
+        # bf16 row: against the oracle's restatement of the bf16 mode (oracle/bf16.py), to 5e-4 or three times the mode's MEASURED
+        # noise floor at this configuration (the oracle's own losses with every weight moved by one fp32 ulp), whichever is larger
+        ptol = max(5e-4, 3.0 * floor) if bf16 else 5e-5
         out["parity_check"] = {"what": "losses of GPU step 0 vs the CPU oracle's step from the same initial weights and batch "
                                        "(benchmarked configuration and kernel dispatch)",
                                "max_rel_loss_err": worst, "tol": ptol, "ok": bool(worst <= ptol),
                                "gpu": got0, "cpu_oracle": ref0}
+        if floor is not None:
+            out["parity_check"]["oracle_one_ulp_noise_floor"] = floor
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -125,6 +125,13 @@ int pesr_pack_conv3x3_bf16(const float* w, void* w_packed, int Cout, int Cin, in
 int pesr_conv3x3_bf16(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask, float* y,
                       int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in,
                       void* stream);
+/* Stride-2 forward in the bf16 mode (the Discriminator's down-sampling convs, reference model/pesr.py:56-64: Conv(k=3, stride=2,
+ * padding=1)): x [N][H][W][Cin] -> y [N][(H-1)/2+1][(W-1)/2+1][Cout], skip / mask shaped like y; weights packed by
+ * pesr_pack_conv3x3_bf16 mode 0 (the stride-1 forward's packing).  Its input and weight gradients stay on the fp32 kernels.
+ * pesr_conv3x3_bf16_s2_score: as above, but half of min_wgs workgroups already qualify (these layers are small). */
+int pesr_conv3x3_bf16_s2_score(int N, int H, int W, int Cin, int Cout, int min_wgs);
+int pesr_conv3x3_bf16_s2(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask, float* y,
+                         int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, void* stream);
 /* Weight / bias gradient of the same conv in the bf16 mode: dw = alpha * sum bf16(dy) * bf16(x) (fp32 sums; fixed-order split-K
  * reduce, bit-reproducible), db = alpha * sum dy (fp32, un-rounded).  Same tensors and ps_in / accumulate meaning as
  * pesr_conv3x3_wgrad.  Stride 1, W % 48 == 0, Cin % 64 == 0, Cout % 128 == 0 (Cout % 512 == 0 with ps_in); workspace_bytes

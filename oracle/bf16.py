@@ -4,6 +4,7 @@ The reference (thangvubk/PESR) is fp32 only, so this mode has no reference file 
 definition (pesr_amd/csrc/conv3x3_bf16.hip, conv3x3_wgrad_bf16.hip, pesr_amd/ops.py bf16_eligible / wgrad_bf16_eligible):
     * a stride-1 3x3 conv whose shape the bf16 kernels cover rounds BOTH operands of every product to bfloat16 (round to nearest
       even) and sums the exact products in fp32:   y  = conv(r(x), r(w)) + b
+      (a stride-2 conv likewise in its FORWARD pass where the stride-2 form of the kernel covers it; its gradients stay fp32)
     * its input gradient, where the (transposed) shape is covered:   dx = conv_T(r(dy), r(w))
     * its weight gradient, where THAT kernel covers the shape:       dw = corr(r(x), r(dy));   db = sum(dy) always un-rounded
     * every other op, and every conv the rules below reject, is the fp32 arithmetic of oracle/model.py.
@@ -63,11 +64,40 @@ def conv_score(N, H, W, Cin, Cout, min_wgs):
     return int(1000.0 * eff) if tiles >= min_wgs else 0
 
 
+def conv_s2_score(N, H, W, Cin, Cout, min_wgs):
+    """conv3x3_bf16.hip b16_plan_s2 (H, W: the INPUT's size): 144 output pixels per tile, a (2 TR + 1) x (2 TW + 1) halo of at most
+    640 pixels, 128 (64) output channels per workgroup; half of min_wgs workgroups qualify."""
+    if N < 1 or H < 2 or W < 2 or Cin % 32 or Cin < 32 or Cout % 64 or H * W * Cin * 4 >= 1 << 31:
+        return 0
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    best = None
+    for TW in range(1, 145):
+        if 144 % TW:
+            continue
+        TR = 144 // TW
+        HT, WT = 2 * TR + 1, 2 * TW + 1
+        if HT * WT * 8 > 5120:
+            continue
+        cover = _cdiv(OH, TR) * TR * _cdiv(OW, TW) * TW
+        score = cover * 8192 + (4096 if TW % 16 else 0) + HT * WT
+        if best is None or score < best[0]:
+            best = (score, TR, TW)
+    if best is None:
+        return 0
+    _, TR, TW = best
+    bn = 128 if Cout % 128 == 0 else 64
+    tiles = N * _cdiv(OH, TR) * _cdiv(OW, TW) * (Cout // bn)
+    eff = OH * OW / (_cdiv(OH, TR) * TR * _cdiv(OW, TW) * TW)
+    return int(1000.0 * eff) if tiles >= (min_wgs + 1) // 2 else 0
+
+
 def conv_eligible(N, H, W, Cin, Cout, stride=1, ps_out=False, ps_in=False):
-    """pesr_amd.ops.bf16_eligible for the problem the kernel runs (an input gradient: Cin / Cout swapped)."""
+    """pesr_amd.ops.bf16_eligible for the problem the kernel runs (an input gradient: Cin / Cout swapped; stride 2: forward only)."""
     bn = 256 if Cout % 256 == 0 else (128 if Cout % 128 == 0 else 64)
-    if stride != 1 or Cin % 32 or Cout % 64 or (ps_out and Cout % (4 * bn)) or (ps_in and Cin % 128):
+    if stride not in (1, 2) or Cin % 32 or Cout % 64 or (ps_out and Cout % (4 * bn)) or (ps_in and Cin % 128):
         return False
+    if stride == 2:
+        return not (ps_out or ps_in) and conv_s2_score(N, H, W, Cin, Cout, MIN_WGS) >= 780
     return conv_score(N, H, W, Cin, Cout, MIN_WGS) >= 780
 
 
@@ -111,7 +141,7 @@ def conv3x3(x, w, b=None, stride=1, ps=False):
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     f_fwd = conv_eligible(N, H, W, Cin, Cout, stride, ps_out=ps)
-    f_dgrad = conv_eligible(N, H, W, Cout, Cin, stride, ps_in=ps)
+    f_dgrad = stride == 1 and conv_eligible(N, H, W, Cout, Cin, 1, ps_in=ps)
     f_wgrad = wgrad_eligible(N, H, W, Cin, Cout, stride, ps_in=ps)
     if not (f_fwd or f_dgrad or f_wgrad):
         return F.conv2d(x, w, b, stride=stride, padding=1)

@@ -36,10 +36,10 @@ def round_bf16(t):
     return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
 
 
-def conv3x3_bf16(x, w, b=None):
-    """model/basic.py:4-7 `Conv` (stride 1) as the bf16 mode computes it: BOTH operands of every product rounded to bf16, the
+def conv3x3_bf16(x, w, b=None, stride=1):
+    """model/basic.py:4-7 `Conv` as the bf16 mode computes its forward: BOTH operands of every product rounded to bf16, the
     products (exact in fp32) summed - here in float64, so the kernel is checked to fp32-accumulation accuracy - bias in fp32."""
-    y = F.conv2d(round_bf16(x).double(), round_bf16(w).double(), None, padding=1).float()
+    y = F.conv2d(round_bf16(x).double(), round_bf16(w).double(), None, stride=stride, padding=1).float()
     return y if b is None else y + b.view(1, -1, 1, 1)
 
 

@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 9; }
+PESR_API int pesr_abi_version(void) { return 10; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -208,6 +208,13 @@ PESR_API int pesr_conv3x3_bf16(const float* x, const void* w_packed, const float
                                int ps_in, void* stream) {
     return pesr_conv3x3_bf16_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, ps_out, ps_in,
                                     (hipStream_t)stream);
+}
+PESR_API int pesr_conv3x3_bf16_s2_score(int N, int H, int W, int Cin, int Cout, int min_wgs) {
+    return pesr_conv3x3_bf16_s2_score_impl(N, H, W, Cin, Cout, min_wgs);
+}
+PESR_API int pesr_conv3x3_bf16_s2(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask,
+                                  float* y, int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, void* stream) {
+    return pesr_conv3x3_bf16_s2_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, (hipStream_t)stream);
 }
 PESR_API size_t pesr_conv3x3_wgrad_bf16_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
     return pesr_conv3x3_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout);

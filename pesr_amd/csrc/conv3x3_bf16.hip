@@ -1,4 +1,4 @@
-// 3x3 stride-1 convolution on the bf16 MFMA (v_mfma_f32_16x16x32_bf16), gfx950: the OPTIONAL reduced-precision mode.
+// 3x3 convolution (stride 1; stride 2 forward) on the bf16 MFMA (v_mfma_f32_16x16x32_bf16), gfx950: the OPTIONAL reduced-precision mode.
 //
 // Same contract and fused epilogue as conv3x3_wino4.hip (reference nn.Conv2d(k=3, padding=1), model/basic.py:4-7, forward and -
 // with mode-1 packed weights - input gradient): y = act(alpha * (conv + bias) [masked] + skip), fused PixelShuffle store / fused
@@ -33,8 +33,9 @@ struct Bf16Args {
     const float* skip;         // [N][H][W][Cout] or null
     const float* mask;         // [N][H][W][Cout] or null : result zeroed where mask <= 0
     float* y;                  // [N][H][W][Cout]
-    int N, H, W, Cin, Cout;
-    int TR, TW;                // tile: TR rows x TW pixels (TR * TW == 144)
+    int N, H, W, Cin, Cout;    // H, W: the INPUT's size
+    int OH, OW;                // the output's size (== H, W for stride 1)
+    int TR, TW;                // tile: TR rows x TW OUTPUT pixels (TR * TW == 144)
     int tiles_x, tiles_y, n_tiles;
     int HT, WT;                // halo rows / columns
     float alpha, slope;
@@ -53,10 +54,15 @@ constexpr int B16_PX = 96;     // LDS bytes per halo pixel: 64 of data + 32 of p
 // waves per SIMD on 16-cycle MFMAs every other vector instruction competes with the matrix pipe for issue slots.
 // NW: waves per workgroup.  8 (x NTW = 2 / 1: 256 / 128 output channels per workgroup), or 4 with NTW = 1 for the 64-channel layers
 // (vgg19 conv1_2, the input gradients of the 64 -> 128 convs): 144 pixels x 64 channels, 256 threads, several workgroups per CU.
-template <int NTW, int WTC, int NW>
+// S = 2: the stride-2 forward (the Discriminator's down-sampling convs, reference model/pesr.py:56-64).  The halo is (2 TR + 1) x
+// (2 TW + 1) input pixels (up to 640: ten staging items per thread instead of four); a halo row is stored DE-INTERLEAVED - its even
+// columns first, then the odd ones - so that the 16 pixels of a fragment read are again 16 consecutive LDS entries and a tap is
+// again one uniform offset: kx = 0 / 1 / 2 -> even plane / odd plane / even plane + 1.
+template <int NTW, int WTC, int NW, int S = 1>
 __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a) {
-    constexpr int NT = NW * 64, NU = 2048 / NT, BN = NW * 16 * NTW;
+    constexpr int NT = NW * 64, NU = (S == 2 ? 5120 : 2048) / NT, BN = NW * 16 * NTW;
     const int WT = WTC ? WTC : a.WT;
+    const int WE = (WT + 1) >> 1;                                       // even columns of a halo row (S = 2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int v_bytes = (a.HT * WT + 1) * B16_PX;                       // + the dump pixel
 
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
     for (int i = 0; i < B16_MG; ++i) {
         const int m = i * 16 + r;
         const int trow = m / a.TW, tcol = m - trow * a.TW;
-        a_off[i] = (trow * WT + tcol) * B16_PX + g * 16;
+        a_off[i] = (S * trow * WT + tcol) * B16_PX + g * 16;
     }
 
     // ---- weight operand: this lane's 16 bytes of slab (tap, chunk), n-tile j.  A buffer load: the slab's offset is a SCALAR offset
@@ -106,8 +112,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
     for (int u = 0; u < NU; ++u) {
         const int it = tid + u * NT;
         const int q = it & 7, px = it >> 3;
-        const int hrow = px / WT, hcol = px - hrow * WT;
-        const int iy = gy0 - 1 + hrow, ix = gx0 - 1 + hcol;
+        const int hrow = px / WT, slot = px - hrow * WT;
+        const int hcol = S == 2 ? (slot < WE ? 2 * slot : 2 * (slot - WE) + 1) : slot;      // LDS slot `slot` of the row holds halo column hcol
+        const int iy = S * gy0 - 1 + hrow, ix = S * gx0 - 1 + hcol;
         const bool ok = it < n_items && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
         // out-of-image pixels are fetched beyond the buffer descriptor's range: the load returns zeros (images are < 2 GB)
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
 
 #define B16_READ_X(FX, VB, T, GRP)                                                                       \
     {                                                                                                    \
-        const int to_ = (((T) / 3) * WT + (T) % 3) * B16_PX;                                             \
+        const int to_ = (((T) / 3) * WT + (S == 2 ? ((T) % 3 == 1 ? WE : ((T) % 3) >> 1) : (T) % 3)) * B16_PX; \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
             FX[i] = *(const bf16x8*)((VB) + a_cur[(GRP) * 3 + i] + to_);                                 \
     }
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
 #undef B16_MFMA
 
     // ---- epilogue: lane (r, g) holds channels co .. co + 3 of pixel 16 i + r -----------------------------------------------------
-    const size_t img_out = (size_t)img * a.H * a.W;
+    const size_t img_out = (size_t)img * a.OH * a.OW;
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int co = n0 + (wave * NTW + j) * 16 + g * 4;
@@ -226,13 +233,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
                 const int m = (ib + e) * 16 + r;
                 const int trow = m / a.TW, tcol = m - trow * a.TW;
                 const int oy = gy0 + trow, ox = gx0 + tcol;
-                ok[e] = oy < a.H && ox < a.W;
+                ok[e] = oy < a.OH && ox < a.OW;
                 if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
                     const int C = a.Cout >> 2;
                     const int sub = co / C, cc = co - sub * C;
-                    idx[e] = (((size_t)img * (2 * a.H) + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1)) * C + cc;
+                    idx[e] = (((size_t)img * (2 * a.OH) + 2 * oy + (sub >> 1)) * (2 * a.OW) + 2 * ox + (sub & 1)) * C + cc;
                 } else {
-                    idx[e] = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+                    idx[e] = (img_out + (size_t)oy * a.OW + ox) * a.Cout + co;
                 }
                 if (!ok[e]) idx[e] = 0;
                 if (a.mask) mkv[e] = *(const f32x4*)(a.mask + idx[e]);
@@ -319,6 +326,33 @@ static bool b16_plan(int N, int H, int W, int Cin, int Cout, B16Plan* p, int min
     p->score = p->tiles >= min_wgs ? (int)(1000.0 * cover_eff) : 0;
     return true;
 }
+// Stride 2 (forward only): TR x TW == 144 OUTPUT pixels whose (2 TR + 1) x (2 TW + 1) halo fits the ten staging items per thread;
+// 128 output channels per eight-wave workgroup (64: four waves).  These layers are small (the Discriminator's 24^2 / 12^2 outputs
+// give 128 / 64 workgroups) and the fp32 alternative is the small-tile direct kernel: half of min_wgs is already worth the switch.
+static bool b16_plan_s2(int N, int H, int W, int Cin, int Cout, B16Plan* p, int min_wgs = 128) {
+    if (N < 1 || H < 2 || W < 2 || Cin % 32 || Cin < 32 || Cout % 64) return false;
+    if ((size_t)H * W * Cin * 4 >= ((size_t)1 << 31)) return false;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    long best = -1;
+    for (int TW = 1; TW <= 144; ++TW) {
+        if (144 % TW) continue;
+        const int TR = 144 / TW, HT = 2 * TR + 1, WT = 2 * TW + 1;
+        if (HT * WT * 8 > 5120) continue;
+        const long cover = (long)pesr_cdiv(OH, TR) * TR * pesr_cdiv(OW, TW) * TW;
+        const long score = cover * 8192 + (TW % 16 ? 4096 : 0) + (long)HT * WT;
+        if (best < 0 || score < best) { best = score; p->TR = TR; p->TW = TW; }
+    }
+    if (best < 0) return false;
+    p->HT = 2 * p->TR + 1; p->WT = 2 * p->TW + 1;
+    p->ntw = 1;
+    p->bn = Cout % 128 == 0 ? 128 : 64;
+    p->tiles_y = pesr_cdiv(OH, p->TR); p->tiles_x = pesr_cdiv(OW, p->TW); p->n_tiles = Cout / p->bn;
+    p->tiles = (long)N * p->tiles_y * p->tiles_x * p->n_tiles;
+    p->lds = (size_t)2 * (p->HT * p->WT + 1) * B16_PX;
+    const double cover_eff = (double)OH * OW / ((double)p->tiles_y * p->TR * p->tiles_x * p->TW);
+    p->score = p->tiles >= (min_wgs + 1) / 2 ? (int)(1000.0 * cover_eff) : 0;
+    return true;
+}
 }  // namespace
 
 // per-mille of tile area inside the image (0: unsupported shape, or fewer than min_wgs workgroups: not worth leaving the fp32 kernels)
@@ -337,7 +371,7 @@ int pesr_conv3x3_bf16_launch(const float* x, const void* wp, const float* bias, 
     if (ps_in && Cin % 128) return PESR_EINVAL;                                 // a 32-channel chunk must stay inside one sub-pixel
     Bf16Args a{};
     a.x = x; a.wp = (const char*)wp; a.bias = bias; a.skip = skip; a.mask = mask; a.y = y;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.N = N; a.H = H; a.W = W; a.OH = H; a.OW = W; a.Cin = Cin; a.Cout = Cout;
     a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
     a.TR = p.TR; a.TW = p.TW; a.HT = p.HT; a.WT = p.WT;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
@@ -353,5 +387,35 @@ int pesr_conv3x3_bf16_launch(const float* x, const void* wp, const float* bias, 
     if (p.bn == 64) { B16_BY_WT(1, 4) } else if (p.ntw == 2) { B16_BY_WT(2, 8) } else { B16_BY_WT(1, 8) }
 #undef B16_BY_WT
 #undef B16_LAUNCH
+    return pesr_launch_status();
+}
+
+// Stride-2 forward (input [N][H][W][Cin] -> output [N][(H-1)/2+1][(W-1)/2+1][Cout]); same packed weights as the stride-1 forward.
+int pesr_conv3x3_bf16_s2_score_impl(int N, int H, int W, int Cin, int Cout, int min_wgs) {
+    B16Plan p;
+    if (!b16_plan_s2(N, H, W, Cin, Cout, &p, min_wgs)) return 0;
+    return p.score;
+}
+
+int pesr_conv3x3_bf16_s2_launch(const float* x, const void* wp, const float* bias, const float* skip, const float* mask, float* y,
+                                int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, hipStream_t stream) {
+    B16Plan p;
+    if (!b16_plan_s2(N, H, W, Cin, Cout, &p)) return PESR_EINVAL;
+    Bf16Args a{};
+    a.x = x; a.wp = (const char*)wp; a.bias = bias; a.skip = skip; a.mask = mask; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.OH = (H - 1) / 2 + 1; a.OW = (W - 1) / 2 + 1; a.Cin = Cin; a.Cout = Cout;
+    a.alpha = alpha; a.slope = slope; a.act = act; a.ps = 0; a.ps_in = 0;
+    a.TR = p.TR; a.TW = p.TW; a.HT = p.HT; a.WT = p.WT;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
+#define B16_LAUNCH_S2(WT_, NW_)                                                                                        \
+    {                                                                                                                  \
+        auto kern = conv3x3_bf16_kernel<1, WT_, NW_, 2>;                                                               \
+        static std::once_flag once;                                                                                    \
+        std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles), dim3(NW_ * 64), p.lds, stream, a);                           \
+    }
+    if (p.bn == 64) { if (p.WT == 25) B16_LAUNCH_S2(25, 4) else B16_LAUNCH_S2(0, 4) }
+    else { if (p.WT == 25) B16_LAUNCH_S2(25, 8) else B16_LAUNCH_S2(0, 8) }
+#undef B16_LAUNCH_S2
     return pesr_launch_status();
 }

@@ -95,6 +95,9 @@ int pesr_pack_conv3x3_bf16_launch(const float* w, void* out, int O, int I, int m
 int pesr_conv3x3_bf16_launch(const float* x, const void* wp, const float* bias, const float* skip, const float* mask, float* y,
                              int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
                              hipStream_t stream);
+int pesr_conv3x3_bf16_s2_score_impl(int N, int H, int W, int Cin, int Cout, int min_wgs);
+int pesr_conv3x3_bf16_s2_launch(const float* x, const void* wp, const float* bias, const float* skip, const float* mask, float* y,
+                                int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, hipStream_t stream);
 size_t pesr_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int pesr_conv3x3_wgrad_bf16_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                                    float alpha, int ps_in, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -184,7 +184,7 @@ class PackedConvWeights:
     def for_dgrad(self, w: torch.Tensor, x_shape, stride: int = 1):
         """Packed weights for dx of y = conv(x, w) with x of NHWC shape x_shape."""
         N, H, W, Cin = x_shape
-        if ops.bf16_eligible(N, H, W, w.shape[0], Cin, stride, ps_in=self.ps):
+        if stride == 1 and ops.bf16_eligible(N, H, W, w.shape[0], Cin, 1, ps_in=self.ps):      # (stride 2: forward only)
             return self.bf16_dgrad(w)
         if ops.wino4_eligible(N, H, W, w.shape[0], Cin, stride):
             return self.wino4_dgrad(w)

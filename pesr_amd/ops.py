@@ -245,6 +245,7 @@ def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacke
 # Everything else (and everything by default) stays on the fp32 kernels.
 PRECISION = __import__("os").environ.get("PESR_PRECISION", "fp32")
 _B16_SCORE = {}
+_BF16_NO_S2 = __import__("os").environ.get("PESR_BF16_NO_S2", "0") == "1"      # A/B switch of scripts/gpu_call51.sh: stride-2 forwards stay fp32
 BF16_MIN_WGS = 128        # layers whose bf16 launch would have fewer workgroups stay on the fp32 kernels (tests lower it)
 
 
@@ -267,12 +268,15 @@ def bf16_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, 
     """PRECISION is "bf16" and the bf16 kernel covers the shape with at least 78 % of its tile area inside the image.
     Cin / Cout are those of the problem the kernel runs."""
     bn = 256 if Cout % 256 == 0 else (128 if Cout % 128 == 0 else 64)        # output channels per workgroup (conv3x3_bf16.hip)
-    if PRECISION != "bf16" or stride != 1 or Cin % 32 or Cout % 64 or (ps_out and Cout % (4 * bn)) or (ps_in and Cin % 128):
+    if PRECISION != "bf16" or stride not in (1, 2) or Cin % 32 or Cout % 64 or (ps_out and Cout % (4 * bn)) or (ps_in and Cin % 128):
         return False
-    key = (N, H, W, Cin, Cout, BF16_MIN_WGS)
+    if stride == 2 and (ps_out or ps_in or _BF16_NO_S2):
+        return False
+    key = (N, H, W, Cin, Cout, BF16_MIN_WGS, stride)
     sc = _B16_SCORE.get(key)
-    if sc is None:
-        sc = _B16_SCORE[key] = _lib.lib().pesr_conv3x3_bf16_score(N, H, W, Cin, Cout, BF16_MIN_WGS)
+    if sc is None:       # stride 2: the FORWARD kernel only (H, W: the input's size); its gradients stay on the fp32 kernels
+        score = _lib.lib().pesr_conv3x3_bf16_score if stride == 1 else _lib.lib().pesr_conv3x3_bf16_s2_score
+        sc = _B16_SCORE[key] = score(N, H, W, Cin, Cout, BF16_MIN_WGS)
     return sc >= 780
 
 
@@ -347,7 +351,10 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         FLOPS.add(18.0 * N * OH * OW * Cin * cout, *_conv_family(wp))
     br = KERNEL_EVENTS.begin("fwd", N, H, W, Cin, cout, stride)
     L = _lib.lib()
-    if isinstance(wp, (WinoPacked, Wino4Packed, Bf16Packed)):
+    if isinstance(wp, Bf16Packed) and stride == 2:
+        assert not ps_out
+        rc = L.pesr_conv3x3_bf16_s2(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope, _stream())
+    elif isinstance(wp, (WinoPacked, Wino4Packed, Bf16Packed)):
         assert stride == 1
         _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, "fwd", ps_out=ps_out)
         rc = 0

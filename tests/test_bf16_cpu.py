@@ -16,6 +16,7 @@ def test_bf16_rules_mirror_the_library_planners():
     for N, (H, W), Cin, Cout, mw in itertools.product((1, 2, 16), ((48, 48), (96, 96), (192, 192), (24, 24), (12, 12), (7, 48), (5, 100), (30, 36), (6, 144)),
                                                       (3, 32, 64, 96, 128, 256, 512), (64, 128, 192, 256, 384, 1024), (1, 128)):
         assert OB.conv_score(N, H, W, Cin, Cout, mw) == L.pesr_conv3x3_bf16_score(N, H, W, Cin, Cout, mw), (N, H, W, Cin, Cout, mw)
+        assert OB.conv_s2_score(N, H, W, Cin, Cout, mw) == L.pesr_conv3x3_bf16_s2_score(N, H, W, Cin, Cout, mw), (N, H, W, Cin, Cout, mw)
         with OB.enabled(True, mw):
             lib_ok = W % 48 == 0 and Cin % 64 == 0 and Cout % 128 == 0 and L.pesr_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, Cin, Cout) > 0 \
                 and N * ((H + 1) // 2) * (W // 48) >= (96 if mw >= 128 else 1)
@@ -55,3 +56,19 @@ def test_bf16_conv_function_rounds_what_it_says():
         else:            # 32 input channels: neither the 128 -> 32 input gradient nor the weight gradient is covered: fp32 on fp32 operands
             assert torch.allclose(xr.grad, dx32, rtol=0, atol=1e-5 * dx32.abs().max().item())
             assert torch.allclose(wr.grad, dw32, rtol=0, atol=1e-5 * dw32.abs().max().item())
+
+
+def test_bf16_stride2_conv_rounds_its_forward_only():
+    """A stride-2 conv the stride-2 form of the kernel covers: forward on rounded operands, both gradients in fp32."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 64, 24, 24, generator=g); w = torch.randn(128, 64, 3, 3, generator=g) * 0.1
+    dy = torch.randn(1, 128, 12, 12, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    with OB.enabled(True, 1):
+        assert OB.conv_eligible(1, 24, 24, 64, 128, 2) and not OB.conv_eligible(1, 24, 24, 48, 128, 2)
+        y = OB.conv3x3(xr, wr, None, stride=2)
+        y.backward(dy)
+    assert torch.equal(y.detach(), F.conv2d(O.round_bf16(x), O.round_bf16(w), None, stride=2, padding=1))
+    dx32, dw32, _ = O.conv3x3_grads(x, w, dy, 2)
+    assert torch.allclose(xr.grad, dx32, rtol=0, atol=1e-5 * dx32.abs().max().item())
+    assert torch.allclose(wr.grad, dw32, rtol=0, atol=1e-5 * dw32.abs().max().item())

@@ -292,3 +292,24 @@ def test_bf16_determinism_race_screen():
             if wgr:
                 g, b = wgr()
                 assert torch.equal(g, g0[0]) and torch.equal(b, g0[1])
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 48, 48, 128, 128), (1, 24, 24, 256, 256), (2, 24, 24, 512, 512), (1, 13, 11, 32, 128),
+                                             (1, 30, 70, 64, 64), (2, 96, 96, 64, 64), (1, 7, 300, 64, 128), (3, 2, 2, 32, 192)])
+def test_conv3x3_bf16_stride2_forward(N, H, W, Cin, Cout):
+    """The stride-2 form of the bf16 kernel (the Discriminator's down-sampling convs; de-interleaved halo columns): forward with
+    the fused epilogues, odd sizes, the four-wave 64-channel workgroups; bit-reproducible."""
+    from pesr_amd import ops
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = _rand(N, Cin, H, W, seed=31); w = _rand(Cout, Cin, 3, 3, seed=32, scale=0.1); b = _rand(Cout, seed=33)
+    skip = _rand(N, Cout, OH, OW, seed=34); mk = _rand(N, Cout, OH, OW, seed=35)
+    ref = O.conv3x3_bf16(x, w, b, stride=2)
+    wf = ops.pack_conv3x3_bf16(w.cuda(), 0)
+    y = ops.conv3x3_fwd(_nhwc(x), wf, b.cuda(), Cout, 2, act=ops.ACT_LRELU, slope=0.2)
+    assert y.shape == (N, OH, OW, Cout)
+    _close(_nchw(y), torch.nn.functional.leaky_relu(ref, 0.2), 1e-5)
+    _close(_nchw(y), torch.nn.functional.leaky_relu(O.conv3x3(x, w, b, 2), 0.2), 1e-2)       # it IS the conv, to bf16-operand accuracy
+    y2 = ops.conv3x3_fwd(_nhwc(x), wf, b.cuda(), Cout, 2, alpha=0.1, skip=_nhwc(skip), mask=_nhwc(mk))
+    _close(_nchw(y2), torch.where(mk > 0, ref * 0.1, torch.zeros_like(ref)) + skip, 1e-5)
+    for _ in range(4):
+        assert torch.equal(ops.conv3x3_fwd(_nhwc(x), wf, b.cuda(), Cout, 2, act=ops.ACT_LRELU, slope=0.2), y)
