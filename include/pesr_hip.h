@@ -127,11 +127,18 @@ int pesr_conv3x3_bf16(const float* x, const void* w_packed, const float* bias, c
                       void* stream);
 /* Stride-2 forward in the bf16 mode (the Discriminator's down-sampling convs, reference model/pesr.py:56-64: Conv(k=3, stride=2,
  * padding=1)): x [N][H][W][Cin] -> y [N][(H-1)/2+1][(W-1)/2+1][Cout], skip / mask shaped like y; weights packed by
- * pesr_pack_conv3x3_bf16 mode 0 (the stride-1 forward's packing).  Its input and weight gradients stay on the fp32 kernels.
+ * pesr_pack_conv3x3_bf16 mode 0 (the stride-1 forward's packing).  Its weight gradient stays on the fp32 kernels.
  * pesr_conv3x3_bf16_s2_score: as above, but half of min_wgs workgroups already qualify (these layers are small). */
 int pesr_conv3x3_bf16_s2_score(int N, int H, int W, int Cin, int Cout, int min_wgs);
 int pesr_conv3x3_bf16_s2(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask, float* y,
                          int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, void* stream);
+/* Input gradient of the same stride-2 conv in the bf16 mode: dy [N][(H-1)/2+1][(W-1)/2+1][Cout_fwd] -> dx [N][H][W][Cin_fwd] =
+ * alpha * grad [zeroed where mask <= 0] + skip (mask / skip shaped like dx, may be null); the four output parity classes are
+ * four small stride-1 problems with 1 / 2 / 2 / 4 taps inside ONE launch.  w_packed: pesr_pack_conv3x3_bf16 mode 1 of the forward
+ * weights (the stride-1 input gradient's packing).  Cout_fwd % 32 == 0, Cin_fwd % 64 == 0. */
+int pesr_conv3x3_bf16_s2_dgrad_score(int N, int H, int W, int Cout_fwd, int Cin_fwd, int min_wgs);
+int pesr_conv3x3_bf16_s2_dgrad(const float* dy, const void* w_packed, const float* mask, const float* skip, float* dx, int N, int H,
+                               int W, int Cout_fwd, int Cin_fwd, float alpha, void* stream);
 /* Weight / bias gradient of the same conv in the bf16 mode: dw = alpha * sum bf16(dy) * bf16(x) (fp32 sums; fixed-order split-K
  * reduce, bit-reproducible), db = alpha * sum dy (fp32, un-rounded).  Same tensors and ps_in / accumulate meaning as
  * pesr_conv3x3_wgrad.  Stride 1, W % 48 == 0, Cin % 64 == 0, Cout % 128 == 0 (Cout % 512 == 0 with ps_in); workspace_bytes

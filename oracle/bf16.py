@@ -4,7 +4,8 @@ The reference (thangvubk/PESR) is fp32 only, so this mode has no reference file 
 definition (pesr_amd/csrc/conv3x3_bf16.hip, conv3x3_wgrad_bf16.hip, pesr_amd/ops.py bf16_eligible / wgrad_bf16_eligible):
     * a stride-1 3x3 conv whose shape the bf16 kernels cover rounds BOTH operands of every product to bfloat16 (round to nearest
       even) and sums the exact products in fp32:   y  = conv(r(x), r(w)) + b
-      (a stride-2 conv likewise in its FORWARD pass where the stride-2 form of the kernel covers it; its gradients stay fp32)
+      (a stride-2 conv likewise in its forward pass and its input gradient where the stride-2 forms of the kernel cover them; its
+      weight gradient stays fp32)
     * its input gradient, where the (transposed) shape is covered:   dx = conv_T(r(dy), r(w))
     * its weight gradient, where THAT kernel covers the shape:       dw = corr(r(x), r(dy));   db = sum(dy) always un-rounded
     * every other op, and every conv the rules below reject, is the fp32 arithmetic of oracle/model.py.
@@ -91,8 +92,45 @@ def conv_s2_score(N, H, W, Cin, Cout, min_wgs):
     return int(1000.0 * eff) if tiles >= (min_wgs + 1) // 2 else 0
 
 
+def conv_s2_dgrad_score(N, H, W, Cout_fwd, Cin_fwd, min_wgs):
+    """conv3x3_bf16.hip b16_plan_s2d (H, W: dx's size): four parity classes over dy, 144 dy positions per tile, a (TR + 1) x (TW + 1)
+    halo; the four classes' workgroups together count against min_wgs."""
+    if H < 1 or W < 1:
+        return 0
+    DH, DW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Cin, Cout = Cout_fwd, Cin_fwd
+    if N < 1 or Cin % 32 or Cin < 32 or Cout % 64 or DH * DW * Cin * 4 >= 1 << 31:
+        return 0
+    best = None
+    for TW in range(1, 145):
+        if 144 % TW:
+            continue
+        TR = 144 // TW
+        HT, WT = TR + 1, TW + 1
+        if HT * WT * 8 > 2048:
+            continue
+        cover = _cdiv(DH, TR) * TR * _cdiv(DW, TW) * TW
+        score = cover * 8192 + (4096 if TW % 16 else 0) + HT * WT
+        if best is None or score < best[0]:
+            best = (score, TR, TW)
+    if best is None:
+        return 0
+    _, TR, TW = best
+    bn = 256 if Cout % 256 == 0 else (128 if Cout % 128 == 0 else 64)
+    tiles = N * _cdiv(DH, TR) * _cdiv(DW, TW) * (Cout // bn)
+    eff = DH * DW / (_cdiv(DH, TR) * TR * _cdiv(DW, TW) * TW)
+    return int(1000.0 * eff) if 4 * tiles >= min_wgs else 0
+
+
+def conv_s2_dgrad_eligible(N, H, W, Cout_fwd, Cin_fwd):
+    """pesr_amd.ops.bf16_s2_dgrad_eligible (H, W: the forward input's = dx's size)."""
+    if Cout_fwd % 32 or Cin_fwd % 64:
+        return False
+    return conv_s2_dgrad_score(N, H, W, Cout_fwd, Cin_fwd, MIN_WGS) >= 780
+
+
 def conv_eligible(N, H, W, Cin, Cout, stride=1, ps_out=False, ps_in=False):
-    """pesr_amd.ops.bf16_eligible for the problem the kernel runs (an input gradient: Cin / Cout swapped; stride 2: forward only)."""
+    """pesr_amd.ops.bf16_eligible for the problem the kernel runs (a stride-1 input gradient: Cin / Cout swapped; stride 2: the forward)."""
     bn = 256 if Cout % 256 == 0 else (128 if Cout % 128 == 0 else 64)
     if stride not in (1, 2) or Cin % 32 or Cout % 64 or (ps_out and Cout % (4 * bn)) or (ps_in and Cin % 128):
         return False
@@ -141,7 +179,7 @@ def conv3x3(x, w, b=None, stride=1, ps=False):
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     f_fwd = conv_eligible(N, H, W, Cin, Cout, stride, ps_out=ps)
-    f_dgrad = stride == 1 and conv_eligible(N, H, W, Cout, Cin, 1, ps_in=ps)
+    f_dgrad = conv_eligible(N, H, W, Cout, Cin, 1, ps_in=ps) if stride == 1 else (not ps and conv_s2_dgrad_eligible(N, H, W, Cout, Cin))
     f_wgrad = wgrad_eligible(N, H, W, Cin, Cout, stride, ps_in=ps)
     if not (f_fwd or f_dgrad or f_wgrad):
         return F.conv2d(x, w, b, stride=stride, padding=1)

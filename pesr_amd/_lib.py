@@ -47,6 +47,8 @@ SIGNATURES.update({
                                   c_int, _P]),
     "pesr_conv3x3_bf16_s2_score": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "pesr_conv3x3_bf16_s2": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, _P]),
+    "pesr_conv3x3_bf16_s2_dgrad_score": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pesr_conv3x3_bf16_s2_dgrad": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "pesr_conv3x3_wgrad_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "pesr_conv3x3_wgrad_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P, c_size_t, _P]),
     "pesr_conv3x3_rgb_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),

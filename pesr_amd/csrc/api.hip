@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 10; }
+PESR_API int pesr_abi_version(void) { return 11; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -215,6 +215,13 @@ PESR_API int pesr_conv3x3_bf16_s2_score(int N, int H, int W, int Cin, int Cout, 
 PESR_API int pesr_conv3x3_bf16_s2(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask,
                                   float* y, int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, void* stream) {
     return pesr_conv3x3_bf16_s2_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, (hipStream_t)stream);
+}
+PESR_API int pesr_conv3x3_bf16_s2_dgrad_score(int N, int H, int W, int Cout_fwd, int Cin_fwd, int min_wgs) {
+    return pesr_conv3x3_bf16_s2_dgrad_score_impl(N, H, W, Cout_fwd, Cin_fwd, min_wgs);
+}
+PESR_API int pesr_conv3x3_bf16_s2_dgrad(const float* dy, const void* w_packed, const float* mask, const float* skip, float* dx, int N,
+                                        int H, int W, int Cout_fwd, int Cin_fwd, float alpha, void* stream) {
+    return pesr_conv3x3_bf16_s2_dgrad_launch(dy, w_packed, mask, skip, dx, N, H, W, Cout_fwd, Cin_fwd, alpha, (hipStream_t)stream);
 }
 PESR_API size_t pesr_conv3x3_wgrad_bf16_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
     return pesr_conv3x3_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout);

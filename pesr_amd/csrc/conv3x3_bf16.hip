@@ -58,8 +58,28 @@ constexpr int B16_PX = 96;     // LDS bytes per halo pixel: 64 of data + 32 of p
 // (2 TW + 1) input pixels (up to 640: ten staging items per thread instead of four); a halo row is stored DE-INTERLEAVED - its even
 // columns first, then the odd ones - so that the 16 pixels of a fragment read are again 16 consecutive LDS entries and a tap is
 // again one uniform offset: kx = 0 / 1 / 2 -> even plane / odd plane / even plane + 1.
-template <int NTW, int WTC, int NW, int S = 1>
-__global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a) {
+//
+// CLS = 0..3: one output parity class (py, px) = (CLS >> 1, CLS & 1) of the STRIDE-2 INPUT GRADIENT: dx[2u + py][2v + px] =
+// sum over the taps with ky = 1 (py = 0) or ky in {0, 2} (py = 1), likewise kx, of dy[u + (ky == 0)][v + (kx == 0)] * w[ky][kx]
+// - a stride-1 problem over dy with 1 / 2 / 2 / 4 taps, no multiply-by-zero work (conv3x3_mfma.hip does the same in fp32).  x = dy,
+// H, W = dy's size, OH, OW = dx's size; the halo is (TR + 1) x (TW + 1) with its origin AT the tile; the weights are the mode-1
+// packing (its slab t holds forward tap 8 - t).
+__host__ __device__ constexpr bool b16_tap_used(int cls, int t) {
+    return cls < 0 || ((((cls >> 1) != 0) == (t / 3 != 1)) && (((cls & 1) != 0) == (t % 3 != 1)));
+}
+__host__ __device__ constexpr int b16_ntaps(int cls) { return cls < 0 ? 9 : (1 + (cls >> 1)) * (1 + (cls & 1)); }
+// the k-th used tap of a class (forward tap index ky * 3 + kx), in increasing order
+__host__ __device__ constexpr int b16_tap(int cls, int k) {
+    int n = 0;
+    for (int t = 0; t < 9; ++t)
+        if (b16_tap_used(cls, t)) { if (n == k) return t; ++n; }
+    return 0;
+}
+
+template <int NTW, int WTC, int NW, int S, int CLS>
+__device__ __forceinline__ void conv3x3_bf16_body(const Bf16Args& a) {
+    constexpr int NTAP = b16_ntaps(CLS);
+    constexpr int PY = CLS < 0 ? 0 : (CLS >> 1), PX = CLS < 0 ? 0 : (CLS & 1);
     constexpr int NT = NW * 64, NU = (S == 2 ? 5120 : 2048) / NT, BN = NW * 16 * NTW;
     const int WT = WTC ? WTC : a.WT;
     const int WE = (WT + 1) >> 1;                                       // even columns of a halo row (S = 2)
@@ -98,7 +118,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
     const __amdgpu_buffer_rsrc_t w_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (unsigned)((size_t)9 * a.Cin * a.Cout * 2), 0x00020000);
     auto ldw = [&](int t, int j, int cc) -> bf16x8 {
-        const int so = (t * C32 + cc) * slab_bytes;
+        const int so = ((CLS < 0 ? t : 8 - t) * C32 + cc) * slab_bytes;
         return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_lane + j * 1024, so, 0));
     };
 
@@ -114,7 +134,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
         const int q = it & 7, px = it >> 3;
         const int hrow = px / WT, slot = px - hrow * WT;
         const int hcol = S == 2 ? (slot < WE ? 2 * slot : 2 * (slot - WE) + 1) : slot;      // LDS slot `slot` of the row holds halo column hcol
-        const int iy = S * gy0 - 1 + hrow, ix = S * gx0 - 1 + hcol;
+        const int iy = S * gy0 - (CLS < 0 ? 1 : 0) + hrow, ix = S * gx0 - (CLS < 0 ? 1 : 0) + hcol;
         const bool ok = it < n_items && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
         // out-of-image pixels are fetched beyond the buffer descriptor's range: the load returns zeros (images are < 2 GB)
@@ -159,7 +179,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
 
 #define B16_READ_X(FX, VB, T, GRP)                                                                       \
     {                                                                                                    \
-        const int to_ = (((T) / 3) * WT + (S == 2 ? ((T) % 3 == 1 ? WE : ((T) % 3) >> 1) : (T) % 3)) * B16_PX; \
+        const int tt_ = b16_tap(CLS, (T));      /* (folds to a constant once the tap loop is unrolled) */ \
+        const int to_ = CLS >= 0 ? ((tt_ / 3 == 0 ? WT : 0) + (tt_ % 3 == 0 ? 1 : 0)) * B16_PX                \
+                                 : ((tt_ / 3) * WT + (S == 2 ? (tt_ % 3 == 1 ? WE : (tt_ % 3) >> 1) : tt_ % 3)) * B16_PX; \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
             FX[i] = *(const bf16x8*)((VB) + a_cur[(GRP) * 3 + i] + to_);                                 \
     }
@@ -173,9 +195,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
     stage_load(0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < NTAP; ++t) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) fw[t][j] = ldw(t, j, 0);
+        for (int j = 0; j < NTW; ++j) fw[t][j] = ldw(b16_tap(CLS, t), j, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     stage_store(smem);
@@ -197,19 +219,19 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
 #pragma unroll
         for (int G0 = 0; G0 < B16_FXD - 1; ++G0) B16_READ_X(fx[G0], smem, G0 / 3, G0 % 3)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < NTAP; ++t) {
 #pragma unroll
             for (int grp = 0; grp < 3; ++grp) {
                 const int G = t * 3 + grp, Gn = G + B16_FXD - 1;
-                if (Gn < 27) B16_READ_X(fx[Gn % B16_FXD], smem, Gn / 3, Gn % 3)
+                if (Gn < 3 * NTAP) B16_READ_X(fx[Gn % B16_FXD], smem, Gn / 3, Gn % 3)
                 __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of the MFMA group
                 B16_MFMA(fx[G % B16_FXD], t, grp)
                 __builtin_amdgcn_sched_barrier(0);
             }
             // this tap's weights are consumed: fetch the same tap of the next chunk into their registers
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) fw[t][j] = ldw(t, j, cn);
-            if (t == B16_STAGE_T) { stage_store(vnext); __builtin_amdgcn_sched_barrier(0); }
+            for (int j = 0; j < NTW; ++j) fw[t][j] = ldw(b16_tap(CLS, t), j, cn);
+            if (t == (NTAP == 9 ? B16_STAGE_T : NTAP - 1)) { stage_store(vnext); __builtin_amdgcn_sched_barrier(0); }
         }
         __syncthreads();                                   // the next image is complete and visible; everyone is done with this one
     }
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
             for (int e = 0; e < 3; ++e) {
                 const int m = (ib + e) * 16 + r;
                 const int trow = m / a.TW, tcol = m - trow * a.TW;
-                const int oy = gy0 + trow, ox = gx0 + tcol;
+                const int oy = CLS < 0 ? gy0 + trow : 2 * (gy0 + trow) + PY, ox = CLS < 0 ? gx0 + tcol : 2 * (gx0 + tcol) + PX;
                 ok[e] = oy < a.OH && ox < a.OW;
                 if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
                     const int C = a.Cout >> 2;
@@ -265,6 +287,22 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a)
                 *(f32x4*)(a.y + idx[e]) = o;
             }
         }
+    }
+}
+
+template <int NTW, int WTC, int NW, int S = 1>
+__global__ __launch_bounds__(NW * 64) void conv3x3_bf16_kernel(const Bf16Args a) {
+    conv3x3_bf16_body<NTW, WTC, NW, S, -1>(a);
+}
+
+// stride-2 input gradient: blockIdx.y = parity class, so that the four small problems fill the chip together
+template <int NTW, int WTC, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_bf16_s2_dgrad_kernel(const Bf16Args a) {
+    switch (blockIdx.y) {           // the four-tap class is dispatched first
+        case 0: conv3x3_bf16_body<NTW, WTC, NW, 1, 3>(a); break;
+        case 1: conv3x3_bf16_body<NTW, WTC, NW, 1, 2>(a); break;
+        case 2: conv3x3_bf16_body<NTW, WTC, NW, 1, 1>(a); break;
+        default: conv3x3_bf16_body<NTW, WTC, NW, 1, 0>(a); break;
     }
 }
 
@@ -353,6 +391,31 @@ static bool b16_plan_s2(int N, int H, int W, int Cin, int Cout, B16Plan* p, int 
     p->score = p->tiles >= (min_wgs + 1) / 2 ? (int)(1000.0 * cover_eff) : 0;
     return true;
 }
+// Stride-2 input gradient (four parity classes over dy [N][DH][DW][Cin]; Cout = the forward conv's input channels): TR x TW == 144
+// dy positions per tile, (TR + 1) x (TW + 1) halo; blockIdx.y = class.
+static bool b16_plan_s2d(int N, int DH, int DW, int Cin, int Cout, B16Plan* p, int min_wgs = 128) {
+    if (N < 1 || DH < 1 || DW < 1 || Cin % 32 || Cin < 32 || Cout % 64) return false;
+    if ((size_t)DH * DW * Cin * 4 >= ((size_t)1 << 31)) return false;
+    long best = -1;
+    for (int TW = 1; TW <= 144; ++TW) {
+        if (144 % TW) continue;
+        const int TR = 144 / TW, HT = TR + 1, WT = TW + 1;
+        if (HT * WT * 8 > 2048) continue;
+        const long cover = (long)pesr_cdiv(DH, TR) * TR * pesr_cdiv(DW, TW) * TW;
+        const long score = cover * 8192 + (TW % 16 ? 4096 : 0) + (long)HT * WT;
+        if (best < 0 || score < best) { best = score; p->TR = TR; p->TW = TW; }
+    }
+    if (best < 0) return false;
+    p->HT = p->TR + 1; p->WT = p->TW + 1;
+    p->ntw = Cout % 256 == 0 ? 2 : 1;
+    p->bn = Cout % 128 == 0 ? 128 * p->ntw : 64;
+    p->tiles_y = pesr_cdiv(DH, p->TR); p->tiles_x = pesr_cdiv(DW, p->TW); p->n_tiles = Cout / p->bn;
+    p->tiles = (long)N * p->tiles_y * p->tiles_x * p->n_tiles;       // per class
+    p->lds = (size_t)2 * (p->HT * p->WT + 1) * B16_PX;
+    const double cover_eff = (double)DH * DW / ((double)p->tiles_y * p->TR * p->tiles_x * p->TW);
+    p->score = 4 * p->tiles >= min_wgs ? (int)(1000.0 * cover_eff) : 0;
+    return true;
+}
 }  // namespace
 
 // per-mille of tile area inside the image (0: unsupported shape, or fewer than min_wgs workgroups: not worth leaving the fp32 kernels)
@@ -417,5 +480,32 @@ int pesr_conv3x3_bf16_s2_launch(const float* x, const void* wp, const float* bia
     if (p.bn == 64) { if (p.WT == 25) B16_LAUNCH_S2(25, 4) else B16_LAUNCH_S2(0, 4) }
     else { if (p.WT == 25) B16_LAUNCH_S2(25, 8) else B16_LAUNCH_S2(0, 8) }
 #undef B16_LAUNCH_S2
+    return pesr_launch_status();
+}
+
+// Stride-2 input gradient: dy [N][DH][DW][Cout_fwd] (DH = (H-1)/2+1 ...) -> dx [N][H][W][Cin_fwd]; weights: mode-1 packing of the
+// forward weights [Cout_fwd][Cin_fwd][3][3] (the stride-1 input gradient's packing).  dx = alpha * grad [masked] + skip.
+int pesr_conv3x3_bf16_s2_dgrad_score_impl(int N, int H, int W, int Cout_fwd, int Cin_fwd, int min_wgs) {
+    B16Plan p;
+    if (H < 1 || W < 1 || !b16_plan_s2d(N, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cout_fwd, Cin_fwd, &p, min_wgs)) return 0;
+    return p.score;
+}
+
+int pesr_conv3x3_bf16_s2_dgrad_launch(const float* dy, const void* wp, const float* mask, const float* skip, float* dx, int N, int H, int W,
+                                      int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream) {
+    B16Plan p;
+    if (H < 1 || W < 1) return PESR_EINVAL;
+    const int DH = (H - 1) / 2 + 1, DW = (W - 1) / 2 + 1;
+    if (!b16_plan_s2d(N, DH, DW, Cout_fwd, Cin_fwd, &p)) return PESR_EINVAL;
+    Bf16Args a{};
+    a.x = dy; a.wp = (const char*)wp; a.bias = nullptr; a.skip = skip; a.mask = mask; a.y = dx;
+    a.N = N; a.H = DH; a.W = DW; a.OH = H; a.OW = W; a.Cin = Cout_fwd; a.Cout = Cin_fwd;
+    a.alpha = alpha; a.slope = 0.f; a.act = PESR_ACT_NONE; a.ps = 0; a.ps_in = 0;
+    a.TR = p.TR; a.TW = p.TW; a.HT = p.HT; a.WT = p.WT;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
+    const dim3 grid((unsigned)p.tiles, 4);
+    if (p.bn == 64) hipLaunchKernelGGL((conv3x3_bf16_s2_dgrad_kernel<1, 0, 4>), grid, dim3(256), p.lds, stream, a);
+    else if (p.ntw == 2) hipLaunchKernelGGL((conv3x3_bf16_s2_dgrad_kernel<2, 0, 8>), grid, dim3(512), p.lds, stream, a);
+    else hipLaunchKernelGGL((conv3x3_bf16_s2_dgrad_kernel<1, 0, 8>), grid, dim3(512), p.lds, stream, a);
     return pesr_launch_status();
 }

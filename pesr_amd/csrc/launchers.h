@@ -98,6 +98,9 @@ int pesr_conv3x3_bf16_launch(const float* x, const void* wp, const float* bias, 
 int pesr_conv3x3_bf16_s2_score_impl(int N, int H, int W, int Cin, int Cout, int min_wgs);
 int pesr_conv3x3_bf16_s2_launch(const float* x, const void* wp, const float* bias, const float* skip, const float* mask, float* y,
                                 int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, hipStream_t stream);
+int pesr_conv3x3_bf16_s2_dgrad_score_impl(int N, int H, int W, int Cout_fwd, int Cin_fwd, int min_wgs);
+int pesr_conv3x3_bf16_s2_dgrad_launch(const float* dy, const void* wp, const float* mask, const float* skip, float* dx, int N, int H, int W,
+                                      int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream);
 size_t pesr_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int pesr_conv3x3_wgrad_bf16_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                                    float alpha, int ps_in, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);

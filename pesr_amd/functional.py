@@ -184,7 +184,9 @@ class PackedConvWeights:
     def for_dgrad(self, w: torch.Tensor, x_shape, stride: int = 1):
         """Packed weights for dx of y = conv(x, w) with x of NHWC shape x_shape."""
         N, H, W, Cin = x_shape
-        if stride == 1 and ops.bf16_eligible(N, H, W, w.shape[0], Cin, 1, ps_in=self.ps):      # (stride 2: forward only)
+        if stride == 1 and ops.bf16_eligible(N, H, W, w.shape[0], Cin, 1, ps_in=self.ps):
+            return self.bf16_dgrad(w)
+        if stride == 2 and not self.ps and ops.bf16_s2_dgrad_eligible(N, H, W, w.shape[0], Cin):
             return self.bf16_dgrad(w)
         if ops.wino4_eligible(N, H, W, w.shape[0], Cin, stride):
             return self.wino4_dgrad(w)

@@ -280,6 +280,17 @@ def bf16_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, 
     return sc >= 780
 
 
+def bf16_s2_dgrad_eligible(N: int, H: int, W: int, Cout_fwd: int, Cin_fwd: int) -> bool:
+    """PRECISION is "bf16" and the stride-2 input-gradient form of the bf16 kernel covers dx [N, H, W, Cin_fwd]."""
+    if PRECISION != "bf16" or _BF16_NO_S2 or Cout_fwd % 32 or Cin_fwd % 64:
+        return False
+    key = (N, H, W, Cout_fwd, Cin_fwd, BF16_MIN_WGS, "s2d")
+    sc = _B16_SCORE.get(key)
+    if sc is None:
+        sc = _B16_SCORE[key] = _lib.lib().pesr_conv3x3_bf16_s2_dgrad_score(N, H, W, Cout_fwd, Cin_fwd, BF16_MIN_WGS)
+    return sc >= 780
+
+
 def pack_conv3x3_bf16(w: torch.Tensor, mode: int, ps: bool = False) -> Bf16Packed:
     """OIHW [O, I, 3, 3] fp32 -> [9, R/32, Nn, 32] bf16 (mode 0: forward, mode 1: dgrad with flipped taps; ps: sub-pixel-major O)."""
     _chk(w, "pack_conv3x3_bf16.w")
@@ -384,6 +395,12 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
     if FLOPS.on:
         FLOPS.add(18.0 * N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * Cin * cout, *_conv_family(wpd))
     br = KERNEL_EVENTS.begin("dgrad", N, H, W, Cin, cout, stride)
+    if isinstance(wpd, Bf16Packed) and stride == 2:
+        assert not ps_in
+        rc = L.pesr_conv3x3_bf16_s2_dgrad(_p(dy), _p(wpd.t), _p(mask), _p(skip), _p(dx), N, H, W, cout, Cin, alpha, _stream())
+        KERNEL_EVENTS.end(br)
+        _lib.check(rc, f"pesr_conv3x3_bf16_s2_dgrad[{N}x{H}x{W}x{Cin}<-{cout}]")
+        return dx
     if isinstance(wpd, (WinoPacked, Wino4Packed, Bf16Packed)):     # the input gradient is the conv of dy with the flipped, transposed kernel
         assert stride == 1
         _conv3x3_wino(dy, wpd, None, skip, mask, dx, N, H, W, cout, Cin, alpha, ACT_NONE, 0.0, "dgrad", ps_in=ps_in)

@@ -17,6 +17,7 @@ def test_bf16_rules_mirror_the_library_planners():
                                                       (3, 32, 64, 96, 128, 256, 512), (64, 128, 192, 256, 384, 1024), (1, 128)):
         assert OB.conv_score(N, H, W, Cin, Cout, mw) == L.pesr_conv3x3_bf16_score(N, H, W, Cin, Cout, mw), (N, H, W, Cin, Cout, mw)
         assert OB.conv_s2_score(N, H, W, Cin, Cout, mw) == L.pesr_conv3x3_bf16_s2_score(N, H, W, Cin, Cout, mw), (N, H, W, Cin, Cout, mw)
+        assert OB.conv_s2_dgrad_score(N, H, W, Cin, Cout, mw) == L.pesr_conv3x3_bf16_s2_dgrad_score(N, H, W, Cin, Cout, mw), (N, H, W, Cin, Cout, mw)
         with OB.enabled(True, mw):
             lib_ok = W % 48 == 0 and Cin % 64 == 0 and Cout % 128 == 0 and L.pesr_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, Cin, Cout) > 0 \
                 and N * ((H + 1) // 2) * (W // 48) >= (96 if mw >= 128 else 1)
@@ -58,8 +59,8 @@ def test_bf16_conv_function_rounds_what_it_says():
             assert torch.allclose(wr.grad, dw32, rtol=0, atol=1e-5 * dw32.abs().max().item())
 
 
-def test_bf16_stride2_conv_rounds_its_forward_only():
-    """A stride-2 conv the stride-2 form of the kernel covers: forward on rounded operands, both gradients in fp32."""
+def test_bf16_stride2_conv_rounds_forward_and_input_gradient():
+    """A stride-2 conv the stride-2 forms of the kernel cover: forward and input gradient on rounded operands, weight gradient fp32."""
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, 64, 24, 24, generator=g); w = torch.randn(128, 64, 3, 3, generator=g) * 0.1
     dy = torch.randn(1, 128, 12, 12, generator=g)
@@ -70,5 +71,7 @@ def test_bf16_stride2_conv_rounds_its_forward_only():
         y.backward(dy)
     assert torch.equal(y.detach(), F.conv2d(O.round_bf16(x), O.round_bf16(w), None, stride=2, padding=1))
     dx32, dw32, _ = O.conv3x3_grads(x, w, dy, 2)
-    assert torch.allclose(xr.grad, dx32, rtol=0, atol=1e-5 * dx32.abs().max().item())
+    dxb = torch.nn.grad.conv2d_input(x.shape, O.round_bf16(w), O.round_bf16(dy), stride=2, padding=1)
+    assert torch.allclose(xr.grad, dxb, rtol=0, atol=1e-5 * dxb.abs().max().item())
+    assert (xr.grad - dx32).abs().max() > 1e-4 * dx32.abs().max()
     assert torch.allclose(wr.grad, dw32, rtol=0, atol=1e-5 * dw32.abs().max().item())

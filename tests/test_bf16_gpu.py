@@ -313,3 +313,25 @@ def test_conv3x3_bf16_stride2_forward(N, H, W, Cin, Cout):
     _close(_nchw(y2), torch.where(mk > 0, ref * 0.1, torch.zeros_like(ref)) + skip, 1e-5)
     for _ in range(4):
         assert torch.equal(ops.conv3x3_fwd(_nhwc(x), wf, b.cuda(), Cout, 2, act=ops.ACT_LRELU, slope=0.2), y)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 48, 48, 128, 128), (1, 24, 24, 256, 256), (2, 24, 24, 512, 512), (1, 13, 11, 64, 96),
+                                             (1, 30, 70, 64, 64), (2, 96, 96, 64, 64), (1, 7, 300, 128, 64), (3, 2, 2, 64, 32), (1, 1, 5, 64, 32)])
+def test_conv3x3_bf16_stride2_input_gradient(N, H, W, Cin, Cout):
+    """The stride-2 input gradient on the bf16 kernel (four parity classes, one launch): odd sizes, mask / skip epilogue,
+    bit-reproducible.  x [N, Cin, H, W] is the forward conv's input, the conv maps Cin -> Cout."""
+    from pesr_amd import ops
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = _rand(N, Cin, H, W, seed=41); w = _rand(Cout, Cin, 3, 3, seed=42, scale=0.1); dy = _rand(N, Cout, OH, OW, seed=43)
+    xr = O.round_bf16(x).double().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, O.round_bf16(w).double(), None, stride=2, padding=1).backward(O.round_bf16(dy).double())
+    dx_ref = xr.grad.float()
+    wd = ops.pack_conv3x3_bf16(w.cuda(), 1)
+    dx = ops.conv3x3_dgrad(_nhwc(dy), wd, (N, H, W, Cin), 2)
+    _close(_nchw(dx), dx_ref, 1e-5)
+    dx32, _, _ = O.conv3x3_grads(x, w, dy, 2)
+    _close(_nchw(dx), dx32, 1e-2)
+    dx2 = ops.conv3x3_dgrad(_nhwc(dy), wd, (N, H, W, Cin), 2, alpha=0.5, mask=_nhwc(x), skip=_nhwc(x))
+    _close(_nchw(dx2), torch.where(x > 0, 0.5 * dx_ref, torch.zeros_like(dx_ref)) + x, 1e-5)
+    for _ in range(4):
+        assert torch.equal(ops.conv3x3_dgrad(_nhwc(dy), wd, (N, H, W, Cin), 2), dx)
