@@ -119,7 +119,7 @@ int pesr_conv3x3_wino4(const float* x, const float* w_packed, const float* bias,
  * (with ps_out: Cout a multiple of four workgroup widths - 256 / 128 / 64 channels for Cout % 256 / 128 / 64 == 0; Cin % 128 == 0 with ps_in).
  * w_packed: 9 * Cin * Cout bf16 (2 bytes each) from pesr_pack_conv3x3_bf16 (mode 0 forward / mode 1 input gradient - then call
  * with Cin / Cout of the gradient problem swapped).  pesr_conv3x3_bf16_score: per-mille of the kernel's 144-pixel tiles inside
- * the image, 0 for unsupported shapes or fewer than min_wgs workgroups (the host-side dispatch passes 128). */
+ * the image, 0 for unsupported shapes or fewer than min_wgs workgroups (the host-side dispatch passes 64). */
 int pesr_conv3x3_bf16_score(int N, int H, int W, int Cin, int Cout, int min_wgs);
 int pesr_pack_conv3x3_bf16(const float* w, void* w_packed, int Cout, int Cin, int mode, int ps, void* stream);
 int pesr_conv3x3_bf16(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask, float* y,

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from .ops import round_bf16
 
 ON = False            # oracle.model consults this
-MIN_WGS = 128         # pesr_amd.ops.BF16_MIN_WGS: fewer workgroups than this stay on the fp32 kernels
+MIN_WGS = 64          # pesr_amd.ops.BF16_MIN_WGS: fewer workgroups than this stay on the fp32 kernels
 
 
 @contextlib.contextmanager
@@ -60,6 +60,8 @@ def conv_score(N, H, W, Cin, Cout, min_wgs):
         return 0
     _, TR, TW = best
     bn = 256 if Cout % 256 == 0 else (128 if Cout % 128 == 0 else 64)
+    if bn == 256 and N * _cdiv(H, TR) * _cdiv(W, TW) * (Cout // 256) < 128:
+        bn = 128                                          # few tiles: 128 output channels per workgroup instead of 256
     tiles = N * _cdiv(H, TR) * _cdiv(W, TW) * (Cout // bn)
     eff = H * W / (_cdiv(H, TR) * TR * _cdiv(W, TW) * TW)
     return int(1000.0 * eff) if tiles >= min_wgs else 0
@@ -117,6 +119,8 @@ def conv_s2_dgrad_score(N, H, W, Cout_fwd, Cin_fwd, min_wgs):
         return 0
     _, TR, TW = best
     bn = 256 if Cout % 256 == 0 else (128 if Cout % 128 == 0 else 64)
+    if bn == 256 and 4 * N * _cdiv(DH, TR) * _cdiv(DW, TW) * (Cout // 256) < 128:
+        bn = 128
     tiles = N * _cdiv(DH, TR) * _cdiv(DW, TW) * (Cout // bn)
     eff = DH * DW / (_cdiv(DH, TR) * TR * _cdiv(DW, TW) * TW)
     return int(1000.0 * eff) if 4 * tiles >= min_wgs else 0
@@ -145,7 +149,7 @@ def wgrad_eligible(N, H, W, Cin, Cout, stride=1, ps_in=False):
         return False
     if H * W * Cin * 4 >= 1 << 30 or H * W * Cout * 4 >= 1 << 30:
         return False
-    return N * ((H + 1) // 2) * (W // 48) >= (96 if MIN_WGS >= 128 else 1)
+    return N * ((H + 1) // 2) * (W // 48) >= (96 if MIN_WGS >= 64 else 1)
 
 
 class _Bf16Conv(torch.autograd.Function):

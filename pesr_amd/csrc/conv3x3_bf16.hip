@@ -355,9 +355,11 @@ static bool b16_plan(int N, int H, int W, int Cin, int Cout, B16Plan* p, int min
     }
     if (best < 0) return false;
     p->HT = p->TR + 2; p->WT = p->TW + 2;
-    p->ntw = Cout % 256 == 0 ? 2 : 1;
+    p->tiles_y = pesr_cdiv(H, p->TR); p->tiles_x = pesr_cdiv(W, p->TW);
+    // 256 output channels per workgroup unless that leaves fewer than 128 workgroups (the 12^2 / 24^2 layers): then 128 each
+    p->ntw = (Cout % 256 == 0 && (long)N * p->tiles_y * p->tiles_x * (Cout / 256) >= 128) ? 2 : 1;
     p->bn = Cout % 128 == 0 ? 128 * p->ntw : 64;              // 64: the four-wave workgroups
-    p->tiles_y = pesr_cdiv(H, p->TR); p->tiles_x = pesr_cdiv(W, p->TW); p->n_tiles = Cout / p->bn;
+    p->n_tiles = Cout / p->bn;
     p->tiles = (long)N * p->tiles_y * p->tiles_x * p->n_tiles;
     p->lds = (size_t)2 * (p->HT * p->WT + 1) * B16_PX;
     const double cover_eff = (double)H * W / ((double)p->tiles_y * p->TR * p->tiles_x * p->TW);
@@ -407,9 +409,10 @@ static bool b16_plan_s2d(int N, int DH, int DW, int Cin, int Cout, B16Plan* p, i
     }
     if (best < 0) return false;
     p->HT = p->TR + 1; p->WT = p->TW + 1;
-    p->ntw = Cout % 256 == 0 ? 2 : 1;
+    p->tiles_y = pesr_cdiv(DH, p->TR); p->tiles_x = pesr_cdiv(DW, p->TW);
+    p->ntw = (Cout % 256 == 0 && (long)N * p->tiles_y * p->tiles_x * (Cout / 256) * 4 >= 128) ? 2 : 1;
     p->bn = Cout % 128 == 0 ? 128 * p->ntw : 64;
-    p->tiles_y = pesr_cdiv(DH, p->TR); p->tiles_x = pesr_cdiv(DW, p->TW); p->n_tiles = Cout / p->bn;
+    p->n_tiles = Cout / p->bn;
     p->tiles = (long)N * p->tiles_y * p->tiles_x * p->n_tiles;       // per class
     p->lds = (size_t)2 * (p->HT * p->WT + 1) * B16_PX;
     const double cover_eff = (double)DH * DW / ((double)p->tiles_y * p->TR * p->tiles_x * p->TW);

@@ -246,7 +246,9 @@ def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacke
 PRECISION = __import__("os").environ.get("PESR_PRECISION", "fp32")
 _B16_SCORE = {}
 _BF16_NO_S2 = __import__("os").environ.get("PESR_BF16_NO_S2", "0") == "1"      # A/B switch of scripts/gpu_call51.sh: stride-2 forwards stay fp32
-BF16_MIN_WGS = 128        # layers whose bf16 launch would have fewer workgroups stay on the fp32 kernels (tests lower it)
+# layers whose bf16 launch would have fewer workgroups stay on the fp32 kernels (tests lower it; at 64 workgroups the 16x12x12x512
+# layers take 47 us against 89 on the F(4,3) kernel, scripts/bf16_small_time.py).  The env form is for A/B runs only.
+BF16_MIN_WGS = int(__import__("os").environ.get("PESR_BF16_MIN_WGS", "64"))
 
 
 def set_precision(p: str) -> None:
@@ -446,7 +448,7 @@ def wgrad_bf16_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int
         return False
     if _lib.lib().pesr_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, Cin, Cout) == 0:
         return False
-    return N * ((H + 1) // 2) * (W // 48) >= (96 if BF16_MIN_WGS >= 128 else 1)
+    return N * ((H + 1) // 2) * (W // 48) >= (96 if BF16_MIN_WGS >= 64 else 1)
 
 
 def conv3x3_wgrad_bf16(x: torch.Tensor, dy: torch.Tensor, alpha: float = 1.0, want_bias: bool = True, ps_in: bool = False,

@@ -14,16 +14,16 @@ def test_bf16_rules_mirror_the_library_planners():
     L = _lib.lib()
     n = 0
     for N, (H, W), Cin, Cout, mw in itertools.product((1, 2, 16), ((48, 48), (96, 96), (192, 192), (24, 24), (12, 12), (7, 48), (5, 100), (30, 36), (6, 144)),
-                                                      (3, 32, 64, 96, 128, 256, 512), (64, 128, 192, 256, 384, 1024), (1, 128)):
+                                                      (3, 32, 64, 96, 128, 256, 512), (64, 128, 192, 256, 384, 1024), (1, 64, 128)):
         assert OB.conv_score(N, H, W, Cin, Cout, mw) == L.pesr_conv3x3_bf16_score(N, H, W, Cin, Cout, mw), (N, H, W, Cin, Cout, mw)
         assert OB.conv_s2_score(N, H, W, Cin, Cout, mw) == L.pesr_conv3x3_bf16_s2_score(N, H, W, Cin, Cout, mw), (N, H, W, Cin, Cout, mw)
         assert OB.conv_s2_dgrad_score(N, H, W, Cin, Cout, mw) == L.pesr_conv3x3_bf16_s2_dgrad_score(N, H, W, Cin, Cout, mw), (N, H, W, Cin, Cout, mw)
         with OB.enabled(True, mw):
             lib_ok = W % 48 == 0 and Cin % 64 == 0 and Cout % 128 == 0 and L.pesr_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, Cin, Cout) > 0 \
-                and N * ((H + 1) // 2) * (W // 48) >= (96 if mw >= 128 else 1)
+                and N * ((H + 1) // 2) * (W // 48) >= (96 if mw >= 64 else 1)
             assert OB.wgrad_eligible(N, H, W, Cin, Cout) == lib_ok, (N, H, W, Cin, Cout, mw)
         n += 1
-    assert n > 2000
+    assert n > 3000
 
 
 def test_round_bf16_is_round_to_nearest_even():
