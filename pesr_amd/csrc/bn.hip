@@ -75,10 +75,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float momentum, float* __restrict__ mean_invstd,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            long long* __restrict__ num_batches) {
-    __shared__ double red[16][64];
+    __shared__ double red[2][16][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const double s = reduce_rows_block(part, nb, 2 * C, c, c < C, red);
-    const double ss = reduce_rows_block(part, nb, 2 * C, C + c, c < C, red);
+    double s, ss;
+    reduce_rows_block2(part, nb, 2 * C, c, C + c, c < C, red[0], red[1], &s, &ss);
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
     if (c >= C || (threadIdx.x >> 6) != 0) return;
     const double mean = s / (double)M;
@@ -96,10 +96,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 // second stage for backward, same fusion: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat (+ dbeta, dgamma)
 __global__ __launch_bounds__(1024) void bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums,
                                                            float* __restrict__ dbeta, float* __restrict__ dgamma, int accumulate) {
-    __shared__ double red[16][64];
+    __shared__ double red[2][16][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const double s0 = reduce_rows_block(part, nb, 2 * C, c, c < C, red);
-    const double s1 = reduce_rows_block(part, nb, 2 * C, C + c, c < C, red);
+    double s0, s1;
+    reduce_rows_block2(part, nb, 2 * C, c, C + c, c < C, red[0], red[1], &s0, &s1);
     if (c >= C || (threadIdx.x >> 6) != 0) return;
     const float a = (float)s0, b = (float)s1;
     sums[c] = a; sums[C + c] = b;
