@@ -233,7 +233,13 @@ static void lin_plan(int M, int N, long K, LinPlan* p) {
     }
     // dgrad: one-wave blocks, ceil(K/256) * nsplit ~ 1024 of them (every N slice writes an M x K partial: keep them few)
     const long kb = (K + 4 * LD_BT - 1) / (4 * LD_BT);
-    int ns = (int)((1024 * 256 / LD_BT + kb - 1) / kb); if (ns < 1) ns = 1; if (ns > N) ns = N; if (ns > 16) ns = 16;
+#ifndef LD_NS_TARGET
+#define LD_NS_TARGET 1024
+#endif
+#ifndef LD_NS_MAX
+#define LD_NS_MAX 16
+#endif
+    int ns = (int)((LD_NS_TARGET * 256 / LD_BT + kb - 1) / kb); if (ns < 1) ns = 1; if (ns > N) ns = N; if (ns > LD_NS_MAX) ns = LD_NS_MAX;
     p->nchunk = (N + ns - 1) / ns; p->nsplit = (N + p->nchunk - 1) / p->nchunk;
     (void)M;
 }
