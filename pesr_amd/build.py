@@ -17,6 +17,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpesr_hip.so")
 STAMP = LIB + ".stamp"
 ARCH = "gfx950"
+# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs.  Left to its heuristic hipcc parks the accumulators of the smaller
+# kernels (the 256-thread direct-conv configurations above all) in AGPRs and moves them out and back around every loop
+# iteration: v_accvgpr_read / _write for each accumulator register, each write waiting for the MFMAs it follows.
+HIPCC_FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+               "-Wno-unused-result"]
 
 
 def _sources():
@@ -25,6 +30,7 @@ def _sources():
 
 def _digest() -> str:
     h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode())          # a change of the compile command (flags, arch) rebuilds too
     files = _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     files.append(os.path.join(HERE, "..", "include", "pesr_hip.h"))
     for f in files:
@@ -53,11 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in _sources():
         obj = os.path.join(build_dir, os.path.basename(src) + ".o")
         objs.append(obj)
-        # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs.  Left to its heuristic hipcc parks the accumulators of the smaller
-        # kernels (the 256-thread direct-conv configurations above all) in AGPRs and moves them out and back around every loop
-        # iteration: v_accvgpr_read / _write for each accumulator register, each write waiting for the MFMAs it follows.
-        cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden", "-mllvm",
-               "-amdgpu-mfma-vgpr-form=1", "-Wno-unused-result", "-c", src, "-o", obj]
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -1,0 +1,246 @@
+"""Gradient-exchange transports of the data-parallel step (replaces the reduce_add of nn.DataParallel, reference
+train.py:114-118).
+
+Two transports behind one small interface (`all_reduce_async` / `wait` / `host_max`):
+
+* `DirectRccl` - RCCL's C API through ctypes (the librccl.so torch itself links), on a communicator and a HIP stream of our own.
+  An all-reduce forks that stream from the current one with an event, runs `ncclAllReduce` in place on the flat gradient slice,
+  and `wait` joins it back with a second event.  Nothing of torch.distributed touches these collectives: no Work objects, no
+  ProcessGroupNCCL watchdog thread polling their events - so the same calls are capturable into a hipGraph (fork / join become
+  graph edges) with no process-wide state to quiesce first.  torch.distributed is used once, to hand rank 0's `ncclUniqueId` to
+  the other ranks.
+* `TorchGroup` - `torch.distributed.all_reduce(async_op=True)` on a process group: gloo in the CPU tests and for ranks that share
+  one GPU, and the fallback over ProcessGroupNCCL should the direct communicator fail to come up.  Under hipGraph capture it uses
+  a DEDICATED process group on which no eager collective ever ran: the watchdog thread of ProcessGroupNCCL hipEventQuery()s the
+  end events of eager works it has not reaped yet, an event's stream may not be capturing while it is queried, and works launched
+  under capture are never put on the watchdog's list - so the streams that join a capture must be streams the watchdog holds no
+  events of.  (Round 3 slept three watchdog periods instead.)
+
+`make_transport()` picks one for a process group; every rank takes the same decision (the choice is agreed with a MIN
+all-reduce on the bootstrap group).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+NCCL_UNIQUE_ID_BYTES = 128           # rccl.h
+NCCL_SUM, NCCL_MAX = 0, 2            # ncclRedOp_t
+NCCL_FLOAT32, NCCL_FLOAT64 = 7, 8    # ncclDataType_t
+
+
+class CommError(RuntimeError):
+    pass
+
+
+class _UniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+_RCCL = None
+
+
+def rccl_lib():
+    """librccl.so - the copy torch links (one RCCL per process), else the system one."""
+    global _RCCL
+    if _RCCL is not None:
+        return _RCCL
+    cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "/opt/rocm/lib/librccl.so"]
+    err = None
+    for c in cands:
+        try:
+            L = ctypes.CDLL(c)
+        except OSError as e:
+            err = e
+            continue
+        L.ncclGetErrorString.restype = ctypes.c_char_p
+        L.ncclGetErrorString.argtypes = [ctypes.c_int]
+        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
+        L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
+        L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                    ctypes.c_void_p]
+        L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        L.ncclGetVersion.argtypes = [ctypes.POINTER(ctypes.c_int)]
+        for f in (L.ncclGetUniqueId, L.ncclCommInitRank, L.ncclAllReduce, L.ncclCommDestroy, L.ncclGetVersion):
+            f.restype = ctypes.c_int
+        _RCCL = L
+        return L
+    raise CommError(f"librccl.so not found ({err})")
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise CommError(f"{what}: RCCL error {rc} ({rccl_lib().ncclGetErrorString(rc).decode()})")
+
+
+class Transport:
+    """all_reduce_async(t) -> handle: SUM over the ranks, in place, asynchronously to the current stream (which the collective
+    waits for first); wait(handles): the current stream waits for those collectives; host_max(values): element-wise MAX of a
+    few host floats over the ranks (policy decisions every rank must take alike)."""
+    name = "?"
+    world = 1
+    capturable = False
+
+    def all_reduce_async(self, t: torch.Tensor):
+        raise NotImplementedError
+
+    def wait(self, handles) -> None:
+        raise NotImplementedError
+
+    def host_max(self, values: List[float]) -> List[float]:
+        raise NotImplementedError
+
+    def begin_capture(self) -> None:
+        """Called once before a hipGraph capture that will contain this transport's collectives."""
+
+    def close(self) -> None:
+        pass
+
+
+class DirectRccl(Transport):
+    name = "rccl-direct"
+    capturable = True
+
+    def __init__(self, device: torch.device, rank: int, world: int, bootstrap_group=None):
+        L = rccl_lib()
+        self.device, self.rank, self.world = device, rank, world
+        uid = _UniqueId()
+        if rank == 0:
+            _check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        if world > 1:      # the only use of torch.distributed: rank 0's id to everybody (a CPU tensor over gloo, a GPU one over nccl)
+            on_gpu = dist.get_backend(bootstrap_group) == "nccl"
+            t = torch.frombuffer(bytearray(bytes(uid.internal)) if rank == 0 else bytearray(NCCL_UNIQUE_ID_BYTES), dtype=torch.uint8).clone()
+            if on_gpu:
+                t = t.to(device)
+            src = 0 if bootstrap_group is None else dist.get_global_rank(bootstrap_group, 0)
+            dist.broadcast(t, src, group=bootstrap_group)
+            ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), NCCL_UNIQUE_ID_BYTES)
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _check(L.ncclCommInitRank(ctypes.byref(self._comm), world, uid, rank), "ncclCommInitRank")
+            self.stream = torch.cuda.Stream(device=device)
+        v = ctypes.c_int()
+        L.ncclGetVersion(ctypes.byref(v))
+        self.version = v.value
+        # self-test: every rank contributes 1 -> world (also warms the communicator's first-use setup outside any timed region)
+        one = torch.ones(4, dtype=torch.float32, device=device)
+        self.wait([self.all_reduce_async(one)])
+        torch.cuda.current_stream(device).synchronize()
+        if [float(x) for x in one.cpu()] != [float(world)] * 4:
+            raise CommError(f"ncclAllReduce self-test: expected {world}, got {one.cpu().tolist()}")
+
+    def _launch(self, t: torch.Tensor, op: int):
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                      # fork: the collective reads what the current stream has written so far
+        self.stream.wait_event(ready)
+        dt = NCCL_FLOAT32 if t.dtype == torch.float32 else NCCL_FLOAT64
+        _check(rccl_lib().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, op, self._comm, self.stream.cuda_stream), "ncclAllReduce")
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return done
+
+    def all_reduce_async(self, t: torch.Tensor):
+        return self._launch(t, NCCL_SUM)
+
+    def wait(self, handles) -> None:
+        cur = torch.cuda.current_stream(self.device)
+        for h in handles:
+            cur.wait_event(h)                  # join (the host does not block)
+
+    def host_max(self, values: List[float]) -> List[float]:
+        t = torch.tensor(values, dtype=torch.float64, device=self.device)
+        self.wait([self._launch(t, NCCL_MAX)])
+        return [float(x) for x in t.cpu()]     # (.cpu() synchronises the current stream, which has joined the collective)
+
+    def close(self) -> None:
+        if self._comm:
+            torch.cuda.synchronize(self.device)
+            rccl_lib().ncclCommDestroy(self._comm)
+            self._comm = ctypes.c_void_p()
+
+
+class TorchGroup(Transport):
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.name = f"torch.distributed[{self.backend}]"
+        self.capturable = self.backend == "nccl"
+        self._capture_group = None
+        self._active = group
+
+    def all_reduce_async(self, t: torch.Tensor):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._active, async_op=True)
+
+    def wait(self, handles) -> None:
+        for w in handles:
+            w.wait()        # (nccl: the current stream waits for the communication stream; gloo: the host blocks)
+
+    def host_max(self, values: List[float]) -> List[float]:
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor(values, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return [float(x) for x in t.cpu()]
+
+    def begin_capture(self) -> None:
+        """From now on the collectives run on a process group of their own, created here (collectively) and never used eagerly
+        before: the capture joins only THAT group's communication stream, of whose events the watchdog holds none."""
+        if self.backend == "nccl" and self._capture_group is None:
+            ranks = list(range(dist.get_world_size())) if self.group is None else dist.get_process_group_ranks(self.group)
+            self._capture_group = dist.new_group(ranks=ranks, backend="nccl")
+            self._active = self._capture_group
+
+
+def make_transport(device: Optional[torch.device], group=None, prefer: Optional[str] = None) -> Transport:
+    """The transport of this process group's gradient exchange.  prefer (or env PESR_DP_TRANSPORT): "rccl" = the direct
+    communicator or an error, "torch" = torch.distributed, "auto" (default) = direct RCCL when the ranks own one GPU each and the
+    bootstrap backend is nccl, else torch.distributed; should the direct communicator fail on ANY rank, all ranks fall back
+    together (agreed by a MIN all-reduce) and the reason is kept in `.fallback_reason`."""
+    prefer = prefer or os.environ.get("PESR_DP_TRANSPORT", "auto")
+    if prefer not in ("auto", "rccl", "torch"):
+        raise ValueError(f"PESR_DP_TRANSPORT must be auto, rccl or torch, got {prefer!r}")
+    backend = dist.get_backend(group)
+    want_direct = prefer == "rccl" or (prefer == "auto" and backend == "nccl" and device is not None and device.type == "cuda")
+    if not want_direct:
+        return TorchGroup(group)
+    tr, reason = None, ""
+    try:
+        tr = DirectRccl(device, dist.get_rank(group), dist.get_world_size(group), group)
+    except (CommError, OSError, RuntimeError) as e:      # (decided together below)
+        reason = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([1.0 if tr is not None else 0.0], device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if float(ok.item()) == 1.0:
+        return tr
+    if prefer == "rccl":
+        raise CommError("the direct RCCL communicator did not come up on every rank" + (f" (here: {reason})" if reason else ""))
+    if tr is not None:
+        tr.close()
+    fb = TorchGroup(group)
+    fb.fallback_reason = reason or "another rank failed to create its communicator"
+    return fb
+
+
+_TRANSPORTS = {}
+
+
+def get_transport(device: Optional[torch.device], group=None) -> Transport:
+    """One transport per (process group, device), shared by the optimizers of a process (ONE communicator for G and D)."""
+    key = (None if group is None else id(group), None if device is None or device.type != "cuda" else device.index)
+    tr = _TRANSPORTS.get(key)
+    if tr is None:
+        tr = _TRANSPORTS[key] = make_transport(device, group)
+    return tr
+
+
+def close_transports() -> None:
+    """Destroy the direct communicators (call before dist.destroy_process_group())."""
+    for tr in list(_TRANSPORTS.values()):
+        tr.close()
+    _TRANSPORTS.clear()

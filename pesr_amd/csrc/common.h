@@ -21,6 +21,28 @@ static inline int pesr_launch_status() {
     return e == hipSuccess ? PESR_OK : (int)e;
 }
 
+// One-time kernel attributes (hipFuncAttributeMaxDynamicSharedMemorySize) belong to the function object of ONE device: a process
+// that drives several GPUs (the reference's single-process nn.DataParallel, train.py:114-118) must set them once per device, not
+// once per process.  static PesrDeviceOnce once; once([&] { hipFuncSetAttribute(...); });
+#ifdef __cplusplus
+#include <atomic>
+#include <mutex>
+struct PesrDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    std::mutex m;
+    template <class F> void operator()(F&& f) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> g(m);
+        if (done.load(std::memory_order_relaxed) & bit) return;
+        f();
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
+#endif
+
 static inline int pesr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // epilogue activation ids

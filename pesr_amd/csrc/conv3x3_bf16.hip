@@ -476,8 +476,8 @@ int pesr_conv3x3_bf16_s2_launch(const float* x, const void* wp, const float* bia
 #define B16_LAUNCH_S2(WT_, NW_)                                                                                        \
     {                                                                                                                  \
         auto kern = conv3x3_bf16_kernel<1, WT_, NW_, 2>;                                                               \
-        static std::once_flag once;                                                                                    \
-        std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+        static PesrDeviceOnce once;                                                                                    \
+        once([&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles), dim3(NW_ * 64), p.lds, stream, a);                           \
     }
     if (p.bn == 64) { if (p.WT == 25) B16_LAUNCH_S2(25, 4) else B16_LAUNCH_S2(0, 4) }

@@ -561,8 +561,8 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int t
 #define PESR_LAUNCH_MODE(M_)                                                                              \
     {                                                                                                      \
         auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, M_>;                              \
-        static std::once_flag attr_once;                                        \
-        std::call_once(attr_once, [&] {                                                           \
+        static PesrDeviceOnce attr_once;                                        \
+        attr_once([&] {                                                           \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         });                                                                                                  \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);                          \

@@ -401,8 +401,8 @@ static int launch_wgrad(const WgradArgs& a, int split, hipStream_t stream) {
     constexpr size_t lds = 2 * (size_t)(X_FLOATS + D_FLOATS) * sizeof(float);
     static_assert(lds <= 160 * 1024, "wgrad LDS budget");
     auto kern = conv3x3_wgrad_kernel<COW, S, TWO, R>;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static PesrDeviceOnce attr_once;
+    attr_once([&] {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int grid = split * a.co_tiles * a.ci_tiles;

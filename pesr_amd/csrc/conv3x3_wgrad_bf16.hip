@@ -284,8 +284,8 @@ int pesr_conv3x3_wgrad_bf16_launch(const float* x, const float* dy, float* dw, f
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.segs_x = p.segs_x; a.row_groups = p.row_groups; a.total_segs = p.total_segs; a.segs_per_split = p.segs_per_split;
     a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.ps_in = ps_in;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static PesrDeviceOnce attr_once;
+    attr_once([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, dim3((unsigned)(p.split * p.co_tiles * p.ci_tiles)), dim3(512), 2 * WB_BUF, stream, a);

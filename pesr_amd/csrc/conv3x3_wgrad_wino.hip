@@ -346,15 +346,12 @@ int pesr_conv3x3_wgrad_wino_launch(const float* x, const float* dy, float* dw, f
     a.bias_part = db ? (float*)((char*)ws + p.slab_bytes + (((size_t)Cout * sizeof(double) + 255) / 256) * 256) : nullptr;
     constexpr size_t lds = (size_t)(6 * WW_SLOT) * sizeof(float);
     static_assert(lds <= 160 * 1024, "wgrad-wino LDS budget");
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static PesrDeviceOnce attr_once;
+    attr_once([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int grid = p.split * p.co_tiles * p.ci_tiles;
     hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3(grid), dim3(WW_NT), lds, stream, a);
-#ifdef WW_SKIP_REDUCE
-    return 0;
-#endif
     const long units = 3L * Cout * Cin / 4;
     const int rgrid = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
     hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)ws, dw, p.split, Cout, Cin, alpha, ps_in,

@@ -673,14 +673,14 @@ int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, 
     constexpr size_t lds = (size_t)(G4_RING * G4_VROW + 4 * G4_DROW) * sizeof(float);
     static_assert(lds >= (size_t)9 * 64 * 32 * sizeof(float), "epilogue staging fits");
     static_assert(lds <= 160 * 1024, "wgrad-wino4 LDS budget");
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static PesrDeviceOnce attr_once;
+    attr_once([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     constexpr size_t ldsx = (size_t)2 * 6 * 3 * 1024 * sizeof(float);      // the variant's G^T staging (147 KB) exceeds its ring (129 KB)
     static_assert(ldsx >= (size_t)(G4_RING * X4_VROW + 4 * X4_DROW) * sizeof(float) && ldsx <= 160 * 1024, "wgrad-wino4x LDS budget");
-    static std::once_flag attr_once_x;
-    std::call_once(attr_once_x, [&] {
+    static PesrDeviceOnce attr_once_x;
+    attr_once_x([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int grid = p.split * p.co_tiles * p.ci_tiles;

@@ -342,8 +342,8 @@ int pesr_conv3x3_wino_launch(const float* x, const float* wp, const float* bias,
     size_t lds = raw_bytes + (size_t)a.HT * 4 * a.TXT * 64 + (size_t)WINO_RING * WINO_SLAB;
     const size_t lds_out = (size_t)288 * (WINO_BN * 4 + 16);
     if (lds_out > lds) lds = lds_out;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static PesrDeviceOnce attr_once;
+    attr_once([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const long tiles = (long)N * a.tiles_y * a.tiles_x * a.n_tiles;

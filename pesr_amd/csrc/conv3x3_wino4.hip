@@ -503,8 +503,8 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     a.ksplit = p.ksplit; a.chunks_per_split = p.chunks_per_split; a.slab = (float*)ws;
     a.stack = p.stack; a.stack_n = N; a.v_row = p.v_row;
     if (p.stack) a.N = 1;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static PesrDeviceOnce attr_once;
+    attr_once([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

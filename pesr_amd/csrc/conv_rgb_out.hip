@@ -135,12 +135,8 @@ __global__ __launch_bounds__(RO_NT) void conv_rgb_out_kernel(const RgbOutArgs a)
 #pragma unroll
                     for (int tt = 0; tt < RO_MT; ++tt) {
                         const float av = __builtin_bit_cast(f32x4, fa[slot][tt])[kk];
-#ifdef RO_ABL_MFMA      // timing-only: the memory side alone
-                        acc[0][tt][kk] += av * fb0[kk]; acc[1][tt][kk] += av * fb1[kk];
-#else
                         acc[0][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, fb0[kk], acc[0][tt], 0, 0, 0);
                         acc[1][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, fb1[kk], acc[1][tt], 0, 0, 0);
-#endif
                     }
             }
             if (!next_valid) primed = false;
@@ -194,8 +190,8 @@ int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bi
     else { a.halo = 1; a.outw = RO_COLS - 2; a.strips = pesr_cdiv(W, a.outw); }
     a.bands = pesr_cdiv(H, RO_TH);
     const size_t lds = ((size_t)(C / 16) * 512 + 4 * RO_PROW) * sizeof(float);
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static PesrDeviceOnce attr_once;
+    attr_once([&] {
         (void)hipFuncSetAttribute((const void*)conv_rgb_out_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_rgb_out_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });

@@ -173,6 +173,7 @@ class PackedConvWeights:
         """Packed weights for y = conv(x, w): Winograd F(4,3) where that kernel applies and fills the chip, else F(2,3)
         where THAT applies, else the direct packing.  (ops.PRECISION == "bf16": the bf16 kernel where IT applies, first.)"""
         N, H, W, Cin = x_shape
+        assert tuple(w.shape[2:]) == (3, 3), f"PackedConvWeights: 3x3 kernels only, got a weight of shape {tuple(w.shape)}"
         if ops.bf16_eligible(N, H, W, Cin, w.shape[0], stride, ps_out=self.ps):
             return self.bf16_fwd(w)
         if ops.wino4_eligible(N, H, W, Cin, w.shape[0], stride, ps_out=self.ps):
@@ -184,6 +185,7 @@ class PackedConvWeights:
     def for_dgrad(self, w: torch.Tensor, x_shape, stride: int = 1):
         """Packed weights for dx of y = conv(x, w) with x of NHWC shape x_shape."""
         N, H, W, Cin = x_shape
+        assert tuple(w.shape[2:]) == (3, 3), f"PackedConvWeights: 3x3 kernels only, got a weight of shape {tuple(w.shape)}"
         if stride == 1 and ops.bf16_eligible(N, H, W, w.shape[0], Cin, 1, ps_in=self.ps):
             return self.bf16_dgrad(w)
         if stride == 2 and not self.ps and ops.bf16_s2_dgrad_eligible(N, H, W, w.shape[0], Cin):

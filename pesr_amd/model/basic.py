@@ -211,7 +211,9 @@ class ResBlock(nn.Module):
         self.body = nn.Sequential(*modules_body)
         self.res_scale = res_scale
         self._bn = bn
-        self._fused = bias and not bn and isinstance(act, nn.ReLU) and not isinstance(act, nn.LeakyReLU)
+        # the fused node runs the 3x3 kernels only: any other (odd) kernel size takes the un-fused path, whose _conv_act
+        # routes it to the generic kernels (a [C,C,5,5] weight read by a 3x3 packer would be silently wrong)
+        self._fused = kernel_size == 3 and bias and not bn and isinstance(act, nn.ReLU) and not isinstance(act, nn.LeakyReLU)
 
     def forward(self, x):
         if self._fused:

@@ -78,6 +78,41 @@ class _KernelEvents:
 KERNEL_EVENTS = _KernelEvents()
 
 
+class _OpEvents:
+    """Optional HIP-event brackets around the HBM-bound ops that have no conv shape key (bench.py's config-5 side measurement:
+    the C -> 3 and 3 -> C convs, MeanShift), recorded on the launch stream; off unless enabled."""
+
+    def __init__(self):
+        self.on, self.pairs = False, {}
+
+    def enable(self):
+        self.on, self.pairs = True, {}
+
+    def begin(self, name):
+        if not self.on:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, e0)
+
+    def end(self, br):
+        if br is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.pairs.setdefault(br[0], []).append((br[1], e1))
+
+    def drain(self):
+        """-> {name: (mean milliseconds per launch, launches)}; disables recording."""
+        pairs, self.pairs, self.on = self.pairs, {}, False
+        if not pairs:
+            return {}
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in pairs.items()}
+
+
+OP_EVENTS = _OpEvents()
+
+
 class _FlopCount:
     """Optional tally of the matrix-pipe work of a step (bench.py's step_issued_frac): per conv / Linear launch the
     ALGORITHMIC flops of the op and the flops the dispatched kernel ISSUES for them (x 1/2 on the F(4,3) kernels, x 2/3 on
@@ -134,7 +169,7 @@ def pack_conv3x3(w: torch.Tensor, mode: int, ps: bool = False) -> torch.Tensor:
     """OIHW [O, I, 3, 3] -> packed [9, R/16, Nn, 16] (mode 0: forward, mode 1: dgrad)."""
     _chk(w, "pack_conv3x3.w")
     O, I = w.shape[0], w.shape[1]
-    assert w.shape[2:] == (3, 3)
+    assert tuple(w.shape[2:]) == (3, 3), f"pack_conv3x3: a 3x3 kernel is required, got {tuple(w.shape)}"
     R, Nn = (I, O) if mode == 0 else (O, I)
     nn_pad = 16 if Nn <= 16 else (Nn + 63) // 64 * 64
     out = torch.empty(9 * ((R + 15) // 16 * 16) * nn_pad, dtype=torch.float32, device=w.device)
@@ -223,6 +258,7 @@ def pack_conv3x3_wino4(w: torch.Tensor, mode: int, ps: bool = False) -> Wino4Pac
     """OIHW [O, I, 3, 3] -> transformed [18, R/16, Nn, 16] (mode 0: forward, mode 1: dgrad; ps: sub-pixel-major O order)."""
     _chk(w, "pack_conv3x3_wino4.w")
     O, I = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3), f"pack_conv3x3_wino4: a 3x3 kernel is required, got {tuple(w.shape)}"
     out = torch.empty(18 * O * I, dtype=torch.float32, device=w.device)
     rc = _lib.lib().pesr_pack_conv3x3_wino4(_p(w), _p(out), O, I, mode, int(ps), _stream())
     _lib.check(rc, f"pesr_pack_conv3x3_wino4[{O}x{I},mode{mode}]")
@@ -233,6 +269,7 @@ def pack_conv3x3_wino(w: torch.Tensor, mode: int, ps: bool = False) -> WinoPacke
     """OIHW [O, I, 3, 3] -> transformed [12, R/16, Nn, 16] (mode 0: forward, mode 1: dgrad; ps: sub-pixel-major O order)."""
     _chk(w, "pack_conv3x3_wino.w")
     O, I = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3), f"pack_conv3x3_wino: a 3x3 kernel is required, got {tuple(w.shape)}"
     out = torch.empty(12 * O * I, dtype=torch.float32, device=w.device)
     rc = _lib.lib().pesr_pack_conv3x3_wino(_p(w), _p(out), O, I, mode, int(ps), _stream())
     _lib.check(rc, f"pesr_pack_conv3x3_wino[{O}x{I},mode{mode}]")
@@ -297,6 +334,7 @@ def pack_conv3x3_bf16(w: torch.Tensor, mode: int, ps: bool = False) -> Bf16Packe
     """OIHW [O, I, 3, 3] fp32 -> [9, R/32, Nn, 32] bf16 (mode 0: forward, mode 1: dgrad with flipped taps; ps: sub-pixel-major O)."""
     _chk(w, "pack_conv3x3_bf16.w")
     O, I = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3), f"pack_conv3x3_bf16: a 3x3 kernel is required, got {tuple(w.shape)}"
     out = torch.empty(9 * O * I, dtype=torch.bfloat16, device=w.device)
     rc = _lib.lib().pesr_pack_conv3x3_bf16(_p(w), _p(out), O, I, mode, int(ps), _stream())
     _lib.check(rc, f"pesr_pack_conv3x3_bf16[{O}x{I},mode{mode}]")
@@ -349,13 +387,17 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
             and cout % 4 == 0 and 256 % (cout // 4) == 0:
         # RGB input layer: dedicated HBM-bound direct kernel on the un-packed OIHW weights
         FLOPS.add(18.0 * N * OH * OW * Cin * cout, 0.0, "rgb (HBM-bound, VALU)")
+        br = OP_EVENTS.begin(f"conv_rgb_in 3->{cout}")
         rc = _lib.lib().pesr_conv3x3_rgb_fwd(_p(x), _p(w_oihw), _p(bias), _p(y), N, H, W, cout, act, slope, _stream())
+        OP_EVENTS.end(br)
         _lib.check(rc, f"pesr_conv3x3_rgb_fwd[{N}x{H}x{W}x3->{cout}]")
         return y
     if rgb_out_eligible(Cin, cout, stride) and skip is None and mask is None and not ps_out and alpha == 1.0 and w_oihw is not None:
         # -> RGB output layer: dedicated HBM-bound kernel on the un-packed OIHW weights (no pack, no padded MFMAs)
         FLOPS.add(18.0 * N * OH * OW * Cin * cout, 1.0, "rgb (HBM-bound, MFMA)")
+        br = OP_EVENTS.begin(f"conv_rgb_out {Cin}->3")
         rc = _lib.lib().pesr_conv3x3_rgb_out_fwd(_p(x), _p(w_oihw), _p(bias), _p(y), N, H, W, Cin, act, slope, _stream())
+        OP_EVENTS.end(br)
         _lib.check(rc, f"pesr_conv3x3_rgb_out_fwd[{N}x{H}x{W}x{Cin}->3]")
         return y
     if callable(wp):
@@ -542,7 +584,9 @@ def meanshift_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, x_nchw: boo
     else:
         N, H, W, _ = x.shape
     y = torch.empty((N, 3, H, W) if y_nchw else (N, H, W, 3), dtype=torch.float32, device=x.device)
+    br = OP_EVENTS.begin(f"meanshift {H}x{W}")
     rc = _lib.lib().pesr_meanshift_fwd(_p(x), _p(w), _p(b), _p(y), N, H, W, int(x_nchw), int(y_nchw), _stream())
+    OP_EVENTS.end(br)
     _lib.check(rc, "pesr_meanshift_fwd")
     return y
 

@@ -90,19 +90,31 @@ class GradBuckets:
 
     The flat gradient buffer is cut into contiguous buckets of ~bucket_bytes.  A post-accumulate-grad hook on
     every parameter counts its bucket down; when the last gradient of a bucket lands, that slice is
-    all-reduced (SUM) asynchronously on the backend's communication stream - RCCL over xGMI on a GPU node,
-    gloo in the CPU tests.  Parameters are laid out in registration order while backward produces gradients
-    in reverse, so buckets complete from the tail of the buffer while the MFMA kernels of earlier layers
-    still run.  `finish()` launches whatever is left, waits, and returns 1/world_size (the averaging factor
-    that the caller folds into the optimizer kernel)."""
+    all-reduced (SUM) asynchronously on the transport's communication stream (pesr_amd/comm.py: RCCL over xGMI
+    on a GPU node - the direct communicator or ProcessGroupNCCL -, gloo in the CPU tests).  Parameters are laid
+    out in registration order while backward produces gradients in reverse, so buckets complete from the tail
+    of the buffer while the MFMA kernels of earlier layers still run.  `finish()` launches whatever is left,
+    waits, and returns 1/world_size (the averaging factor that the caller folds into the optimizer kernel).
 
-    def __init__(self, flat: FlatParams, group=None, bucket_bytes: int = 32 << 20):
+    `mode` is the bucket policy, switchable between steps (Trainer.calibrate_dp_policy picks it by measurement):
+    "overlap" as above; "deferred": the hooks launch nothing and finish() sends the WHOLE flat buffer as one
+    all-reduce - no collective is resident on a CU while the 256-workgroup conv kernels run (one held CU costs
+    each of those a second round, profiles/r03_cu_contention.txt), at the price of exposing the transfer."""
+
+    MODES = ("overlap", "deferred")
+
+    def __init__(self, flat: FlatParams, group=None, bucket_bytes: int = 32 << 20, transport=None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         # PESR_FORCE_DP=1 runs the bucket / hook / all-reduce machinery even with a single rank (lets the RCCL
         # path be exercised on a 1-GPU box)
         import os
         self.enabled = self.world > 1 or (os.environ.get("PESR_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized())
+        self.mode = "overlap"
+        self.transport = transport
+        if self.enabled and self.transport is None:
+            from . import comm
+            self.transport = comm.get_transport(flat.flat_g.device, group)
         self.bounds, self.members = [], []
         start, acc, cur = 0, 0, []
         esz = flat.flat_g.element_size()
@@ -120,6 +132,7 @@ class GradBuckets:
                 self.bucket_of[i] = b
         self._pending, self._launched, self._works = [], [], []
         self._hooks = []
+        self.launches = 0            # all-reduce calls issued so far (tests count them)
         # measure_exposed = True: bracket finish()'s waits with HIP events on the compute stream; exposed_ms() then reports
         # how long that stream stood still for all-reduces that backward did not cover (bench.py's comm_exposed_ms)
         self.measure_exposed, self._exposed = False, []
@@ -127,6 +140,12 @@ class GradBuckets:
             for i, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
+
+    def set_mode(self, mode: str) -> None:
+        if mode not in self.MODES:
+            raise ValueError(f"bucket policy must be one of {self.MODES}, got {mode!r}")
+        assert not any(self._launched), "the bucket policy changes between steps, not inside one"
+        self.mode = mode
 
     def reset(self) -> None:
         self._pending = [sum(1 for i in mem if self.flat.params[i].requires_grad) for mem in self.members]
@@ -138,20 +157,26 @@ class GradBuckets:
             self.flat.attach_one(i)          # a gradient that arrived as a foreign tensor is moved into the flat buffer first
             b = self.bucket_of[i]
             self._pending[b] -= 1
-            if self._pending[b] == 0 and not self._launched[b]:
+            if self._pending[b] == 0 and not self._launched[b] and self.mode == "overlap":
                 self._launch(b)
         return hook
 
-    def _launch(self, b: int) -> None:
-        lo, hi = self.bounds[b]
-        self._launched[b] = True
+    def _all_reduce(self, lo: int, hi: int) -> None:
         if self.flat.flat_g.is_cuda:
             PF.join_side_stream(self.flat.flat_g.device)    # (no-op unless PESR_SIDE_STREAM routes weight gradients to the side stream)
-        self._works.append(dist.all_reduce(self.flat.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launches += 1
+        self._works.append(self.transport.all_reduce_async(self.flat.flat_g[lo:hi]))
+
+    def _launch(self, b: int) -> None:
+        self._launched[b] = True
+        self._all_reduce(*self.bounds[b])
 
     def finish(self) -> float:
         if not self.enabled:
             return 1.0
+        if self.mode == "deferred" and not any(self._launched):
+            self._launched = [True] * len(self.members)
+            self._all_reduce(0, self.flat.numel)            # one collective over the whole buffer
         for b in range(len(self.members)):
             if not self._launched[b]:
                 self._launch(b)
@@ -159,8 +184,7 @@ class GradBuckets:
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        for w in self._works:
-            w.wait()        # (RCCL: the compute stream waits for the communication stream; the host does not block)
+        self.transport.wait(self._works)   # (RCCL: the compute stream waits for the communication stream; the host does not block)
         if timed:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()

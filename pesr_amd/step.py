@@ -84,6 +84,7 @@ class Trainer:
                              "no second-order oracle (use --precision fp32)")
         self._targets = {}
         self._graph = None
+        self.dp_policy, self.dp_step = "overlap", None
 
     def _target(self, batch, value, device):
         key = (batch, value, device)
@@ -195,10 +196,10 @@ class Trainer:
         What makes the step replayable: every kernel is launched on torch's current stream through the C ABI; the losses stay
         on the device; the two Adam steps read the learning rate and step count from device memory
         (FlatAdam.use_device_state); the packed conv weights are refreshed by launches that are part of the captured sequence.
-        Data-parallel runs capture too: the bucketed all-reduces that the autograd hooks launch (optim.GradBuckets) go to RCCL's
-        communication stream, which forks from the capturing stream at each launch and joins it again in FlatAdam.step's
-        wait - they become nodes of the same graph, still concurrent with the backward kernels between fork and join.  Every
-        rank must capture (and later replay) the same sequence."""
+        Data-parallel runs capture too: the bucketed all-reduces that the autograd hooks launch (optim.GradBuckets) go to the
+        transport's communication stream (pesr_amd/comm.py), which forks from the capturing stream at each launch and joins it
+        again in FlatAdam.step's wait - they become nodes of the same graph, still concurrent with the backward kernels between
+        fork and join.  Every rank must capture (and later replay) the same sequence."""
         if self.gradient_penalty:
             # the penalty's interpolation weights (reference train.py:217, one uniform draw per sample) become a graph INPUT:
             # gan_step_graphed draws them with torch.rand before every replay, or takes the caller's gp_u
@@ -218,7 +219,8 @@ class Trainer:
         steps = [o.steps for o in optims]
         watched, ops.KERNEL_EVENTS.shape = ops.KERNEL_EVENTS.shape, None       # no timing events inside a graph
         torch.cuda.synchronize()
-        self._quiesce_process_group()
+        for t in self._transports(optims):
+            t.begin_capture()       # (torch.distributed transport: its collectives move to a process group that never ran eagerly)
         st["graph"] = torch.cuda.CUDAGraph()
         # The captured repack launches hold raw pointers of their descriptor tables and packed buffers: the record keeps those
         # objects alive for as long as the graph lives, and tells _replay which packings a replay refreshes.
@@ -236,19 +238,89 @@ class Trainer:
         self._graph[kind] = st
         return self.gan_step_graphed if kind == "gan" else self.pretrain_step_graphed
 
-    @staticmethod
-    def _quiesce_process_group():
-        """Before a capture in a process that has issued RCCL collectives: give ProcessGroupNCCL's watchdog thread time to reap
-        the finished work objects of the eager steps.  The watchdog polls every 100 ms and hipEventQuery()s the end events of
-        the works still on its list; those events live on RCCL's communication stream, which becomes part of the capture when the
-        first captured all-reduce forks into it - a query from the watchdog then fails with "operation not permitted when stream
-        is capturing", the watchdog throws and the process aborts (seen once in three runs of the forced-DP graph test).  Works
-        launched UNDER capture are never put on that list.  After a device synchronize every listed work is complete, so two
-        polling periods empty the list."""
+    def _transports(self, optims=None):
+        """The distinct gradient-exchange transports (pesr_amd/comm.py) of the given optimizers' buckets."""
+        seen = []
+        for o in (optims if optims is not None else [o for o in (self.optim_D, self.optim_G) if o is not None]):
+            t = o.buckets.transport if o.buckets.enabled else None
+            if t is not None and all(t is not u for u in seen):
+                seen.append(t)
+        return seen
+
+    # ---- data-parallel schedule, chosen by measurement -------------------------------------------------------------------
+    DP_POLICIES = {"overlap": ("overlap", "overlap"), "defer_g": ("deferred", "overlap"), "defer_all": ("deferred", "deferred")}
+
+    def set_dp_policy(self, name: str) -> None:
+        """Bucket policies of (G, D): "overlap" - both exchanges ride under the backward passes (buckets launched from the
+        autograd hooks); "defer_g" - G's 172 MB go as ONE all-reduce after its backward pass, whose 256-workgroup body kernels
+        each pay a second round for any CU a collective holds (profiles/r03_cu_contention.txt), D's stay under D's backward and
+        the many-workgroup VGG kernels; "defer_all" - both deferred."""
+        g_mode, d_mode = self.DP_POLICIES[name]
+        if self.optim_G is not None:
+            self.optim_G.buckets.set_mode(g_mode)
+        if self.optim_D is not None:
+            self.optim_D.buckets.set_mode(d_mode)
+        self.dp_policy = name
+
+    def calibrate_dp_policy(self, kind, next_batch, steps=3, graph=True, candidates=None):
+        """Pick the data-parallel schedule by timing it (call it inside the warm-up, on every rank, after at least two eager
+        steps).  Each eager candidate of DP_POLICIES runs one untimed step (the policy switch) and `steps` timed ones; then,
+        if the transport is capturable, the step is captured as a hipGraph with the best eager bucket policy and its replays
+        are timed the same way.  Every rank uses the SLOWEST rank's time per candidate (Transport.host_max), so all ranks
+        choose alike; ties go to the earlier candidate.  Returns {"chosen", "ms_per_step": {candidate: ms}, "graph_error",
+        "transport"}; afterwards `self.dp_step` is the step function to call (eager method or graph replay).
+        These are real optimizer steps on real batches - nothing is thrown away."""
         import time
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-            time.sleep(0.3)
+        eager = self.gan_step if kind == "gan" else self.pretrain_step
+        trs = self._transports((self.optim_D, self.optim_G) if kind == "gan" else (self.optim_G,))
+        assert len(trs) == 1, "calibrate_dp_policy: the optimizers must share one enabled transport"
+        tr = trs[0]
+        cands = list(candidates) if candidates else (["overlap", "defer_g", "defer_all"] if kind == "gan" else ["overlap", "defer_g"])
+
+        def sync():
+            if torch.cuda.is_available():              # (the world-size-2 gloo test of this selection logic runs on the CPU)
+                torch.cuda.synchronize()
+
+        def timed(fn):
+            fn(*next_batch())                          # untimed: first step under the new schedule
+            tr.host_max([0.0])                         # aligns the ranks (and synchronises the device)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn(*next_batch())
+            sync()
+            return 1e3 * (time.perf_counter() - t0) / steps
+
+        mine = []
+        for c in cands:
+            self.set_dp_policy(c)
+            mine.append(timed(eager))
+        agreed = tr.host_max(mine)
+        ms = dict(zip(cands, agreed))
+        best = min(cands, key=lambda c: (ms[c], cands.index(c)))
+        self.set_dp_policy(best)
+        self.dp_step, chosen, graph_error = eager, best, None
+        if graph and tr.capturable:
+            t_graph, err = float("inf"), None
+            try:
+                lr, hr = next_batch()
+                fn = self.capture_gan_step(lr, hr) if kind == "gan" else self.capture_pretrain_step(lr, hr)
+                t_graph = timed(fn)
+            except Exception as e:                      # (decided together below: every rank still takes part in host_max)
+                err = f"{type(e).__name__}: {e}"
+            bad, t_all = tr.host_max([0.0 if err is None else 1.0, t_graph if err is None else 0.0])
+            if bad:
+                graph_error = err or "the capture failed on another rank"
+                if self._graph:
+                    self._graph.pop(kind, None)
+            else:
+                ms["graph+" + best] = t_all
+                if t_all < ms[best]:
+                    self.dp_step, chosen = fn, "graph+" + best
+                else:
+                    self._graph.pop(kind, None)         # frees the graph's private memory pool
+        return {"chosen": chosen, "ms_per_step": {k: round(v, 3) for k, v in ms.items()}, "graph_error": graph_error,
+                "transport": tr.name, "steps_per_candidate": steps}
 
     def _replay(self, kind, lr, hr, gp_u=None):
         assert self._graph and kind in self._graph, f"capture_{kind}_step first"

@@ -50,6 +50,12 @@ def pmc(out, paths):
         w.writerow(["kernel", "counter", "launches", "mean_per_launch"])
         for (k, c), (n, s) in sorted(agg.items()):
             w.writerow([k, c, n, round(s / n, 1)])
+    # side-car: hashes of the kernel sources the counters were taken on (bench.py refuses a summary whose kernel file changed since)
+    import glob, hashlib, json, os
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pesr_amd", "csrc")
+    meta = {"sources_sha256": {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()
+                               for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))}}
+    json.dump(meta, open(os.path.splitext(out)[0] + ".meta.json", "w"), indent=0, sort_keys=True)
 
 
 if __name__ == "__main__":

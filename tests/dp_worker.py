@@ -18,9 +18,11 @@ sys.path.insert(0, HERE)
 # "small": the GAN step as trained; "pretrain": the L1 step (well conditioned: pins 1/N and the shard layout tightly);
 # "tv": a GAN step whose generator gradient is the TV term alone (alpha_tv = 1, everything else 0) - TV is a SUM over the
 # global batch (reference train.py:137-140), so this pins the x world_size of pesr_amd/step.py
-CONFIGS = {"small": dict(C=64, depth=2, ps=24, B=4, steps=2, kind="gan", alphas={}),
-           "pretrain": dict(C=64, depth=2, ps=24, B=4, steps=2, kind="pretrain", alphas={}),
-           "tv": dict(C=64, depth=2, ps=24, B=4, steps=1, kind="gan", alphas=dict(alpha_tv=1.0, alpha_vgg=0.0, alpha_gan=0.0, alpha_l1=0.0))}
+# "policy": the bucket schedule the run uses (Trainer.set_dp_policy) - each of the three is held to the same parity once
+CONFIGS = {"small": dict(C=64, depth=2, ps=24, B=4, steps=2, kind="gan", alphas={}, policy="overlap"),
+           "pretrain": dict(C=64, depth=2, ps=24, B=4, steps=2, kind="pretrain", alphas={}, policy="defer_g"),
+           "tv": dict(C=64, depth=2, ps=24, B=4, steps=1, kind="gan", alphas=dict(alpha_tv=1.0, alpha_vgg=0.0, alpha_gan=0.0, alpha_l1=0.0),
+                      policy="defer_all")}
 
 
 def main():
@@ -55,6 +57,7 @@ def main():
     oD = FlatAdam(D.parameters(), lr=5e-5, bucket_bytes=256 << 10)
     assert oG.buckets.enabled and oD.buckets.enabled and len(oG.buckets.bounds) > 2
     tr = Trainer(G, D, V, oG, oD, world_size=world, **cfg["alphas"])
+    tr.set_dp_policy(cfg["policy"])
     gan = cfg["kind"] == "gan"
     losses = []
     for it in range(cfg["steps"]):
@@ -82,8 +85,12 @@ def main():
         torch.save({"losses": torch.stack(losses),
                     "G": {k: v.cpu() for k, v in G.state_dict().items()}, "D": {k: v.cpu() for k, v in D.state_dict().items()},
                     "G.grad": g0["G"], "D.grad": g0["D"],
-                    "world": world}, args.out)
+                    "world": world, "transport": oG.buckets.transport.name, "policy": tr.dp_policy,
+                    "launches": {"G": oG.buckets.launches, "D": oD.buckets.launches, "G.buckets": len(oG.buckets.bounds),
+                                 "D.buckets": len(oD.buckets.bounds)}}, args.out)
     dist.barrier()
+    from pesr_amd import comm
+    comm.close_transports()
     dist.destroy_process_group()
 
 

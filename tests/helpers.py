@@ -60,14 +60,15 @@ def adam_close(got, ref, lr, steps, what=""):
         assert rest.mean() <= 0.06 * lr + 2e-6 * scale, f"{what}: mean err of the rest {rest.mean():.3e} = {rest.mean() / lr:.3f} lr"
 
 
-def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0):
+def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0, detail=None):
     """Gradient parity where fp32 itself is ill-conditioned (ReLU / LeakyReLU kinks, BatchNorm batch statistics, L1's sign):
     `g` holds the REFERENCE's fp32 gradient samples, `g64` the same computation done in float64
     (tests/golden/make_golden_fp64.py).  Per tensor, our error against the fp64 truth may be at most `factor` x the
     reference's own fp32 error for that tensor, and never has to beat twice the worst error the reference itself shows on any
     tensor of the network (the errors are noise - a flipped ReLU mask is a discrete event - so a single tensor's own error is a
     one-sample estimate); the distance to the reference's fp32 values is then bounded by the sum of both errors.
-    get_grad(name) -> our gradient tensor.  Returns (tensors checked, (worst error / allowance, its name))."""
+    get_grad(name) -> our gradient tensor.  Returns (tensors checked, (worst error / allowance, its name)).
+    detail: a dict that receives {name: (our error, the reference's own fp32 error)}, both relative to the tensor's maximum."""
     keys = [k[len(prefix) + 5:] for k in g.files if k.startswith(prefix + "gidx.")]
     assert keys
     net_floor = float(g64[prefix + "floor_worst"])
@@ -82,6 +83,8 @@ def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0):
         e_ref = np.abs(ref32 - v64).max() / mx
         e_ours = np.abs(ours - v64).max() / mx
         tol = max(factor * e_ref, 2.0 * net_floor, 1e-6)
+        if detail is not None:
+            detail[key] = (float(e_ours), float(e_ref))
         assert e_ours <= tol, f"grad {prefix}{key}: error vs fp64 {e_ours:.2e} > {tol:.2e} (reference's own fp32 error {e_ref:.2e})"
         if e_ours / tol > worst[0]:
             worst = (e_ours / tol, key)

@@ -50,7 +50,7 @@ def test_conv3x3_fwd(N, H, W, Cin, Cout, stride):
     ref = O.conv3x3(x, w, b, stride)
     wp = ops.pack_conv3x3(w.cuda(), 0)
     y = ops.conv3x3_fwd(_nhwc(x), wp, b.cuda(), Cout, stride)
-    _close(_nchw(y), ref, 2e-6 * (Cin * 9) ** 0.5)
+    _close(_nchw(y), ref, 1e-5)          # flat kernel-level bound, the same the Winograd tests use; measured <= 6e-7
 
 
 def test_conv3x3_fwd_epilogue():
@@ -80,11 +80,11 @@ def test_conv3x3_dgrad_wgrad(N, H, W, Cin, Cout, stride):
     if Cout % 16 == 0 and Cin % 64 == 0:
         wpd = ops.pack_conv3x3(w.cuda(), 1)
         dx = ops.conv3x3_dgrad(_nhwc(dy), wpd, (N, H, W, Cin), stride)
-        _close(_nchw(dx), dx_ref, 2e-6 * (Cout * 9) ** 0.5)
+        _close(_nchw(dx), dx_ref, 1e-5)
     if Cin % 64 == 0 and Cout % 64 == 0:
         dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), stride)
-        _close(dw.cpu(), dw_ref, 2e-6 * (N * OH * OW) ** 0.5)
-        _close(db.cpu(), db_ref, 2e-6 * (N * OH * OW) ** 0.5)
+        _close(dw.cpu(), dw_ref, 1e-5)
+        _close(db.cpu(), db_ref, 1e-5)
 
 
 def test_conv3x3_pixel_shuffle_fused():
@@ -369,7 +369,7 @@ def test_conv3x3_rgb_out_kernel(N, H, W, Cin, bias, act):
     xg, wg, bg = _nhwc(x), w.cuda(), (b.cuda() if bias else None)
     kw = dict(act=ops.ACT_LRELU, slope=0.2) if act == 2 else {}
     y = ops.conv3x3_fwd(xg, lambda: (_ for _ in ()).throw(AssertionError("the packed weights must not be needed")), bg, 3, w_oihw=wg, **kw)
-    _close(_nchw(y), ref, 2e-6 * (Cin * 9) ** 0.5)
+    _close(_nchw(y), ref, 1e-5)          # flat kernel-level bound, the same the Winograd tests use; measured <= 6e-7
     ops.USE_RGB_OUT = False
     try:
         y2 = ops.conv3x3_fwd(xg, ops.pack_conv3x3(wg, 0), bg, 3, w_oihw=wg, **kw)

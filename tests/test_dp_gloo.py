@@ -175,3 +175,82 @@ def test_two_rank_rasgan_losses_equal_full_batch():
     (ld + 3.0 * lg).backward()
     assert torch.allclose(losses, torch.stack([ld.detach(), lg.detach()]), rtol=1e-6, atol=1e-7)
     assert torch.allclose(g_pr, pr.grad, rtol=1e-5, atol=1e-8) and torch.allclose(g_pf, pf.grad, rtol=1e-5, atol=1e-8)
+
+
+def _policy_worker(rank, world, port, q):
+    """Two ranks pick the data-parallel schedule by measurement (Trainer.calibrate_dp_policy): rank 1 is made slow under the
+    "overlap" schedule only, so the max-over-ranks times must make BOTH ranks choose "defer_g"."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from pesr_amd import comm
+        from pesr_amd.optim import FlatParams, GradBuckets
+        from pesr_amd.step import Trainer
+        torch.set_num_threads(2)
+        sd = gen_sd(16, 1)
+        params = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+        leaves = dict(zip(sd.keys(), params))
+        flat = FlatParams(params)
+        buckets = GradBuckets(flat, bucket_bytes=8 << 10)
+        assert isinstance(buckets.transport, comm.TorchGroup) and buckets.transport.backend == "gloo" and not buckets.transport.capturable
+        nb = len(buckets.bounds)
+        assert nb > 3
+
+        class Opt:
+            pass
+        oG = Opt(); oG.buckets = buckets
+        launches = {}
+
+        class T(Trainer):
+            def pretrain_step(self, lr, hr):
+                flat.zero_grad(); buckets.reset()
+                n0 = buckets.launches
+                sr = OM.generator_forward(leaves, lr, 1, 0.1)
+                F.l1_loss(sr, hr).backward()
+                if rank == 1 and buckets.mode == "overlap":
+                    time.sleep(0.05)                   # this rank is slow under this schedule only
+                assert buckets.finish() == 1.0 / world
+                launches.setdefault(buckets.mode, set()).add(buckets.launches - n0)
+                return {"l1": torch.zeros(())}
+
+        tr = T(None, optim_G=oG, world_size=world)
+        B = 2
+        lr = detrand.image_batch((B, 3, 8, 8), 11 + rank); hr = detrand.image_batch((B, 3, 32, 32), 12 + rank)
+        info = tr.calibrate_dp_policy("pretrain", lambda: (lr, hr), steps=2)
+        assert info["chosen"] == "defer_g" and tr.dp_policy == "defer_g" and buckets.mode == "deferred", info
+        assert tr.dp_step == tr.pretrain_step and info["graph_error"] is None and "graph+defer_g" not in info["ms_per_step"]
+        assert info["ms_per_step"]["overlap"] >= 50.0 > info["ms_per_step"]["defer_g"], info      # rank 0 sees rank 1's time
+        assert launches == {"overlap": {nb}, "deferred": {1}}, launches                         # one collective when deferred
+        # the deferred all-reduce moves the same gradients: both schedules give the same averaged gradient
+        tr.set_dp_policy("overlap"); tr.pretrain_step(lr, hr); g_a = flat.flat_g.clone()
+        tr.set_dp_policy("defer_g"); tr.pretrain_step(lr, hr); g_b = flat.flat_g.clone()
+        assert torch.allclose(g_a, g_b, rtol=1e-6, atol=1e-7 * float(g_a.abs().max()))
+        q.put((rank, info["chosen"], info["ms_per_step"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_dp_policy_selection_agrees():
+    world = 2
+    ctx = mp.get_context("spawn")
+    got = None
+    for attempt in range(3):
+        port, q = _free_port(), ctx.Queue()
+        procs = [ctx.Process(target=_policy_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            got = [q.get(timeout=150) for _ in range(world)]
+        except Exception:
+            got = None
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+        if got is not None and all(p.exitcode == 0 for p in procs):
+            break
+        got = None
+    assert got is not None, "the 2-rank gloo job failed three times"
+    assert {g[1] for g in got} == {"defer_g"} and got[0][2] == got[1][2], got      # same choice from the same agreed numbers

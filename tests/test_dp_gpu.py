@@ -52,28 +52,35 @@ def _two_steps(C=64, depth=2, ps=8, B=4, graph=False, steps=2):
     return torch.stack(logs), oG, oD
 
 
-def test_single_rank_nccl_forced_dp_is_bit_identical(monkeypatch):
+def _one_rank_group():
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        calls = []
-        real = dist.all_reduce
 
-        def counted(t, *a, **k):
-            calls.append(t.numel())
-            return real(t, *a, **k)
-        monkeypatch.setattr(dist, "all_reduce", counted)
+
+def _close_group():
+    from pesr_amd import comm
+    comm.close_transports()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+def test_single_rank_nccl_forced_dp_is_bit_identical(monkeypatch, transport):
+    """transport "rccl": the direct communicator (ctypes over librccl, pesr_amd/comm.py); "torch": ProcessGroupNCCL."""
+    from pesr_amd import comm
+    monkeypatch.setenv("PESR_DP_TRANSPORT", transport)
+    _one_rank_group()
+    try:
         monkeypatch.setenv("PESR_FORCE_DP", "1")
         la, oGa, oDa = _two_steps()
         assert oGa.buckets.enabled and oDa.buckets.enabled and len(oGa.buckets.bounds) > 2 and len(oDa.buckets.bounds) > 2
-        n_dp = len(calls)
+        assert oGa.buckets.transport is oDa.buckets.transport                     # ONE communicator for both optimizers
+        assert isinstance(oGa.buckets.transport, comm.DirectRccl if transport == "rccl" else comm.TorchGroup), oGa.buckets.transport.name
         # 2 steps x (every G bucket + every D bucket), each launched exactly once
-        assert n_dp == 2 * (len(oGa.buckets.bounds) + len(oDa.buckets.bounds)), (n_dp, len(oGa.buckets.bounds), len(oDa.buckets.bounds))
-        assert sum(calls) == 2 * (oGa.flat.numel + oDa.flat.numel)
+        assert oGa.buckets.launches == 2 * len(oGa.buckets.bounds) and oDa.buckets.launches == 2 * len(oDa.buckets.bounds)
         monkeypatch.delenv("PESR_FORCE_DP")
         lb, oGb, oDb = _two_steps()
-        assert not oGb.buckets.enabled and len(calls) == n_dp
+        assert not oGb.buckets.enabled and oGb.buckets.launches == 0
         assert torch.equal(la, lb), (la, lb)
         for a, b in ((oGa, oGb), (oDa, oDb)):
             assert torch.equal(a.flat.flat_p, b.flat.flat_p) and torch.equal(a.flat.flat_g, b.flat.flat_g)
@@ -81,18 +88,92 @@ def test_single_rank_nccl_forced_dp_is_bit_identical(monkeypatch):
         # the same through the hipGraph path: the forced-DP step CAPTURED (all-reduces included) and replayed twice against
         # four plain eager steps
         monkeypatch.setenv("PESR_FORCE_DP", "1")
-        n0 = len(calls)
         lc, oGc, oDc = _two_steps(graph=True, steps=4)
         assert oGc.buckets.enabled
         # two eager steps + ONE capture pass issue all-reduce calls; the two replays issue none from Python
-        assert len(calls) - n0 == 3 * (len(oGc.buckets.bounds) + len(oDc.buckets.bounds)), (len(calls) - n0)
+        assert oGc.buckets.launches == 3 * len(oGc.buckets.bounds) and oDc.buckets.launches == 3 * len(oDc.buckets.bounds)
         monkeypatch.delenv("PESR_FORCE_DP")
         le, oGe, oDe = _two_steps(steps=4)          # plain twin, four eager steps
         assert torch.equal(lc, le), (lc, le)
         for a, b in ((oGc, oGe), (oDc, oDe)):
             assert torch.equal(a.flat.flat_p, b.flat.flat_p) and torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
     finally:
-        dist.destroy_process_group()
+        _close_group()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+def test_forced_dp_capture_twenty_times(monkeypatch, transport):
+    """The data-parallel capture has no timing-based synchronisation left (round 3 slept three watchdog periods before it):
+    eager collectives right before the capture, no pause, twenty captures + replays in a row, each bit-identical to the first.
+    A watchdog thread that queried an event of a capturing stream would abort the process."""
+    monkeypatch.setenv("PESR_DP_TRANSPORT", transport)
+    _one_rank_group()
+    try:
+        monkeypatch.setenv("PESR_FORCE_DP", "1")
+        first = None
+        for i in range(20):
+            l, oG, oD = _two_steps(graph=True, steps=3)
+            state = (l, oG.flat.flat_p.clone(), oD.flat.flat_p.clone())
+            if first is None:
+                first = state
+            assert all(torch.equal(x, y) for x, y in zip(state, first)), i
+    finally:
+        _close_group()
+
+
+def test_dp_policy_calibration_one_rank_rccl(monkeypatch):
+    """Trainer.calibrate_dp_policy on hardware (one-rank RCCL group, direct communicator): the three eager schedules and the
+    captured step are all timed, one is chosen, and - an all-reduce over one rank being the identity and a replay being
+    bit-identical to eager - the parameters after the calibration and three more steps on the chosen schedule equal a plain
+    run of the same number of steps on the same batches, bit for bit."""
+    from model import Discriminator, Generator, VGG
+    from pesr_amd.optim import FlatAdam
+    from pesr_amd.step import Trainer
+    monkeypatch.setenv("PESR_DP_TRANSPORT", "rccl")
+    _one_rank_group()
+    try:
+        C, depth, ps, B = 64, 2, 8, 4
+
+        def run(forced):
+            if forced:
+                monkeypatch.setenv("PESR_FORCE_DP", "1")
+            else:
+                monkeypatch.delenv("PESR_FORCE_DP", raising=False)
+            G = Generator({"num_channels": C, "depth": depth, "res_scale": 0.1}); G.load_state_dict(gen_sd(C, depth)); G.cuda()
+            D = Discriminator({"patch_size": ps, "spectral_norm": False}); D.load_state_dict(dis_sd(ps)); D.cuda()
+            V = VGG(); V.load_state_dict(vgg_sd()); V.cuda()
+            oG = FlatAdam(G.parameters(), lr=5e-5, bucket_bytes=64 << 10)
+            oD = FlatAdam(D.parameters(), lr=5e-5, bucket_bytes=256 << 10)
+            tr = Trainer(G, D, V, oG, oD)
+            n = [0]
+
+            def next_batch():
+                i = n[0]; n[0] += 1
+                return detrand.image_batch((B, 3, ps, ps), 700 + i).cuda(), detrand.image_batch((B, 3, 4 * ps, 4 * ps), 800 + i).cuda()
+            for _ in range(2):
+                tr.gan_step(*next_batch())
+            info = None
+            if forced:
+                info = tr.calibrate_dp_policy("gan", next_batch, steps=2)
+                step = tr.dp_step
+            else:
+                step = tr.gan_step
+            while n[0] < 2 + 4 * 3 + 1 + 3:          # 2 eager + 4 candidates x (1 + 2) + the capture's batch + 3 more
+                if not forced and n[0] == 2 + 3 * 3:
+                    next_batch()                      # the batch the twin's capture consumed without running a step
+                    continue
+                log = step(*next_batch())
+            return info, oG.flat.flat_p.clone(), oD.flat.flat_p.clone(), {k: float(v) for k, v in log.items()}
+        info, pG, pD, log = run(True)
+        assert info["transport"] == "rccl-direct" and info["graph_error"] is None, info
+        assert set(info["ms_per_step"]) >= {"overlap", "defer_g", "defer_all"} and any(k.startswith("graph+") for k in info["ms_per_step"]), info
+        assert info["chosen"] in info["ms_per_step"] and all(v > 0 for v in info["ms_per_step"].values())
+        _, qG, qD, log2 = run(False)
+        assert log == log2, (log, log2)
+        assert torch.equal(pG, qG) and torch.equal(pD, qD)
+        print("calibration:", info)
+    finally:
+        _close_group()
 
 
 def _launch_worker(nproc, config, backend, share_gpu, out):
@@ -152,6 +233,12 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
         pytest.skip(f"{nproc} GPUs needed, {torch.cuda.device_count()} visible")
     got = _launch_worker(nproc, config, backend, share, str(tmp_path / "dp.pt"))
     assert got["world"] == nproc
+    from dp_worker import CONFIGS
+    c = CONFIGS[config]
+    assert got["policy"] == c["policy"] and got["transport"] == ("rccl-direct" if backend == "nccl" else "torch.distributed[gloo]"), got["transport"]
+    n_g, n_d = {"overlap": (got["launches"]["G.buckets"], got["launches"]["D.buckets"]), "defer_g": (1, got["launches"]["D.buckets"]),
+                "defer_all": (1, 1)}[c["policy"]]
+    assert got["launches"]["G"] == c["steps"] * n_g and got["launches"]["D"] == (c["steps"] * n_d if c["kind"] == "gan" else 0), got["launches"]
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     st32, cfg, batch = _oracle_step(config, nproc, torch.float32)
     st64, _, batch64 = _oracle_step(config, nproc, torch.float64)
@@ -200,3 +287,42 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
         for k, v in st32.d.items():
             if v.is_floating_point() and "running" not in k:
                 adam_close(got["D"][k], v, 5e-5, cfg["steps"], "D." + k)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="nn.DataParallel over several devices needs two visible GPUs")
+def test_nn_dataparallel_two_devices_matches_single_device():
+    """The reference's own multi-GPU form, single process: `nn.DataParallel(G)` / `(D)` (reference train.py:114-118,303).  The
+    replicas are shallow copies that SHARE each module's PackedConvWeights while their weights live on different devices and
+    their forwards run on concurrent threads: per-device pack slots behind a lock, per-device one-time kernel
+    attributes (common.h PesrDeviceOnce).  Generator: outputs and parameter gradients of a batch scattered over two devices
+    against the same batch on one device; Discriminator: per-replica BatchNorm statistics = two half-batch calls on one device."""
+    import torch.nn as nn
+    from model import Discriminator, Generator
+    from pesr_amd import functional as PF
+    from pesr_amd.model.basic import nhwc
+    C, depth, ps, B = 64, 2, 12, 4
+    G = Generator({"num_channels": C, "depth": depth, "res_scale": 0.1}); G.load_state_dict(gen_sd(C, depth)); G.cuda(0)
+    lr = detrand.image_batch((B, 3, ps, ps), 900).cuda(0)
+    hr = detrand.image_batch((B, 3, 4 * ps, 4 * ps), 901).cuda(0)
+    sr1 = G(lr)
+    PF.l1_loss(nhwc(sr1), nhwc(hr.contiguous(memory_format=torch.channels_last))).backward()
+    g1 = {k: p.grad.clone() for k, p in G.named_parameters()}
+    G.zero_grad(set_to_none=True)
+    Gp = nn.DataParallel(G, device_ids=[0, 1])
+    for _ in range(2):                 # twice: the second pass runs on packings cached per device
+        G.zero_grad(set_to_none=True)
+        sr2 = Gp(lr)
+        assert sr2.device.index == 0 and sr2.shape == sr1.shape
+        PF.l1_loss(nhwc(sr2.contiguous(memory_format=torch.channels_last)), nhwc(hr.contiguous(memory_format=torch.channels_last))).backward()
+        close(sr2, sr1.detach(), 1e-6, 1e-4, "DataParallel forward")
+        for k, p in G.named_parameters():
+            close(p.grad, g1[k], 1e-4, what="DataParallel grad " + k)
+    D = Discriminator({"patch_size": ps, "spectral_norm": False}); D.load_state_dict(dis_sd(ps)); D.cuda(0)
+    x = detrand.image_batch((B, 3, 4 * ps, 4 * ps), 902).cuda(0)
+    with torch.no_grad():
+        ref = torch.cat([D(x[:B // 2]), D(x[B // 2:])])           # per-replica batch statistics
+    D.load_state_dict(dis_sd(ps))                                  # (running statistics back to their start)
+    out = nn.DataParallel(D, device_ids=[0, 1])(x)
+    close(out, ref, 1e-5, what="DataParallel D forward")
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in D.parameters())

@@ -391,6 +391,35 @@ def test_res_block_constructor_branches(bias, bn, act):
         close(pg.grad, pr.grad, 1e-4, what="grad " + k)
 
 
+@pytest.mark.parametrize("k", [5, 1])
+def test_res_block_other_kernel_size_vs_torch(k):
+    """ResBlock(n_feats, kernel_size != 3) in the reference's default configuration (bias, no BN, ReLU; model/basic.py:33-52
+    accepts any size): must take the un-fused generic-kernel path, never the 3x3 packers (a [C,C,5,5] weight read
+    as [C,C,3,3] was silently wrong) - against the same block built from nn.Conv2d on the CPU."""
+    import torch.nn as nn
+    from model import ResBlock
+    from pesr_amd import ops
+    torch.manual_seed(5)
+    blk = ResBlock(64, k, res_scale=0.1)
+    assert not blk._fused
+    ref = nn.Sequential(nn.Conv2d(64, 64, k, padding=k // 2), nn.ReLU(True), nn.Conv2d(64, 64, k, padding=k // 2))
+    ref.load_state_dict(blk.body.state_dict())
+    blk = blk.cuda()
+    x = detrand.uniform((2, 64, 12, 16), 31)      # W % 4 == 0, C % 64 == 0: a shape the Winograd dispatch WOULD have taken
+    xr = x.clone().requires_grad_(True); xg = x.cuda().requires_grad_(True)
+    gy = detrand.uniform((2, 64, 12, 16), 32)
+    yr = ref(xr).mul(0.1) + xr; yr.backward(gy)
+    yg = blk(xg); yg.backward(gy.cuda())
+    close(yg, yr.detach(), 2e-5, what="forward")
+    close(xg.grad, xr.grad, 1e-4, what="grad input")
+    for (kk, pg), (_, pr) in zip(blk.body.named_parameters(), ref.named_parameters()):
+        close(pg.grad, pr.grad, 1e-4, what="grad " + kk)
+    w5 = torch.zeros(64, 64, 5, 5, device="cuda")
+    for pack in (ops.pack_conv3x3, ops.pack_conv3x3_wino, ops.pack_conv3x3_wino4, ops.pack_conv3x3_bf16):
+        with pytest.raises(AssertionError, match="3x3"):
+            pack(w5, 0)
+
+
 def test_discriminator_second_order_forward_equals_forward():
     """Discriminator.forward_second_order (un-fused, twice differentiable) computes the same D(x) and the same first-order
     gradients as the fused forward."""

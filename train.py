@@ -61,8 +61,12 @@ def build_parser():
     p.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (smoke runs)")
     p.add_argument("--hip_graph", type=str, default="auto", choices=["auto", "true", "false", "True", "False"],
                    help="capture the train step into a hipGraph after two eager iterations and replay it (same results bit for "
-                        "bit; the host no longer issues ~1000 launches per step).  auto = on for a single-GPU run, off under "
-                        "torch.distributed (there the RCCL all-reduces are captured with the step: opt in with true)")
+                        "bit; the host no longer issues ~1000 launches per step).  auto = on for a single-GPU run; under "
+                        "torch.distributed the captured step (RCCL all-reduces included) is one candidate of --dp_policy auto")
+    p.add_argument("--dp_policy", type=str, default="auto", choices=["auto", "overlap", "defer_g", "defer_all"],
+                   help="under torch.distributed: how the gradient all-reduces are scheduled against the backward kernels.  auto = "
+                        "measured during the first iterations (Trainer.calibrate_dp_policy: eager overlap, G's exchange deferred behind "
+                        "its backward pass, both deferred, and - unless --hip_graph false - the captured step) and the fastest kept")
     p.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16"],
                    help="fp32 (default): the reference's arithmetic.  bf16: OPTIONAL mixed-precision mode - the stride-1 3x3 convs with "
                         "32-multiple input / 64-multiple output channels run on the bf16 MFMA (both operands rounded to bf16, fp32 "
@@ -254,6 +258,13 @@ def main(argv=None):
     keys = ("l1", "vgg", "g", "tv", "d") if gan else ("l1",)
     graphed, graph_shapes, eager_at_shape = None, None, 0
     use_graph = device.type == "cuda" and (world == 1 if args.hip_graph == "auto" else str2bool(args.hip_graph))
+    # data-parallel schedule: fixed by flag, or measured once (inside the first epoch that is long enough for it)
+    dp_on = optim_G.buckets.enabled
+    dp_calibrate = dp_on and args.dp_policy == "auto"
+    if dp_on and args.dp_policy != "auto":
+        trainer.set_dp_policy(args.dp_policy)
+    CALIB_STEPS = 3
+    calib_need = (4 if gan else 3) * (CALIB_STEPS + 1) + 2          # iterations the calibration consumes at most
 
     for epoch in range(1, args.num_epochs + 1):
         # The reference calls scheduler.step() at epoch START (train.py:156,185-186); under its pinned torch 0.4 the
@@ -264,13 +275,37 @@ def main(argv=None):
             sampler.set_epoch(epoch)
         running = torch.zeros(len(keys), device=device)      # accumulated on the device: one host sync per epoch
         iters = 0
-        for lr_img, hr_img in train_loader:
-            lr_img, hr_img = lr_img.to(device, non_blocking=True), hr_img.to(device, non_blocking=True)
+        batch_iter = iter(train_loader)
+        n_iters = len(train_loader) if not args.max_iters else min(len(train_loader), args.max_iters)
+        consumed = [0]
+
+        def next_batch():
+            a, b = next(batch_iter)
+            consumed[0] += 1
+            return a.to(device, non_blocking=True), b.to(device, non_blocking=True)
+
+        while consumed[0] < n_iters:
+            try:
+                lr_img, hr_img = next_batch()
+            except StopIteration:
+                break
             if graphed is not None and lr_img.shape == graph_shapes[0] and hr_img.shape == graph_shapes[1]:
                 logs = graphed(lr_img, hr_img)
             else:
                 logs = trainer.gan_step(lr_img, hr_img) if gan else trainer.pretrain_step(lr_img, hr_img)
-                if use_graph and graphed is None:
+                if dp_calibrate and iters >= 1 and n_iters - consumed[0] >= calib_need:
+                    # every rank is at the same iteration of equally long loaders: the calibration's collectives line up.  Its
+                    # steps are real training steps (their losses are not added to this epoch's averages).
+                    info = trainer.calibrate_dp_policy("gan" if gan else "pretrain", next_batch, steps=CALIB_STEPS,
+                                                       graph=args.hip_graph == "auto")
+                    dp_calibrate = False
+                    if rank == 0:
+                        print("data-parallel schedule:", info)
+                    if info["chosen"].startswith("graph"):
+                        graphed, graph_shapes = trainer.dp_step, (lr_img.shape, hr_img.shape)
+                    # (--hip_graph true / false: the flag decides and only the bucket schedule was measured; the capture below
+                    # then runs with that schedule)
+                if use_graph and graphed is None and not dp_calibrate:
                     # capture after TWO eager steps at these shapes: the second one has seen every weight packing the first one
                     # created (some only in its backward pass), so nothing is allocated or uploaded under capture
                     shapes = (lr_img.shape, hr_img.shape)
@@ -280,8 +315,6 @@ def main(argv=None):
                         graphed = (trainer.capture_gan_step if gan else trainer.capture_pretrain_step)(lr_img, hr_img)
             running += torch.stack([logs[k].float() for k in keys])
             iters += 1
-            if args.max_iters and iters >= args.max_iters:
-                break
         if world > 1:
             dist.all_reduce(running)
             running /= world
@@ -318,6 +351,8 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
     if world > 1:
+        from pesr_amd import comm
+        comm.close_transports()
         dist.destroy_process_group()
 
 
