@@ -162,6 +162,12 @@ int pesr_conv3x3_rgb_out_fwd(const float* x, const float* w, const float* bias, 
  * convolution_backward(input) for it.  dy [N][H][W][3], w OIHW [3][C][3][3] (NOT packed), dx [N][H][W][C]. */
 int pesr_conv3x3_rgb_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, void* stream);
 
+/* Input gradient of a 3 -> C conv (stride 1): Discriminator features.0 (reference model/pesr.py:53) and vgg19 features.0
+ * (model/vgg.py:8-10) on the Generator's backward path, i.e. ATen convolution_backward(input) for them.  dy [N][H][W][C]
+ * (C a multiple of 64, <= 512), w = the forward conv's OIHW [C][3][3][3] (NOT packed), dx [N][H][W][3].  HBM-bound (reads dy
+ * once): the kernel of pesr_conv3x3_rgb_out_fwd with a transposing weight index.  (ABI 12) */
+int pesr_conv3x3_rgb_in_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, void* stream);
+
 /* Weight gradient of the RGB-boundary convs (one operand has 3 channels): reference `embed`
  * (model/pesr.py:23), Discriminator features.0 (model/pesr.py:53), Upsampler's last conv (model/basic.py:60).
  * a: the C-channel tensor [N][H][W][C], b3: the 3-channel tensor [N][H][W][3].

@@ -54,6 +54,7 @@ SIGNATURES.update({
     "pesr_conv3x3_rgb_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "pesr_conv3x3_rgb_out_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "pesr_conv3x3_rgb_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pesr_conv3x3_rgb_in_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "pesr_meanshift_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pesr_meanshift_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "pesr_pixel_shuffle_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -10,11 +10,12 @@ Two transports behind one small interface (`all_reduce_async` / `wait` / `host_m
   graph edges) with no process-wide state to quiesce first.  torch.distributed is used once, to hand rank 0's `ncclUniqueId` to
   the other ranks.
 * `TorchGroup` - `torch.distributed.all_reduce(async_op=True)` on a process group: gloo in the CPU tests and for ranks that share
-  one GPU, and the fallback over ProcessGroupNCCL should the direct communicator fail to come up.  Under hipGraph capture it uses
-  a DEDICATED process group on which no eager collective ever ran: the watchdog thread of ProcessGroupNCCL hipEventQuery()s the
-  end events of eager works it has not reaped yet, an event's stream may not be capturing while it is queried, and works launched
-  under capture are never put on the watchdog's list - so the streams that join a capture must be streams the watchdog holds no
-  events of.  (Round 3 slept three watchdog periods instead.)
+  one GPU, and the EAGER fallback over ProcessGroupNCCL should the direct communicator fail to come up.  It is NOT capturable:
+  ProcessGroupNCCL's watchdog thread hipEventQuery()s the end events of eager works it has not reaped yet, an event's stream may
+  not be capturing while it is queried, and nothing tells the caller when the watchdog has reaped a work - round 3 slept three
+  watchdog periods before a capture, and a dedicated capture-only group (tried in round 4) still needs one eager collective to
+  bring its communicator up, i.e. the same race: twenty captures in a row aborted.  Captured data-parallel steps therefore
+  exist on the direct transport only (Trainer._capture refuses the other).
 
 `make_transport()` picks one for a process group; every rank takes the same decision (the choice is agreed with a MIN
 all-reduce on the bootstrap group).
@@ -166,17 +167,16 @@ class DirectRccl(Transport):
 
 
 class TorchGroup(Transport):
+    capturable = False
+
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.name = f"torch.distributed[{self.backend}]"
-        self.capturable = self.backend == "nccl"
-        self._capture_group = None
-        self._active = group
 
     def all_reduce_async(self, t: torch.Tensor):
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._active, async_op=True)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def wait(self, handles) -> None:
         for w in handles:
@@ -189,12 +189,8 @@ class TorchGroup(Transport):
         return [float(x) for x in t.cpu()]
 
     def begin_capture(self) -> None:
-        """From now on the collectives run on a process group of their own, created here (collectively) and never used eagerly
-        before: the capture joins only THAT group's communication stream, of whose events the watchdog holds none."""
-        if self.backend == "nccl" and self._capture_group is None:
-            ranks = list(range(dist.get_world_size())) if self.group is None else dist.get_process_group_ranks(self.group)
-            self._capture_group = dist.new_group(ranks=ranks, backend="nccl")
-            self._active = self._capture_group
+        raise CommError(f"a data-parallel step over {self.name} cannot be captured into a hipGraph (ProcessGroupNCCL's watchdog queries "
+                        "events of the streams that join the capture): use the direct RCCL transport (PESR_DP_TRANSPORT=rccl or auto)")
 
 
 def make_transport(device: Optional[torch.device], group=None, prefer: Optional[str] = None) -> Transport:

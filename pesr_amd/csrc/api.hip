@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 11; }
+PESR_API int pesr_abi_version(void) { return 12; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -165,6 +165,10 @@ PESR_API int pesr_conv3x3_rgb_fwd(const float* x, const float* w, const float* b
 PESR_API int pesr_conv3x3_rgb_out_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
                                       float slope, void* stream) {
     return pesr_conv_rgb_out_fwd_launch(x, w, bias, y, N, H, W, C, act, slope, (hipStream_t)stream);
+}
+
+PESR_API int pesr_conv3x3_rgb_in_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, void* stream) {
+    return pesr_conv_rgb_in_dgrad_launch(dy, w, dx, N, H, W, C, (hipStream_t)stream);
 }
 
 PESR_API int pesr_conv3x3_rgb_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, void* stream) {

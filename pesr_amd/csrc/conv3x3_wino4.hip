@@ -55,9 +55,6 @@ struct Wino4Args {
     };
 
 constexpr int W4_BN = 64, W4_MG = 9;
-#ifndef W4_NO_TXTC
-#define W4_NO_TXTC 0
-#endif
 
 // Wave w owns the 16 channels w & 3 and HALF of the xi planes (w >> 2: xi 0..2 / 3..5): 27 accumulator tiles, 2 waves per SIMD.
 // (A 12-wave variant - a third of the xi planes per wave, 3 waves per SIMD in the 168-VGPR budget - measured 2 % slower.)
@@ -326,7 +323,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     const int co = n0 + cb * 16 + g * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias && a.ksplit == 1) bias4 = *(const f32x4*)(a.bias + co);
-    // batches of three m-tiles x two outputs: a batch's LDS reads and skip / mask loads are issued before its first store
+    // batches of three m-tiles x two outputs: a batch's LDS reads and skip / mask loads are issued before its first store.
+    // (Round 4 measured the skip / mask loads issued ONE BATCH AHEAD, the first batch's in front of the exchange barrier: 175.9 vs
+    // 172.6 us with bias + ReLU, 179.4 vs 177.1 with the skip, 179.0 vs 177.3 with the mask - slower in every form; the skip costs
+    // this epilogue 4.5 us, not the 11 us the one-chunk builds of round 3 had suggested.  profiles/r04_ab_notes.txt)
 #pragma unroll
     for (int ib = 0; ib < W4_MG; ib += 3) {
         f32x4 v[6], mkv[6], skv[6];
@@ -512,8 +512,8 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     });
     const dim3 grid((unsigned)(p.tiles * p.ksplit));
     if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0>), grid, dim3(512), p.lds, stream, a);
-    else if (p.TXT == 12 && !W4_NO_TXTC) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12>), grid, dim3(512), p.lds, stream, a);
-    else if (p.TXT == 24 && !W4_NO_TXTC) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24>), grid, dim3(512), p.lds, stream, a);
+    else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12>), grid, dim3(512), p.lds, stream, a);
+    else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24>), grid, dim3(512), p.lds, stream, a);
     else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0>), grid, dim3(512), p.lds, stream, a);
     if (p.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, act,

@@ -41,6 +41,8 @@ struct RgbOutArgs {
     int strips, halo, outw;   // strips per row; 1 when strips overlap (W > 192), else 0; output columns per strip
     int bands;                // ceil(H / TH)
     int act; float slope;
+    int wmode;                // 0: w is the conv's own OIHW [3][C][3][3]; 1: w is OIHW [C][3][3][3] of a 3 -> C conv whose INPUT GRADIENT
+                              //    this launch computes (x = its dy): w'[co][c][ky][kx] = w[c][co][2-ky][2-kx]
 };
 
 template <int RO_D>               // chunk ring depth per column tile (RO_D - 1 loads in flight)
@@ -64,7 +66,10 @@ __global__ __launch_bounds__(RO_NT) void conv_rgb_out_kernel(const RgbOutArgs a)
     for (int e = tid; e < C16 * 512; e += RO_NT) {
         const int c15 = e & 15, n = (e >> 4) & 31, chunk = e >> 9;
         float v = 0.f;
-        if (n < 27) { const int ky = n / 9, kx = (n - ky * 9) / 3, co = n % 3; v = a.w[((size_t)(co * a.C + chunk * 16 + c15) * 3 + ky) * 3 + kx]; }
+        if (n < 27) {
+            const int ky = n / 9, kx = (n - ky * 9) / 3, co = n % 3, c = chunk * 16 + c15;
+            v = a.wmode ? a.w[((size_t)(c * 3 + co) * 3 + (2 - ky)) * 3 + (2 - kx)] : a.w[((size_t)(co * a.C + c) * 3 + ky) * 3 + kx];
+        }
         wl[e] = v;
     }
     for (int e = tid; e < 4 * RO_PROW; e += RO_NT) pring[e] = 0.f;
@@ -180,12 +185,12 @@ __global__ __launch_bounds__(RO_NT) void conv_rgb_out_kernel(const RgbOutArgs a)
 }
 }  // namespace
 
-int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
-                                 float slope, hipStream_t stream) {
+static int rgb_out_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act, float slope,
+                          int wmode, hipStream_t stream) {
     if (N < 1 || H < 1 || W < 1 || C < 64 || C % 64 || C > 512) return PESR_EINVAL;   // the chunk loop is unrolled by the ring depth (>= 4)
     if ((size_t)W * C * 4 >= ((size_t)1 << 31)) return PESR_EINVAL;
     RgbOutArgs a{};
-    a.x = x; a.w = w; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.C = C; a.act = act; a.slope = slope;
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.C = C; a.act = act; a.slope = slope; a.wmode = wmode;
     if (W <= RO_COLS) { a.strips = 1; a.halo = 0; a.outw = RO_COLS; }
     else { a.halo = 1; a.outw = RO_COLS - 2; a.strips = pesr_cdiv(W, a.outw); }
     a.bands = pesr_cdiv(H, RO_TH);
@@ -199,4 +204,15 @@ int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bi
     if (C % 128 == 0) hipLaunchKernelGGL(conv_rgb_out_kernel<8>, grid, dim3(RO_NT), lds, stream, a);
     else hipLaunchKernelGGL(conv_rgb_out_kernel<4>, grid, dim3(RO_NT), lds, stream, a);
     return pesr_launch_status();
+}
+
+int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
+                                 float slope, hipStream_t stream) {
+    return rgb_out_launch(x, w, bias, y, N, H, W, C, act, slope, 0, stream);
+}
+
+// Input gradient of a 3 -> C conv = the C -> 3 conv of dy with the flipped, transposed kernel: the same HBM-bound kernel, reading
+// the forward conv's OIHW [C][3][3][3] weights through the transposing index (no pack, no padded MFMAs).
+int pesr_conv_rgb_in_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream) {
+    return rgb_out_launch(dy, w, nullptr, dx, N, H, W, C, PESR_ACT_NONE, 0.f, 1, stream);
 }

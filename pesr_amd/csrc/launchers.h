@@ -117,6 +117,7 @@ int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, f
                             float slope, hipStream_t stream);
 int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
                                  float slope, hipStream_t stream);
+int pesr_conv_rgb_in_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream);
 int pesr_conv_rgb_out_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream);
 
 int pesr_conv_kxk_fwd_launch(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int Cin, int Cout, int k, int s,

@@ -72,20 +72,27 @@ __global__ __launch_bounds__(64) void corr_rgb_kernel(const float* __restrict__ 
 // above issues one 4-byte load per 27 FMAs and is bound by them).  The B operand - the 27 neighbourhood values of the pixel -
 // is gathered from three zero-padded B3 rows staged in LDS.  One workgroup = 256 channels x rows_per_split image rows; wave w
 // owns channels 64 w .. 64 w + 63 (4 M tiles x 2 N tiles); loads run CR_D - 1 k-steps (4 pixels each) ahead.
+// CW = 4: the four waves own four 64-channel groups of the same pixels (C % 256 == 0).  CW = 1 (round 4; C % 64 == 0 - the
+// 3 -> 64 layers, Discriminator features.0: 158 us on the VALU kernel above, 0.95 TB/s): the four waves own the SAME 64 channels
+// and every fourth k-step each, so a wave-instruction still reads 1 KiB of contiguous memory (four pixels x 256 B); every wave
+// writes its own partial.
 constexpr int CR_D = 8;
+template <int CW>
 __global__ __launch_bounds__(256) void corr_rgb_mfma_kernel(const float* __restrict__ A, const float* __restrict__ b3p,
                                                             float* __restrict__ part, int NH, int H, int W, int C,
                                                             int rows_per_split) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][3][(W + 2) * 3] padded B3 rows, double buffered
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int ncol = C >> 8;
+    const int ncol = C / (64 * CW);
     const int cc = blockIdx.x % ncol, sp = blockIdx.x / ncol;
-    const int c0 = cc * 256 + wave * 64;
+    const int c0 = CW == 4 ? cc * 256 + wave * 64 : cc * 64;
+    const int sw = CW == 4 ? 0 : wave, sm = CW == 4 ? 1 : 4;              // this wave's k-steps: sm * j + sw
     const int r0 = sp * rows_per_split;
     int r1 = r0 + rows_per_split; if (r1 > NH) r1 = NH;
     const int WP3 = (W + 2) * 3;
-    const int ksteps = (W + 3) >> 2;
+    const int ksteps_all = (W + 3) >> 2;
+    const int ksteps = CW == 4 ? ksteps_all : (ksteps_all + 3) >> 2;       // per wave (CW = 1: steps past the row read zeros)
     f32x4 acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -113,8 +120,8 @@ __global__ __launch_bounds__(256) void corr_rgb_mfma_kernel(const float* __restr
             (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(av >> 32)) << 32) |
                     (unsigned)__builtin_amdgcn_readfirstlane((unsigned)av)),     // (unsigned): the builtin returns int - no sign extension
             0, row_bytes, 0x00020000);
-        auto a_load = [&](int s) -> u32x4 {                                // k-step s: pixel 4 s + g (beyond the row: zeros)
-            const int px = 4 * s + g;
+        auto a_load = [&](int s) -> u32x4 {                                // this wave's k-step s: pixel 4 (sm s + sw) + g (beyond the row: zeros)
+            const int px = 4 * (sm * s + sw) + g;
             return __builtin_amdgcn_raw_buffer_load_b128(rs, px < W ? a_lane + (unsigned)px * C * 4 : 0x80000000u, 0, 0);
         };
         u32x4 fa[CR_D];
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) void corr_rgb_mfma_kernel(const float* __restr
             const int s = s0 + u;
             if (s < ksteps) {
                 fa[(u + CR_D - 1) % CR_D] = a_load(s + CR_D - 1);
-                int px = 4 * s + g; if (px > W - 1) px = W - 1;            // a pixel past the row multiplies zeros: any finite B value
+                int px = 4 * (sm * s + sw) + g; if (px > W - 1) px = W - 1; // a pixel past the row multiplies zeros: any finite B value
                 const float b0 = bl[px * 3 + boff0];
                 const float b1 = boff1 >= 0 ? bl[px * 3 + boff1] : 0.f;
                 const f32x4 av = __builtin_bit_cast(f32x4, fa[u]);
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void corr_rgb_mfma_kernel(const float* __restr
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int n = 16 * h + i, c = c0 + 4 * (4 * g + jj) + t;
-                if (n < 27) part[((size_t)sp * C + c) * 27 + n] = acc[t][h][jj];
+                if (n < 27) part[((size_t)(CW == 4 ? sp : sp * 4 + wave) * C + c) * 27 + n] = acc[t][h][jj];
             }
 }
 
@@ -187,19 +194,22 @@ __global__ void colsum3_final_kernel(const double* __restrict__ dsum, float* __r
 }
 
 namespace {
-struct RgbPlan { int nsplit, rows_per_split, mfma; size_t pad_bytes, part_bytes, dsum_bytes, bias_bytes, total; };
+struct RgbPlan { int nsplit, rows_per_split, mfma, nparts; size_t pad_bytes, part_bytes, dsum_bytes, bias_bytes, total; };
 static bool rgb_plan(int N, int H, int W, int C, RgbPlan* p) {
     if (C < 1) return false;
     const int NH = N * H;
     // MFMA kernel (C % 256 == 0): one 4-wave workgroup per 256 channels and row range, two resident per CU -> ~512 workgroups
-    p->mfma = C % 256 == 0 && (size_t)W * C * 4 < ((size_t)1 << 31) && (size_t)2 * 3 * (W + 2) * 3 * sizeof(float) <= 64 * 1024;
-    int want = p->mfma ? 512 / (C / 256) : 4096 / ((C + 63) / 64);
+    // mfma = 4: four channel groups per workgroup; 1: one (its four waves split the pixels and write a partial each); 0: VALU kernel
+    const bool fits = (size_t)W * C * 4 < ((size_t)1 << 31) && (size_t)2 * 3 * (W + 2) * 3 * sizeof(float) <= 64 * 1024;
+    p->mfma = !fits ? 0 : (C % 256 == 0 ? 4 : (C % 64 == 0 ? 1 : 0));
+    int want = p->mfma ? 512 / (C / (64 * p->mfma)) : 4096 / ((C + 63) / 64);
     if (want > NH) want = NH;
     if (want < 1) want = 1;
     p->rows_per_split = (NH + want - 1) / want;
     p->nsplit = (NH + p->rows_per_split - 1) / p->rows_per_split;
+    p->nparts = p->mfma == 1 ? 4 * p->nsplit : p->nsplit;
     p->pad_bytes = ((size_t)N * (H + 2) * (W + 2) * 3 * sizeof(float) + 255) / 256 * 256;
-    p->part_bytes = ((size_t)p->nsplit * C * 27 * sizeof(float) + 255) / 256 * 256;
+    p->part_bytes = ((size_t)p->nparts * C * 27 * sizeof(float) + 255) / 256 * 256;
     p->dsum_bytes = ((size_t)C * 27 * sizeof(double) + 255) / 256 * 256;
     p->bias_bytes = (size_t)1024 * 2 * (C > 4 ? C : 4) * sizeof(float) + 2 * (size_t)(C > 4 ? C : 4) * sizeof(double) + 256;
     p->total = p->pad_bytes + p->part_bytes + p->dsum_bytes + p->bias_bytes;
@@ -226,12 +236,16 @@ int pesr_conv3x3_wgrad_rgb_launch(const float* A, const float* b3, float* dw, fl
     hipLaunchKernelGGL(pad_rgb_kernel, dim3((unsigned)((padn + 255) / 256 < 2048 ? (padn + 255) / 256 : 2048)), dim3(256), 0, stream, b3, b3p, N, H, W);
     if (p.mfma) {
         const size_t lds = (size_t)2 * 3 * (W + 2) * 3 * sizeof(float);
-        hipLaunchKernelGGL(corr_rgb_mfma_kernel, dim3((C / 256) * p.nsplit), dim3(256), lds, stream, A, (const float*)b3p, part, N * H, H, W, C,
-                           p.rows_per_split);
+        if (p.mfma == 4)
+            hipLaunchKernelGGL(corr_rgb_mfma_kernel<4>, dim3((C / 256) * p.nsplit), dim3(256), lds, stream, A, (const float*)b3p, part, N * H, H, W,
+                               C, p.rows_per_split);
+        else
+            hipLaunchKernelGGL(corr_rgb_mfma_kernel<1>, dim3((C / 64) * p.nsplit), dim3(256), lds, stream, A, (const float*)b3p, part, N * H, H, W,
+                               C, p.rows_per_split);
     } else {
         hipLaunchKernelGGL(corr_rgb_kernel, dim3(((C + 63) / 64) * p.nsplit), dim3(64), 0, stream, A, (const float*)b3p, part, N * H, H, W, C, p.rows_per_split);
     }
-    hipLaunchKernelGGL(corr_rgb_final_kernel, dim3((C * 27 + 63) / 64), dim3(1024), 0, stream, (const float*)part, p.nsplit, dw, C, mode, alpha,
+    hipLaunchKernelGGL(corr_rgb_final_kernel, dim3((C * 27 + 63) / 64), dim3(1024), 0, stream, (const float*)part, p.nparts, dw, C, mode, alpha,
                        accumulate);
     int rc = pesr_launch_status();
     if (rc || !db) return rc;

@@ -423,7 +423,9 @@ class Conv3x3Fn(Function):
         dx = dw = db = None
         # dx of a C -> 3 conv is a 3 -> C conv of dy: the HBM-bound direct kernel, no packed weights
         rgb_dgrad = weight.shape[0] == 3 and ctx.stride == 1 and not ctx.relu_in and not ps and cin % 4 == 0 and 256 % (cin // 4) == 0
-        wpd = ctx.cache.for_dgrad(weight, x.shape, ctx.stride) if ctx.needs_input_grad[0] and not rgb_dgrad else None
+        # ... and dx of a 3 -> C conv is a C -> 3 conv of dy: the HBM-bound kernel of the C -> 3 forward, on the OIHW weights
+        rgb_in_dgrad = not ctx.relu_in and not ps and ops.rgb_in_dgrad_eligible(cin, weight.shape[0], ctx.stride)
+        wpd = ctx.cache.for_dgrad(weight, x.shape, ctx.stride) if ctx.needs_input_grad[0] and not (rgb_dgrad or rgb_in_dgrad) else None
         if ctx.needs_input_grad[1]:
             want_b = ctx.has_bias and ctx.needs_input_grad[2]
             outs = dict(dw_out=grad_out(weight), db_out=grad_out(ctx.bias_ref) if want_b else None)
@@ -437,6 +439,8 @@ class Conv3x3Fn(Function):
         if ctx.needs_input_grad[0]:
             if rgb_dgrad:
                 dx = ops.conv3x3_rgb_dgrad(gy, weight.detach(), tuple(x.shape))
+            elif rgb_in_dgrad:
+                dx = ops.conv3x3_rgb_in_dgrad(gy, weight.detach(), tuple(x.shape))
             else:
                 dx = ops.conv3x3_dgrad(gy, wpd, tuple(x.shape), ctx.stride, mask=x if ctx.relu_in else None, ps_in=ps)
         return dx, dw, db, None, None, None, None, None
@@ -468,7 +472,10 @@ class ConvLReluFn(Function):
                 dw, db = ops.conv3x3_wgrad(x, gz, ctx.stride, want_bias=want_b, ps_in=ctx.cache.ps, dw_out=grad_out(weight),
                                            db_out=grad_out(ctx.bias_ref) if want_b else None)
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3x3_dgrad(gz, ctx.cache.for_dgrad(weight, x.shape, ctx.stride), tuple(x.shape), ctx.stride, ps_in=ctx.cache.ps)
+            if not ctx.cache.ps and ops.rgb_in_dgrad_eligible(x.shape[3], weight.shape[0], ctx.stride):
+                dx = ops.conv3x3_rgb_in_dgrad(gz, weight.detach(), tuple(x.shape))
+            else:
+                dx = ops.conv3x3_dgrad(gz, ctx.cache.for_dgrad(weight, x.shape, ctx.stride), tuple(x.shape), ctx.stride, ps_in=ctx.cache.ps)
         return dx, dw, db, None, None, None
 
 
@@ -643,7 +650,8 @@ class ConvBnLReluFn(Function):
             dz, dgamma, dbeta = bwd(z, gy, gamma.detach(), beta.detach(), stats, ctx.slope, ctx.y_nchw, need_p,
                                     dgamma_out=grad_out(gamma) if need_p else None, dbeta_out=grad_out(beta) if need_p else None)
         dx = dw = db = None
-        wpd = ctx.cache.for_dgrad(weight, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
+        rgb_in_dgrad = ops.rgb_in_dgrad_eligible(x.shape[3], weight.shape[0], ctx.stride)     # Discriminator features.0
+        wpd = ctx.cache.for_dgrad(weight, x.shape, ctx.stride) if ctx.needs_input_grad[0] and not rgb_in_dgrad else None
         if again:
             if x.shape[3] == 3:
                 ops.conv3x3_wgrad_rgb(dz, x, 0, want_bias=False, dw_out=a_w, accumulate=True)
@@ -659,7 +667,7 @@ class ConvBnLReluFn(Function):
                 else:
                     dw, db = ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=want_b, dw_out=o_w, db_out=o_b)
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3x3_dgrad(dz, wpd, tuple(x.shape), ctx.stride)
+            dx = ops.conv3x3_rgb_in_dgrad(dz, weight.detach(), tuple(x.shape)) if rgb_in_dgrad else ops.conv3x3_dgrad(dz, wpd, tuple(x.shape), ctx.stride)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 

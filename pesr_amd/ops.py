@@ -459,6 +459,29 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
     return dx
 
 
+USE_RGB_IN_DGRAD = True   # tests switch it off to compare with the implicit-GEMM path
+
+
+def rgb_in_dgrad_eligible(cin: int, cout: int, stride: int) -> bool:
+    """Shapes of pesr_conv3x3_rgb_in_dgrad (input gradient of a 3 -> C conv, stride 1)."""
+    return USE_RGB_IN_DGRAD and cin == 3 and stride == 1 and cout % 64 == 0 and cout <= 512
+
+
+def conv3x3_rgb_in_dgrad(dy: torch.Tensor, w_oihw: torch.Tensor, in_shape) -> torch.Tensor:
+    """dx of a 3 -> C conv (stride 1, no fused mask): dy [N,H,W,C], w OIHW [C,3,3,3] -> dx [N,H,W,3] (HBM-bound: reads dy once)."""
+    _chk(dy, "conv3x3_rgb_in_dgrad.dy"); _chk(w_oihw, "conv3x3_rgb_in_dgrad.w")
+    N, H, W, three = in_shape
+    C = dy.shape[3]
+    assert three == 3 and dy.shape == (N, H, W, C) and w_oihw.shape == (C, 3, 3, 3)
+    dx = torch.empty((N, H, W, 3), dtype=torch.float32, device=dy.device)
+    FLOPS.add(18.0 * N * H * W * C * 3, 1.0, "rgb (HBM-bound, MFMA)")
+    br = OP_EVENTS.begin(f"conv_rgb_in_dgrad {C}->3")
+    rc = _lib.lib().pesr_conv3x3_rgb_in_dgrad(_p(dy), _p(w_oihw), _p(dx), N, H, W, C, _stream())
+    OP_EVENTS.end(br)
+    _lib.check(rc, f"pesr_conv3x3_rgb_in_dgrad[{N}x{H}x{W}x3<-{C}]")
+    return dx
+
+
 def conv3x3_rgb_dgrad(dy: torch.Tensor, w_oihw: torch.Tensor, in_shape) -> torch.Tensor:
     """dx of a C -> 3 conv (stride 1, no fused mask): dy [N,H,W,3], w OIHW [3,C,3,3] -> dx [N,H,W,C]."""
     _chk(dy, "conv3x3_rgb_dgrad.dy"); _chk(w_oihw, "conv3x3_rgb_dgrad.w")

@@ -213,14 +213,14 @@ class Trainer:
 
     def _capture(self, kind, fn, optims, lr, hr, gp_u=None):
         from . import ops
+        for t in self._transports(optims):
+            t.begin_capture()       # (the torch.distributed transport refuses: only the direct RCCL transport is capturable)
         for o in optims:
             o.use_device_state()
         st = {"lr": lr.clone(), "hr": hr.clone(), "optims": optims, "gp_u": gp_u}
         steps = [o.steps for o in optims]
         watched, ops.KERNEL_EVENTS.shape = ops.KERNEL_EVENTS.shape, None       # no timing events inside a graph
         torch.cuda.synchronize()
-        for t in self._transports(optims):
-            t.begin_capture()       # (torch.distributed transport: its collectives move to a process group that never ran eagerly)
         st["graph"] = torch.cuda.CUDAGraph()
         # The captured repack launches hold raw pointers of their descriptor tables and packed buffers: the record keeps those
         # objects alive for as long as the graph lives, and tells _replay which packings a replay refreshes.

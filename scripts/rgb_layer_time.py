@@ -34,6 +34,20 @@ def main():
     rows.append(("weight gradient (conv3x3_wgrad_rgb)", timeit(lambda: ops.conv3x3_wgrad_rgb(x, dy, 1))))
     for name, us in rows:
         print(f"{name:<46} {us:8.1f} us   {mb / us:6.2f} TB/s  ({100 * mb / us / 6.29:5.1f} % of 6.29 TB/s)")
+    # the 3 -> 64 layers (Discriminator features.0, vgg19 features.0) at 16 x 192 x 192: the 151 MB 64-channel tensor is the traffic
+    C = 64
+    x3 = torch.rand(N, H, W, 3, device="cuda") * 255
+    w3 = (torch.rand(C, 3, 3, 3, device="cuda") - 0.5) * 0.2
+    b3 = torch.rand(C, device="cuda")
+    dy64 = torch.rand(N, H, W, C, device="cuda") - 0.5
+    mb = dy64.numel() * 4 / 1e6
+    wpd = ops.pack_conv3x3(w3, 1)
+    rows = [("3->64 forward (conv_rgb_in)", timeit(lambda: ops.conv3x3_fwd(x3, None, b3, C, w_oihw=w3))),
+            ("3->64 input gradient, streaming (rgb_in_dgrad)", timeit(lambda: ops.conv3x3_rgb_in_dgrad(dy64, w3, (N, H, W, 3)))),
+            ("3->64 input gradient, implicit GEMM (round 3)", timeit(lambda: ops.conv3x3_dgrad(dy64, wpd, (N, H, W, 3)))),
+            ("3->64 weight gradient (conv3x3_wgrad_rgb)", timeit(lambda: ops.conv3x3_wgrad_rgb(dy64, x3, 0)))]
+    for name, us in rows:
+        print(f"{name:<46} {us:8.1f} us   {mb / us:6.2f} TB/s  ({100 * mb / us / 6.29:5.1f} % of 6.29 TB/s)")
 
 if __name__ == "__main__":
     main()

@@ -1,5 +1,7 @@
 """Same-session interleaved A/B of builds of the F(4,3) conv kernel (each a separate libpesr_hip*.so, scripts/build_variant.sh):
-    python scripts/wino4_ab.py [fwd|skip|wgrad] pesr_amd/libpesr_hip.so exp/libX.so ...     (G-body shape, batch 16)"""
+    python scripts/wino4_ab.py [fwd|skip|mask|both|wgrad] pesr_amd/libpesr_hip.so exp/libX.so ...     (G-body shape, batch 16)
+fwd = bias + ReLU (ResBlock conv1); skip = bias, x 0.1, + skip (conv2, and the input gradient of conv1 without bias); mask = x 0.1 and
+ReLU mask (input gradient of conv2); both = mask + skip (tests only)."""
 import ctypes, os, statistics, sys
 import torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +9,7 @@ sys.path.insert(0, R)
 from pesr_amd import _lib
 what = "fwd"
 args = sys.argv[1:]
-if args and args[0] in ("fwd", "skip", "wgrad"):
+if args and args[0] in ("fwd", "skip", "mask", "both", "wgrad"):
     what = args.pop(0)
 libs = args
 N, H, W, C = 16, 48, 48, 256
@@ -30,9 +32,13 @@ def run(l, iters=20):
     e0.record()
     for _ in range(iters):
         if what == "wgrad":   # transposed F(4,3) weight gradient + its reduce kernel (algo 0 = auto)
-            rc = l.pesr_conv3x3_wgrad(x.data_ptr(), sk.data_ptr(), dw.data_ptr(), dbias.data_ptr(), N, H, W, C, C, 1, 1.0, 0, 0, ws.data_ptr(), ws.numel(), s)
-        elif what == "skip":   # dgrad-of-conv1 style epilogue: ReLU mask + residual add
+            rc = l.pesr_conv3x3_wgrad(x.data_ptr(), sk.data_ptr(), dw.data_ptr(), dbias.data_ptr(), N, H, W, C, C, 1, 1.0, 0, 0, 0, ws.data_ptr(), ws.numel(), s)
+        elif what == "both":   # ReLU mask + residual add
             rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), None, sk.data_ptr(), x.data_ptr(), y.data_ptr(), N, H, W, C, C, 0.1, 0, 0.0, 0, 0, None, 0, s)
+        elif what == "skip":
+            rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), b.data_ptr(), sk.data_ptr(), None, y.data_ptr(), N, H, W, C, C, 0.1, 0, 0.0, 0, 0, None, 0, s)
+        elif what == "mask":
+            rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), None, None, sk.data_ptr(), y.data_ptr(), N, H, W, C, C, 0.1, 0, 0.0, 0, 0, None, 0, s)
         else:
             rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1.0, 1, 0.0, 0, 0, None, 0, s)
         assert rc == 0, rc

@@ -47,6 +47,9 @@ def test_rgb_convs(N, H, W, C):
     wpd = ops.pack_conv3x3(w.cuda(), 1)
     dx = ops.conv3x3_dgrad(_nhwc(dy), wpd, (N, H, W, 3))
     _close(_nchw(dx), dx_ref, 1e-5, "dgrad C->3")
+    assert ops.rgb_in_dgrad_eligible(3, C, 1)
+    dxd = ops.conv3x3_rgb_in_dgrad(_nhwc(dy), w.cuda(), (N, H, W, 3))     # HBM-bound kernel (the C -> 3 forward kernel, transposing weight index)
+    _close(_nchw(dxd), dx_ref, 1e-5, "dgrad C->3, streaming kernel")
     dw, db = ops.conv3x3_wgrad_rgb(_nhwc(dy), _nhwc(x3), 0)
     _close(dw.cpu(), dw_ref, 1e-5, "wgrad 3->C")
     _close(db.cpu(), db_ref, 1e-5, "bgrad 3->C")
@@ -67,6 +70,36 @@ def test_rgb_convs(N, H, W, C):
     dw2, db2 = ops.conv3x3_wgrad_rgb(_nhwc(xc), _nhwc(dy3), 1)
     _close(dw2.cpu(), dw_ref, 1e-5, "wgrad C->3")
     _close(db2.cpu(), db_ref, 1e-5, "bgrad C->3")
+
+
+def test_rgb_in_dgrad_full_size_and_through_autograd():
+    """Input gradient of Discriminator features.0 / vgg19 features.0 at the benchmarked size (16 x 192 x 192, 3 -> 64) on the
+    streaming kernel vs the implicit-GEMM path it replaces (reference model/pesr.py:53, model/vgg.py:8-10), and through the
+    autograd Functions that dispatch to it."""
+    from pesr_amd import functional as PF
+    from pesr_amd import ops
+    N, H, W, C = 16, 192, 192, 64
+    w = _rand(C, 3, 3, 3, seed=2, lo=-0.2, hi=0.2).cuda()
+    dy = _rand(N, H, W, C, seed=5).cuda()
+    a = ops.conv3x3_rgb_in_dgrad(dy, w, (N, H, W, 3))
+    b = ops.conv3x3_dgrad(dy, ops.pack_conv3x3(w, 1), (N, H, W, 3))
+    _close(a.cpu(), b.cpu(), 1e-5, "streaming vs implicit GEMM")
+    x = detrand.image_batch((2, 3, 20, 28), 3)
+    ws = _rand(C, 3, 3, 3, seed=7, lo=-0.2, hi=0.2)
+    g = _rand(2, C, 20, 28, seed=8)
+    dx_ref, _, _ = O.conv3x3_grads(x, ws, g)
+    xg = _nhwc(x).requires_grad_(True)
+    wg = ws.cuda().requires_grad_(True)
+    y = PF.conv3x3(xg, wg, None, PF.PackedConvWeights())
+    calls = []
+    real = ops.conv3x3_rgb_in_dgrad
+    ops.conv3x3_rgb_in_dgrad = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        y.backward(_nhwc(g))
+    finally:
+        ops.conv3x3_rgb_in_dgrad = real
+    assert calls, "Conv3x3Fn.backward did not take the streaming kernel"
+    _close(xg.grad.permute(0, 3, 1, 2).cpu(), dx_ref, 1e-5, "Conv3x3Fn dx")
 
 
 def test_meanshift():
