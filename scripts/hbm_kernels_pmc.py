@@ -32,9 +32,11 @@ for _ in range(4):
               lambda: ops.linear_dgrad(dyl, wl),
               lambda: ops.linear_wgrad(dyl, xl, dw_out=dwl),
               lambda: ops.bn_lrelu_fwd(z, ga, be, rm, rv, nb),
-              lambda: ops.conv3x3_fwd(x3, None, None, 64, w_oihw=w64)):
+              lambda: ops.conv3x3_fwd(x3, None, None, 64, w_oihw=w64),
+              lambda: ops.conv3x3_rgb_in_dgrad(z, w64, (N, H, W, 3)),             # round 4: dx of the 3 -> 64 convs, streaming kernel
+              lambda: ops.conv3x3_wgrad_rgb(z, x3, 0, want_bias=False)):          # round 4: their weight gradient on the MFMA form
         flush.zero_()
         f()
 torch.cuda.synchronize()
 print("algorithmic MB per call: C->3 forward / C<-3 input gradient / its weight gradient 604; Linear fwd / dgrad / wgrad 302; "
-      "BN+LReLU forward 151 read twice + 151 written; 3->64 forward 151 written")
+      "BN+LReLU forward 151 read twice + 151 written; 3->64 forward 151 written; 3->64 input gradient and weight gradient 151 read")
