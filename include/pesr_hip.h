@@ -110,7 +110,6 @@ int pesr_pack_conv3x3_wino4(const float* w, float* w_packed, int Cout, int Cin, 
 int pesr_conv3x3_wino4(const float* x, const float* w_packed, const float* bias, const float* skip, const float* mask, float* y,
                        int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in,
                        void* workspace, size_t ws_bytes, void* stream);
-
 /* ---- OPTIONAL bf16-operand mode (never the default) ---------------------------------------------------------------
  * Stride-1 3x3 conv (pad 1) on v_mfma_f32_16x16x32_bf16: same tensors (fp32 NHWC in HBM), same fused epilogue and PixelShuffle
  * options as pesr_conv3x3_wino4, but BOTH operands of every product are rounded to bf16 (round to nearest even) and summed in

@@ -237,6 +237,7 @@ class Wino4Packed:
 
 
 USE_WINO4 = __import__("os").environ.get("PESR_WINO4", "1") != "0"   # PESR_WINO4=0: no F(4,3) kernel (F(2,3) / direct instead)
+
 _W4_SCORE = {}
 
 

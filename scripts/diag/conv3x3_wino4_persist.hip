@@ -68,7 +68,13 @@ constexpr int W4_BN = 64, W4_MG = 9;
 // or 0 = a.TXT at run time.  With it the (ky, xi) part of a fragment read's address is an immediate of the ds_read and "this
 // chunk's V buffer" is one add per fragment offset and chunk: the loop loses its per-read address add (87 -> 38 v_add_u32 per
 // chunk and wave; G body forward 185.1 -> 182.6 us, 227.7 -> 229.4 patches/s).
-template <bool DENSE, int TXTC>
+// PERSIST (round 4): the launch has gridDim.x (<= 256, a multiple of n_tiles) workgroups and every workgroup walks the work units
+// u = b, b + gridDim.x, ... (same n-tile, successive pixel tiles).  A launch with several rounds of workgroups per CU pays the
+// un-overlapped prologue (first chunk staged synchronously) and epilogue (exchange + 37.7 MB of stores per 256 workgroups) once per
+// ROUND; here the last chunk of a tile stages chunk 0 of the NEXT tile (in the slot where a one-tile workgroup prefetches its last
+// chunk again), the exchange runs in three batches inside the V buffer that is dead by then, and the stores drain under the next
+// tile's MFMAs.  Not for split-K launches (few tiles by definition).
+template <bool DENSE, int TXTC, bool PERSIST>
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     static_assert(!(DENSE && TXTC), "the constant-row-length form is for the non-dense layout");
     constexpr int NT = 512;                                // threads of the workgroup
@@ -92,13 +98,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     int b = blockIdx.x;
     if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int tiles_total = a.n_tiles * a.tiles_x * a.tiles_y * a.N;
-    const int ks = b / tiles_total;
-    int bid = b - ks * tiles_total;
-    const int nt = bid % a.n_tiles;  bid /= a.n_tiles;
-    const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    const int img = bid / a.tiles_y;
-    const int gy0 = ty * a.TR, gt0 = tx * TXTv;          // first output row / first x-tile of the tile
+    const int ks = PERSIST ? 0 : b / tiles_total;
+    int unit = b - ks * tiles_total;                       // work unit = (pixel tile, n-tile), n-tile fastest
+    const int nt = unit % a.n_tiles;                       // (PERSIST: gridDim.x is a multiple of n_tiles, so nt never changes)
+    int img, gy0, gt0;                                     // image, first output row / first x-tile of the current tile
+    auto decode_unit = [&](int u) {
+        int bid = u / a.n_tiles;
+        const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
+        const int ty = bid % a.tiles_y;
+        img = bid / a.tiles_y;
+        gy0 = ty * a.TR; gt0 = tx * TXTv;
+    };
+    decode_unit(unit);
     const int n0 = nt * W4_BN;
     const int C16T = a.Cin >> 4;
     const int CB = ks * a.chunks_per_split;                // this workgroup's chunk range [CB, CB + C16)
@@ -142,7 +153,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     };
 
     // ---- staging items: (halo row, x-tile, 4-channel group); six input columns each; NU items per thread --------------------
-    const float* const x_img = a.x + (size_t)img * a.H * a.W * a.Cin;    // stacked: img == 0, rows run over all images
     const int n_items = a.HT * TXTv * 4;
     const int Cq = a.Cin >> 2;
     // Out-of-image columns (and whole halo rows) are fetched at offset 2^31, beyond the buffer descriptor's range: the load
@@ -154,26 +164,40 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         const int it = tid + u * NT;
         const int q = it & 3, rest = it >> 2;
         const int hrow = rest / TXTv, txt = rest - hrow * TXTv;
-        int iy = gy0 - 1 + hrow;
-        const int ix0 = 4 * (gt0 + txt) - 1;
-        bool item_ok = it < n_items && iy >= 0 && iy < a.H;
-        if (a.stack) {                                      // virtual row -> (image, row); the separator rows read zeros
-            const int im = iy / a.stack, yy = iy - im * a.stack;
-            item_ok = it < n_items && iy >= 0 && im < a.stack_n && yy < a.H;
-            iy = im * a.H + yy;
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int ix = ix0 + j;
-            const bool ok = item_ok && ix >= 0 && ix < a.W;
-            const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
-            st_off[u][j] = ok ? (unsigned)((pix + q * 4) * 4) : 0x80000000u;
-        }
         const int skey = DENSE ? ((hrow * TXTv + txt) >> 2) : ((txt >> 1) ^ (a.row_key * (hrow & 1)));
         st_dst[u] = it < n_items ? hrow * v_row + txt * 64 + ((q ^ skey) & 3) * 16 : -1;
     }
-    const __amdgpu_buffer_rsrc_t x_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)x_img, 0, (unsigned)((size_t)(a.stack ? a.stack_n : 1) * a.H * a.W * a.Cin * 4), 0x00020000);
+    const unsigned x_img_bytes = (unsigned)((size_t)(a.stack ? a.stack_n : 1) * a.H * a.W * a.Cin * 4);
+    __amdgpu_buffer_rsrc_t x_rsrc;
+    auto set_tile_src = [&]() {                            // staging offsets and image descriptor of tile (img, gy0, gt0)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int it = tid + u * NT;
+            const int q = it & 3, rest = it >> 2;
+            const int hrow = rest / TXTv, txt = rest - hrow * TXTv;
+            int iy = gy0 - 1 + hrow;
+            const int ix0 = 4 * (gt0 + txt) - 1;
+            bool item_ok = it < n_items && iy >= 0 && iy < a.H;
+            if (a.stack) {                                      // virtual row -> (image, row); the separator rows read zeros
+                const int im = iy / a.stack, yy = iy - im * a.stack;
+                item_ok = it < n_items && iy >= 0 && im < a.stack_n && yy < a.H;
+                iy = im * a.H + yy;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ix = ix0 + j;
+                const bool ok = item_ok && ix >= 0 && ix < a.W;
+                const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
+                st_off[u][j] = ok ? (unsigned)((pix + q * 4) * 4) : 0x80000000u;
+            }
+        }
+        // (provably wave-uniform base: no waterfall loops around the staging loads)
+        const unsigned long long pv = (unsigned long long)(a.x + (size_t)img * a.H * a.W * a.Cin);     // stacked: img == 0, rows run over all images
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pv >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pv)), 0, x_img_bytes, 0x00020000);
+    };
+    set_tile_src();
     auto chunk_off = [&](int cc) -> int {                  // channel part of an input address (bytes), chunk cc (absolute)
         int coff = cc * 16;
         if (a.ps_in) {   // chunk = channels [16cc, 16cc+16) of sub-pixel `sub`: one pixel of the shuffled tensor
@@ -255,139 +279,180 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     }
     __syncthreads();
 
-#pragma unroll 1
-    for (int c = 0; c < C16; ++c) {
-        char* const vcur = smem + (c & 1) * v_bytes;      // (TXTC: the fragment offsets carry the buffer, moved below)
-        char* const vnext = smem + ((c & 1) ^ 1) * v_bytes;
-        // No branch in the loop: the last chunk "prefetches" itself again (loads, transforms and LDS stores nobody consumes).  With
-        // the prefetch under `if (more)` the staging registers and weight fragments had two definitions merging at the loop header,
-        // and hipcc could not count the outstanding loads exactly.
-        const int cn = CB + (c + 1 < C16 ? c + 1 : c);
-        stage_load(0, cn);                                 // lands while this chunk computes
-        W4_READ_A(fa[0], vcur, 0, 0, 0)
-#pragma unroll
-        for (int s = 0; s < NSLAB; ++s) {                  // slab s = (ky, xl)
-            const int ky = s / NXL, xl = s - ky * NXL;
-            // weight slab s + 2 (of this chunk, or the first ones of the next)
-            {
-                if (s + 2 < NSLAB) fb[(s + 2) % 3] = ldb((s + 2) / NXL, (s + 2) % NXL, CB + c);
-                else fb[(s + 2) % 3] = ldb(0, s + 2 - NSLAB, cn);
-            }
-#pragma unroll
-            for (int grp = 0; grp < 3; ++grp) {
-                const int t = s * 3 + grp, cur = t & 1;
-                if (grp < 2) W4_READ_A(fa[cur ^ 1], vcur, ky, xl, grp + 1)
-                else if (s + 1 < NSLAB) W4_READ_A(fa[cur ^ 1], vcur, (s + 1) / NXL, (s + 1) % NXL, 0)
-                __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of the MFMA group (hipcc sinks it next to its use)
-                W4_MFMA(fa[cur], fb[s % 3], xl, grp)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // A third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs.
-            if (s == 2) { stage_store(0, vnext); stage_load(1, cn); __builtin_amdgcn_sched_barrier(0); }
-            if (s == 6) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
-        }
-        if (TXTC) {
-            const int dv = (c & 1) ? -v_bytes : v_bytes;
-#pragma unroll
-            for (int i = 0; i < W4_MG; ++i) a_off[i] += dv;
-        }
-        __syncthreads();                                   // V[next] complete and visible; everyone is done with V[cur]
-    }
-#undef W4_READ_A
-#undef W4_MFMA
-    // ---- epilogue ------------------------------------------------------------------------------------------------------------
-    // With the weights as the MFMA's A operand a lane holds, per m-tile i, FOUR CONSECUTIVE CHANNELS (cb*16 + 4g ..) of x-tile
-    // 16 i + r for its three xi planes.  y0 = M0 + (M1+M2) + (M3+M4), y1 = (M1-M2) + 2(M3-M4), y2 = (M1+M2) + 4(M3+M4),
-    // y3 = (M1-M2) + 8(M3-M4) + M5: the xi 0..2 wave finishes y0, y1 and the xi 3..5 wave y2, y3; each passes the other its two
-    // partial terms through LDS (lane-linear 16-byte slots: same lane of the partner wave), adds what it receives and stores
-    // 16 bytes per lane straight to global memory - the four channel-block waves fill a pixel's 256-byte line between them.
-    char* const xb = smem;
-    // slot (sender xh, i, k, cb, lane)
-    auto slot = [&](int sender, int i, int k) -> char* { return xb + ((((sender * W4_MG + i) * 2 + k) * 4 + cb) * 64 + lane) * 16; };
-    f32x4 keep[W4_MG][2];
-#pragma unroll
-    for (int i = 0; i < W4_MG; ++i) {
-        const f32x4 q0 = acc[0][i], q1 = acc[1][i], q2 = acc[2][i];
-        if (xt == 0) {
-            const f32x4 sm = q1 + q2, df = q1 - q2;
-            keep[i][0] = q0 + sm; keep[i][1] = df;
-            *(f32x4*)slot(0, i, 0) = sm; *(f32x4*)slot(0, i, 1) = df;
-        } else {
-            const f32x4 sm = q0 + q1, df = q0 - q1;
-            keep[i][0] = 4.0f * sm; keep[i][1] = 8.0f * df + q2;
-            *(f32x4*)slot(1, i, 0) = sm; *(f32x4*)slot(1, i, 1) = 2.0f * df;
-        }
-    }
-    __syncthreads();
-    const size_t img_out = (size_t)img * a.H * a.W;
+    const size_t img_px = (size_t)a.H * a.W;
     const int co = n0 + cb * 16 + g * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias && a.ksplit == 1) bias4 = *(const f32x4*)(a.bias + co);
-    // batches of three m-tiles x two outputs: a batch's LDS reads and skip / mask loads are issued before its first store.
-    // (Round 4 measured the skip / mask loads issued ONE BATCH AHEAD, the first batch's in front of the exchange barrier: 175.9 vs
-    // 172.6 us with bias + ReLU, 179.4 vs 177.1 with the skip, 179.0 vs 177.3 with the mask - slower in every form; and a PERSISTENT
-    // launch form for the layers with several rounds of workgroups per CU - 256 workgroups walking their tiles, the next tile's first
-    // chunk staged under the last chunk, the exchange in three batches inside the dead V buffer: bit-identical and 7 - 32 % SLOWER
-    // (scripts/diag/conv3x3_wino4_persist.hip): a wave's vmcnt retires in order, so a persistent wave cannot wait for its next loads
-    // without waiting for its own output stores, while the NEXT workgroup's prologue on the same CU overlaps them for free.
-    // profiles/r04_ab_notes.txt)
+    int par = 0;                                           // V buffer of the current chunk (keeps alternating across tiles)
+#pragma unroll 1
+    for (;;) {                                             // tiles of this workgroup (one, unless PERSIST)
+        const int o_img = img, o_gy0 = gy0, o_gt0 = gt0;   // the tile whose outputs the epilogue below writes
+        const int unit_next = unit + (int)gridDim.x;
+        const bool has_next = PERSIST && unit_next < tiles_total;
+#pragma unroll 1
+        for (int c = 0; c < C16; ++c) {
+            char* const vcur = smem + par * v_bytes;       // (TXTC: the fragment offsets carry the buffer, moved below)
+            char* const vnext = smem + (par ^ 1) * v_bytes;
+            // No branch around the loads: the last chunk of a one-tile workgroup "prefetches" itself again (loads, transforms and LDS
+            // stores nobody consumes).  With the prefetch under `if (more)` the staging registers and weight fragments had two
+            // definitions merging at the loop header, and hipcc could not count the outstanding loads exactly.  PERSIST: the last
+            // chunk stages chunk 0 of the NEXT tile instead - its offsets replace this tile's, which nothing reads any more.
+            const bool last = c + 1 >= C16;
+            if (PERSIST && last && has_next) { decode_unit(unit_next); set_tile_src(); }
+            const int cn = CB + (last ? (PERSIST ? 0 : c) : c + 1);
+            stage_load(0, cn);                                 // lands while this chunk computes
+            W4_READ_A(fa[0], vcur, 0, 0, 0)
 #pragma unroll
-    for (int ib = 0; ib < W4_MG; ib += 3) {
-        f32x4 v[6], mkv[6], skv[6];
-        size_t idx[6];
-        bool ok[6];
+            for (int s = 0; s < NSLAB; ++s) {                  // slab s = (ky, xl)
+                const int ky = s / NXL, xl = s - ky * NXL;
+                // weight slab s + 2 (of this chunk, or the first ones of the next)
+                {
+                    if (s + 2 < NSLAB) fb[(s + 2) % 3] = ldb((s + 2) / NXL, (s + 2) % NXL, CB + c);
+                    else fb[(s + 2) % 3] = ldb(0, s + 2 - NSLAB, cn);
+                }
 #pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            const int i = ib + (e >> 1), k = e & 1;
-            const int m = i * 16 + r;
-            const int trow = m / TXTv, txt = m - trow * TXTv;
-            int oy = gy0 + trow;
-            const int ox = 4 * (gt0 + txt) + 2 * xt + k;
-            ok[e] = oy < a.H && ox < a.W;
-            if (a.stack) {                                  // virtual row -> row of the [N * H] row space; separator rows are dropped
-                const int im = oy / a.stack, yy = oy - im * a.stack;
-                ok[e] = im < a.stack_n && yy < a.H && ox < a.W;
-                oy = im * a.H + yy;
+                for (int grp = 0; grp < 3; ++grp) {
+                    const int t = s * 3 + grp, cur = t & 1;
+                    if (grp < 2) W4_READ_A(fa[cur ^ 1], vcur, ky, xl, grp + 1)
+                    else if (s + 1 < NSLAB) W4_READ_A(fa[cur ^ 1], vcur, (s + 1) / NXL, (s + 1) % NXL, 0)
+                    __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of the MFMA group (hipcc sinks it next to its use)
+                    W4_MFMA(fa[cur], fb[s % 3], xl, grp)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // A third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs.
+                if (s == 2) { stage_store(0, vnext); stage_load(1, cn); __builtin_amdgcn_sched_barrier(0); }
+                if (s == 6) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
             }
-            // same order of additions as a sequential y = (xi 0..2 part) + (xi 3..5 part)
-            v[e] = xt == 0 ? keep[i][k] + *(const f32x4*)slot(1, i, k) : *(const f32x4*)slot(0, i, k) + keep[i][k];
-            if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
-                const int C = a.Cout >> 2;
-                const int sub = co / C, cc = co - sub * C;
-                idx[e] = (((size_t)img * (2 * a.H) + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1)) * C + cc;
-            } else {
-                idx[e] = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+            if (TXTC) {
+                const int dv = par ? -v_bytes : v_bytes;
+#pragma unroll
+                for (int i = 0; i < W4_MG; ++i) a_off[i] += dv;
             }
-            if (!ok[e]) idx[e] = 0;
-            if (a.ksplit == 1) {
-                if (a.mask) mkv[e] = *(const f32x4*)(a.mask + idx[e]);
-                if (a.skip) skv[e] = *(const f32x4*)(a.skip + idx[e]);
-            }
+            par ^= 1;
+            __syncthreads();                                   // V[next] complete and visible; everyone is done with V[cur]
         }
+        // ---- epilogue of tile (o_img, o_gy0, o_gt0) ------------------------------------------------------------------------------
+        // With the weights as the MFMA's A operand a lane holds, per m-tile i, FOUR CONSECUTIVE CHANNELS (cb*16 + 4g ..) of x-tile
+        // 16 i + r for its three xi planes.  y0 = M0 + (M1+M2) + (M3+M4), y1 = (M1-M2) + 2(M3-M4), y2 = (M1+M2) + 4(M3+M4),
+        // y3 = (M1-M2) + 8(M3-M4) + M5: the xi 0..2 wave finishes y0, y1 and the xi 3..5 wave y2, y3; each passes the other its two
+        // partial terms through LDS (lane-linear 16-byte slots: same lane of the partner wave), adds what it receives and stores
+        // 16 bytes per lane straight to global memory - the four channel-block waves fill a pixel's 256-byte line between them.
+        // One tile per workgroup: all nine m-tiles are exchanged at once (147 KB: both V buffers are dead).  PERSIST: V[par] already
+        // holds the next tile's first chunk, so the exchange runs in three batches of three m-tiles (49 KB) inside the dead buffer
+        // V[par ^ 1], fenced on both sides - the next tile's first chunk stores its successor chunk into that same buffer.
+        constexpr int XB = PERSIST ? 3 : W4_MG;            // m-tiles per exchange batch
+        char* const xb = PERSIST ? smem + (par ^ 1) * v_bytes : smem;
+        // slot (sender xh, i within the batch, k, cb, lane)
+        auto slot = [&](int sender, int i, int k) -> char* { return xb + ((((sender * XB + i) * 2 + k) * 4 + cb) * 64 + lane) * 16; };
+        const size_t img_out = (size_t)o_img * img_px;
 #pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            if (!ok[e]) continue;
-            f32x4 o = v[e];
-            if (a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
-                *(f32x4*)(a.slab + (size_t)ks * ((size_t)(a.stack ? a.stack_n : a.N) * a.H * a.W * a.Cout) + idx[e]) = o;
-                continue;
+        for (int xb0 = 0; xb0 < W4_MG; xb0 += XB) {
+            f32x4 keep[XB][2];
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int i = xb0 + j;
+                const f32x4 q0 = acc[0][i], q1 = acc[1][i], q2 = acc[2][i];
+                if (xt == 0) {
+                    const f32x4 sm = q1 + q2, df = q1 - q2;
+                    keep[j][0] = q0 + sm; keep[j][1] = df;
+                    *(f32x4*)slot(0, j, 0) = sm; *(f32x4*)slot(0, j, 1) = df;
+                } else {
+                    const f32x4 sm = q0 + q1, df = q0 - q1;
+                    keep[j][0] = 4.0f * sm; keep[j][1] = 8.0f * df + q2;
+                    *(f32x4*)slot(1, j, 0) = sm; *(f32x4*)slot(1, j, 1) = 2.0f * df;
+                }
+                if (PERSIST) { acc[0][i] = acc[1][i] = acc[2][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }   // ready for the next tile
             }
-            if (a.bias) o += bias4;
-            o *= a.alpha;
-            if (a.mask) {
-                const f32x4 mk = mkv[e];
-                o.x = mk.x > 0.f ? o.x : 0.f; o.y = mk.y > 0.f ? o.y : 0.f; o.z = mk.z > 0.f ? o.z : 0.f; o.w = mk.w > 0.f ? o.w : 0.f;
+            __syncthreads();
+            // batches of three m-tiles x two outputs: a batch's LDS reads and skip / mask loads are issued before its first store.
+            // (Round 4 measured the skip / mask loads issued ONE BATCH AHEAD, the first batch's in front of the exchange barrier: 175.9 vs
+            // 172.6 us with bias + ReLU, 179.4 vs 177.1 with the skip, 179.0 vs 177.3 with the mask - slower in every form; the skip costs
+            // this epilogue 4.5 us, not the 11 us the one-chunk builds of round 3 had suggested.  profiles/r04_ab_notes.txt)
+            // PERSIST: at most ONE of skip / mask (the launcher's rule): one register set for it - this epilogue sits inside the tile
+            // loop, next to everything the next tile keeps live.
+#pragma unroll
+            for (int jb = 0; jb < XB; jb += 3) {
+                f32x4 v[6], mkv[PERSIST ? 1 : 6], skv[6];
+                size_t idx[6];
+                bool ok[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const int j = jb + (e >> 1), i = xb0 + j, k = e & 1;
+                    const int m = i * 16 + r;
+                    const int trow = m / TXTv, txt = m - trow * TXTv;
+                    int oy = o_gy0 + trow;
+                    const int ox = 4 * (o_gt0 + txt) + 2 * xt + k;
+                    ok[e] = oy < a.H && ox < a.W;
+                    if (a.stack) {                                  // virtual row -> row of the [N * H] row space; separator rows are dropped
+                        const int im = oy / a.stack, yy = oy - im * a.stack;
+                        ok[e] = im < a.stack_n && yy < a.H && ox < a.W;
+                        oy = im * a.H + yy;
+                    }
+                    // same order of additions as a sequential y = (xi 0..2 part) + (xi 3..5 part)
+                    v[e] = xt == 0 ? keep[j][k] + *(const f32x4*)slot(1, j, k) : *(const f32x4*)slot(0, j, k) + keep[j][k];
+                    if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
+                        const int C = a.Cout >> 2;
+                        const int sub = co / C, cc = co - sub * C;
+                        idx[e] = (((size_t)o_img * (2 * a.H) + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1)) * C + cc;
+                    } else {
+                        idx[e] = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+                    }
+                    if (!ok[e]) idx[e] = 0;
+                    if (PERSIST) {
+                        if (a.mask || a.skip) skv[e] = *(const f32x4*)((a.mask ? a.mask : a.skip) + idx[e]);
+                    } else if (a.ksplit == 1) {
+                        if (a.mask) mkv[e] = *(const f32x4*)(a.mask + idx[e]);
+                        if (a.skip) skv[e] = *(const f32x4*)(a.skip + idx[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    if (!ok[e]) continue;
+                    f32x4 o = v[e];
+                    if (!PERSIST && a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
+                        *(f32x4*)(a.slab + (size_t)ks * ((size_t)(a.stack ? a.stack_n : a.N) * a.H * a.W * a.Cout) + idx[e]) = o;
+                        continue;
+                    }
+                    if (a.bias) o += bias4;
+                    o *= a.alpha;
+                    if (a.mask) {
+                        const f32x4 mk = PERSIST ? skv[e] : mkv[PERSIST ? 0 : e];
+                        o.x = mk.x > 0.f ? o.x : 0.f; o.y = mk.y > 0.f ? o.y : 0.f; o.z = mk.z > 0.f ? o.z : 0.f; o.w = mk.w > 0.f ? o.w : 0.f;
+                    }
+                    if (PERSIST ? (a.skip && !a.mask) : (a.skip != nullptr)) o += skv[e];
+                    if (a.act == PESR_ACT_RELU) {
+                        o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+                    } else if (a.act == PESR_ACT_LRELU) {
+                        o.x = o.x > 0.f ? o.x : o.x * a.slope; o.y = o.y > 0.f ? o.y : o.y * a.slope;
+                        o.z = o.z > 0.f ? o.z : o.z * a.slope; o.w = o.w > 0.f ? o.w : o.w * a.slope;
+                    }
+                    *(f32x4*)(a.y + idx[e]) = o;
+                }
             }
-            if (a.skip) o += skv[e];
-            if (a.act == PESR_ACT_RELU) {
-                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
-            } else if (a.act == PESR_ACT_LRELU) {
-                o.x = o.x > 0.f ? o.x : o.x * a.slope; o.y = o.y > 0.f ? o.y : o.y * a.slope;
-                o.z = o.z > 0.f ? o.z : o.z * a.slope; o.w = o.w > 0.f ? o.w : o.w * a.slope;
+            if (PERSIST) __syncthreads();                  // the slots are rewritten by the next batch / the next tile's staging stores
+        }
+        if (!has_next) break;
+        // The next tile's loop state is REBUILT here rather than kept across the epilogue (the staging offsets were needed once
+        // before, for the prefetch in the last chunk): the epilogue then has the registers of a one-tile workgroup's.  The unit
+        // number goes through an opaque move so that hipcc does not simply keep the earlier copies alive.
+        unit = unit_next;
+        {
+            int u2 = unit;
+            asm volatile("" : "+s"(u2));
+            decode_unit(u2);
+            set_tile_src();
+            ktab1 = ktab2 = 0;
+            compute_a_off();
+            if (TXTC && par) {
+#pragma unroll
+                for (int i = 0; i < W4_MG; ++i) a_off[i] += v_bytes;
             }
-            *(f32x4*)(a.y + idx[e]) = o;
+            fb[0] = ldb(0, 0, CB);
+            fb[1] = ldb(0, 1, CB);
         }
     }
+#undef W4_READ_A
+#undef W4_MFMA
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -492,7 +557,7 @@ int pesr_conv3x3_wino4_score_impl(int N, int H, int W, int Cin, int Cout, int al
 
 int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
                               int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
-                              void* ws, size_t ws_bytes, hipStream_t stream) {
+                              void* ws, size_t ws_bytes, hipStream_t stream, int persist_mode) {
     W4Plan p;
     if (!w4_plan(N, H, W, Cin, Cout, ws != nullptr && !ps, ws_bytes, !ps && !ps_in, &p)) return PESR_EINVAL;
     if (ps && (Cout % 256 || skip || mask)) return PESR_EINVAL;    // a 64-channel n-tile must stay inside one sub-pixel plane
@@ -509,16 +574,34 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     if (p.stack) a.N = 1;
     static PesrDeviceOnce attr_once;
     attr_once([&] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 24, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 24, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
+    // Several rounds of workgroups per CU (>= 1.5): the persistent form - 256 workgroups (the largest multiple of n_tiles that fits)
+    // walk their tiles, prologue and epilogue hidden behind the neighbouring tiles' MFMAs.  persist_mode (tests / A-B): 0 never,
+    // 1 by this rule, 2 whenever there is more than one tile per workgroup.
+    const int pgrid = (256 / p.n_tiles) * p.n_tiles;
+    const bool persist = persist_mode != 0 && p.ksplit == 1 && p.n_tiles <= 256 && pgrid >= 192 && !(skip && mask) &&
+                         p.tiles >= (persist_mode == 2 ? (long)pgrid + 1 : (long)pgrid * 3 / 2);
+    if (persist) {
+        const dim3 grid((unsigned)pgrid);
+        if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0, true>), grid, dim3(512), p.lds, stream, a);
+        else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12, true>), grid, dim3(512), p.lds, stream, a);
+        else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24, true>), grid, dim3(512), p.lds, stream, a);
+        else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0, true>), grid, dim3(512), p.lds, stream, a);
+        return pesr_launch_status();
+    }
     const dim3 grid((unsigned)(p.tiles * p.ksplit));
-    if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0>), grid, dim3(512), p.lds, stream, a);
-    else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12>), grid, dim3(512), p.lds, stream, a);
-    else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24>), grid, dim3(512), p.lds, stream, a);
-    else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0>), grid, dim3(512), p.lds, stream, a);
+    if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0, false>), grid, dim3(512), p.lds, stream, a);
+    else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12, false>), grid, dim3(512), p.lds, stream, a);
+    else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24, false>), grid, dim3(512), p.lds, stream, a);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0, false>), grid, dim3(512), p.lds, stream, a);
     if (p.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, act,
                                               slope, stream);
