@@ -960,6 +960,46 @@ class MaxPoolFn(Function):
         return ops.maxpool2x2_bwd(x, _c(gy), ctx.relu_in), None
 
 
+class VggTailFn(Function):
+    """conv4_1 .. conv5_4 (+ pool4) of vgg19 features[:35] (reference model/vgg.py:8-10,19-26) for the sr AND the hr branch in one
+    batch: forward on cat(a, b) - one launch per layer over 2B images instead of two over B -, backward on the sr half only (the
+    hr branch is the reference's no_grad pass; the weights are frozen, so the backward is a chain of input gradients).  steps:
+    [(kind, module, has_relu)] from VGG._steps.  Per layer exactly what Conv3x3Fn / MaxPoolFn do: a conv's ReLU is fused into its
+    epilogue and its mask is applied by the consumer's backward (the next conv's input gradient or the pool's)."""
+
+    @staticmethod
+    def forward(ctx, a, b, steps):
+        B = a.shape[0]
+        x = torch.cat([_c(a), _c(b)])
+        plan, saved, prev_relu = [], [], False
+        for kind, m, has_relu in steps:
+            saved.append(x[:B])                     # (the sr half: a contiguous view)
+            if kind == "conv":
+                plan.append((kind, m, prev_relu, tuple(x[:B].shape)))
+                x = ops.conv3x3_fwd(x, m.packed.for_fwd(m.weight, x.shape, 1), m.packed.bias(m.bias), m.out_channels, 1,
+                                    act=ops.ACT_RELU if has_relu else ops.ACT_NONE, w_oihw=m.weight.detach())
+                prev_relu = has_relu
+            else:
+                plan.append((kind, m, prev_relu, None))
+                x = ops.maxpool2x2_fwd(x)
+                prev_relu = False
+        ctx.plan = plan
+        ctx.save_for_backward(*saved)
+        fa, fb = x[:B], x[B:]
+        ctx.mark_non_differentiable(fb)
+        return fa, fb
+
+    @staticmethod
+    def backward(ctx, ga, _gb):
+        g = _c(ga)
+        for (kind, m, relu_in, shape), xin in zip(reversed(ctx.plan), reversed(ctx.saved_tensors)):
+            if kind == "conv":
+                g = ops.conv3x3_dgrad(g, m.packed.for_dgrad(m.weight, shape, 1), shape, 1, mask=xin if relu_in else None)
+            else:
+                g = ops.maxpool2x2_bwd(xin, g, relu_in)
+        return g, None, None
+
+
 # ------------------------------------------------------------------------------------------------
 # losses                                                       reference train.py:131-140
 # ------------------------------------------------------------------------------------------------

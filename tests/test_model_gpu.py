@@ -107,6 +107,41 @@ def test_gv7_vgg_small():
     close(a.grad, g["gin"], 2e-4, what="grad input")
 
 
+def test_vgg_shared_tail_equals_separate_passes():
+    """VGG.forward runs conv4_1 .. conv5_4 of the sr and hr branches as ONE batch (functional.VggTailFn): features and the sr
+    branch's input gradient must equal the two separate passes (reference model/vgg.py:24-26) to kernel-level precision - a
+    per-image conv is the same arithmetic at batch B and 2B up to the split-K order the planner picks."""
+    from model import VGG
+    from pesr_amd import functional as PF
+    from pesr_amd.model.basic import nhwc
+    V = VGG()
+    V.load_state_dict(vgg_sd())
+    V = V.cuda()
+    x = detrand.image_batch((3, 3, 96, 64), 41).cuda()
+    y = detrand.image_batch((3, 3, 96, 64), 42).cuda()
+    res = []
+    calls = []
+    real = PF.VggTailFn.apply
+    for merged in (True, False):
+        a = x.clone().requires_grad_(True)
+        if merged:
+            PF.VggTailFn.apply = staticmethod(lambda *args: (calls.append(1), real(*args))[1])
+        else:
+            V.TAIL_START = 10 ** 6
+        try:
+            fa, fb = V(a, y)
+        finally:
+            PF.VggTailFn.apply = real
+            V.TAIL_START = type(V).TAIL_START
+        assert fa.shape == (3, 512, 6, 4) and not fb.requires_grad and fa.requires_grad
+        PF.mse_loss(nhwc(fa), nhwc(fb)).backward()
+        res.append((fa.detach().clone(), fb.clone(), a.grad.clone()))
+    assert calls == [1]
+    close(res[0][0], res[1][0], 1e-5, what="features(sr)")
+    close(res[0][1], res[1][1], 1e-5, what="features(hr)")
+    close(res[0][2], res[1][2], 2e-5, what="d mse / d sr")
+
+
 def _trainer(C, depth, ps, lr=5e-5):
     from model import Discriminator, Generator, VGG
     from pesr_amd.optim import FlatAdam
