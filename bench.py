@@ -33,7 +33,7 @@ K1_GFLOP = 2.0 * 16 * 48 * 48 * 256 * 256 * 9 / 1e9     # body conv 256->256 @48
 
 PMC_SUMMARIES = ("r04_k1_pmc_summary.csv", "r04_bf16_pmc_summary.csv", "r03_k1_pmc_summary.csv", "r03_bf16_pmc_summary.csv")     # newest first
 # kernel name -> the source file whose hash must match the summary's side-car (scripts/summarize_profiles.py writes <summary>.meta.json)
-KERNEL_SOURCE = {"conv3x3_wino4_kernel": "conv3x3_wino4.hip", "conv3x3_wino_kernel": "conv3x3_wino.hip", "conv3x3_mfma_kernel": "conv3x3_mfma.hip",
+KERNEL_SOURCE = {"conv3x3_bf16x3_kernel": "conv3x3_bf16x3.hip", "conv3x3_wino4_kernel": "conv3x3_wino4.hip", "conv3x3_wino_kernel": "conv3x3_wino.hip", "conv3x3_mfma_kernel": "conv3x3_mfma.hip",
                  "conv3x3_wgrad_wino4x_kernel": "conv3x3_wgrad_wino4.hip", "conv3x3_wgrad_wino4_kernel": "conv3x3_wgrad_wino4.hip",
                  "conv3x3_wgrad_wino_kernel": "conv3x3_wgrad_wino.hip", "conv3x3_wgrad_kernel": "conv3x3_wgrad.hip",
                  "conv3x3_bf16_kernel": "conv3x3_bf16.hip", "conv3x3_wgrad_bf16_kernel": "conv3x3_wgrad_bf16.hip"}
@@ -253,9 +253,11 @@ def main():
                     help="capture the step into a hipGraph after the warm-up and time replays (bit-identical results; with N > 1 the "
                          "RCCL all-reduces are captured with it; the roofline kernel events are then taken from two extra eager steps "
                          "outside the timed region)")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "split-bf16"], default="fp32",
                     help="fp32 (default, the headline): the reference's arithmetic.  bf16: the OPTIONAL bf16-operand mode (SURVEY 8 f4) - "
-                         "a separate row with its own oracle, tolerance and 2.5 PFLOP/s roofline denominator")
+                         "a separate row with its own oracle, tolerance and 2.5 PFLOP/s roofline denominator.  split-bf16: the OPTIONAL "
+                         "split mode (three bf16 products per multiply, 4e-6 of the output maximum): a separate row too, checked against "
+                         "the fp32 oracle at the fp32 tolerance")
     ap.add_argument("--dp-policy", choices=["auto", "overlap", "defer_g", "defer_all"], default="auto",
                     help="data-parallel schedule (N > 1, or PESR_FORCE_DP=1): auto = measured inside the warm-up - 3 steps each of "
                          "eager overlap / G's all-reduce deferred behind its backward pass / both deferred, then the captured hipGraph "
@@ -402,14 +404,18 @@ def main():
     value = args.steps * global_batch / elapsed
     flop_patch = GFLOP_PER_PATCH[args.workload] * 1e9
     bf16 = args.precision == "bf16"
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    split = args.precision == "split-bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or split) else PEAK_F32_MFMA_TFLOPS
     out = {
-        "metric": "HR-patches/sec (x4 SR GAN train step, 48->192)" + (" [OPTIONAL bf16-operand mode, not the headline]" if bf16 else ""),
+        "metric": "HR-patches/sec (x4 SR GAN train step, 48->192)" + (" [OPTIONAL bf16-operand mode, not the headline]" if bf16 else
+                                                                      " [OPTIONAL split-bf16 mode, not the headline]" if split else ""),
         "value": round(value, 3), "unit": "patches/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "data": "synthetic",
         "dtype": ("bf16 operands / f32 accumulation in the 3x3 convs the bf16 kernels cover (G body, upsamplers, the larger D / VGG layers); "
-                  "f32 tensors, optimizer and every other op") if bf16 else "f32",
+                  "f32 tensors, optimizer and every other op") if bf16 else
+                 ("f32 operands split into hi + lo bf16 terms, three bf16 MFMA products per multiply, f32 accumulation, in the forward / "
+                  "input gradient of the stride-1 convs with Cout % 128 == 0; f32 kernels for weight gradients and every other op") if split else "f32",
         "precision": args.precision,
         "config": {"workload": ("full GAN phase (G + D + VGG + RSGAN focal loss), " if args.workload == "gan"
                                 else "pretrain phase (L1 only), ") +
@@ -478,7 +484,7 @@ def main():
             out["parity_check"]["oracle_one_ulp_noise_floor"] = floor
             if inconclusive:
                 out["parity_check"]["verdict"] = f"inconclusive: 3 x the oracle's own one-ulp noise floor exceeds the cap {BF16_TOL_CAP}"
-    if args.workload == "gan" and world == 1 and not args.no_side and not bf16:
+    if args.workload == "gan" and world == 1 and not args.no_side and not bf16 and not split:
         out["side"] = side_measurements(args, trainer, G, batches, device)
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
@@ -568,9 +574,11 @@ def roofline_objects(args, kern):
     scale = (args.batch / 16) * (args.patch_size / 48) ** 2 * (args.num_channels / 256) ** 2
     bs = (args.batch, args.patch_size, args.patch_size, args.num_channels, args.num_channels)
     # (kernel name, fraction of the conv's algorithmic flops the kernel issues on the matrix pipe)
-    bf16 = getattr(args, "precision", "fp32") == "bf16"
+    bf16 = getattr(args, "precision", "fp32") in ("bf16", "split-bf16")
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    if _ops.bf16_eligible(*bs):
+    if _ops.bf16x3_eligible(*bs):
+        conv_k = ("conv3x3_bf16x3_kernel", 3.0)
+    elif _ops.bf16_eligible(*bs):
         conv_k = ("conv3x3_bf16_kernel", 1.0)
     elif _ops.wino4_eligible(*bs):
         conv_k = ("conv3x3_wino4_kernel", 0.5)
@@ -605,6 +613,16 @@ def roofline_objects(args, kern):
              "sampling": ("every launch of this kind in two eager steps after the timed graph replays is bracketed by HIP events"
                           if getattr(args, "hip_graph", False) else
                           f"every {getattr(args, 'event_every', 1)}-th launch of this kind inside the timed steps is bracketed by HIP events")}
+        if issue_frac > 1.0 and kname == "conv3x3_bf16x3_kernel":
+            o["peak"] = PEAK_BF16_MFMA_TFLOPS
+            o["frac"] = round(issued / PEAK_BF16_MFMA_TFLOPS, 4)
+            o["algorithmic_frac"] = round(ach / PEAK_BF16_MFMA_TFLOPS, 4)
+            o["note"] = ("split-bf16: three v_mfma_f32_16x16x32_bf16 products per multiply; frac = issued bf16 flops (3 x algorithmic) / "
+                         "duration / the nominal 2.5 PFLOP/s")
+        elif kind == "wgrad" and bf16 and kname != "conv3x3_wgrad_bf16_kernel":
+            o["peak"] = PEAK_F32_MFMA_TFLOPS        # the weight gradient of this row stays on the fp32 kernels
+            o["frac"] = round(issued / PEAK_F32_MFMA_TFLOPS, 4)
+            o["algorithmic_frac"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
         if issue_frac < 1.0:
             o["note"] = (f"1-D Winograd {'F(4,3)' if issue_frac == 0.5 else 'F(2,3)'}: the kernel issues "
                          f"{'1/2' if issue_frac == 0.5 else '2/3'} of the direct conv's MFMA flops; frac counts the ISSUED flops "

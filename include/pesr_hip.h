@@ -124,6 +124,19 @@ int pesr_pack_conv3x3_bf16(const float* w, void* w_packed, int Cout, int Cin, in
 int pesr_conv3x3_bf16(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask, float* y,
                       int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in,
                       void* stream);
+/* ---- OPTIONAL split-bf16 mode (SURVEY 8 f4 "bf16/split-bf16 MFMA"; never the default, never the headline row; ABI 12) --------
+ * The same stride-1 3x3 conv with every fp32 operand written as hi + lo (hi = bf16(v), lo = bf16(v - hi)) and every product
+ * replaced by a_hi*b_lo + a_lo*b_hi + a_hi*b_hi on v_mfma_f32_16x16x32_bf16, summed in fp32: 3.6 .. 4.7e-6 of the output maximum
+ * against an fp64 conv (profiles/r04_split_bf16_numerics.txt) - inside the tolerances the fp32 kernels are held to, so its oracle
+ * is the reference's fp32 arithmetic itself (model/basic.py:4-7), not a restatement of the mode.  Cin % 32 == 0, Cout % 128 == 0
+ * (ps_out: Cout a multiple of four workgroup widths, 256 or 128 channels; ps_in: Cin % 128 == 0).  w_packed: 2 * 9 * Cin * Cout
+ * bf16 from pesr_pack_conv3x3_bf16x3 (hi plane, then lo plane; mode 0 forward / mode 1 input gradient).  Weight gradients stay on
+ * the fp32 kernels.  _score: per-mille of the 144-pixel tiles inside the image, 0 if unsupported or fewer than min_wgs workgroups. */
+int pesr_conv3x3_bf16x3_score(int N, int H, int W, int Cin, int Cout, int min_wgs);
+int pesr_pack_conv3x3_bf16x3(const float* w, void* w_packed, int Cout, int Cin, int mode, int ps, void* stream);
+int pesr_conv3x3_bf16x3(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask, float* y,
+                        int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out, int ps_in, void* stream);
+
 /* Stride-2 forward in the bf16 mode (the Discriminator's down-sampling convs, reference model/pesr.py:56-64: Conv(k=3, stride=2,
  * padding=1)): x [N][H][W][Cin] -> y [N][(H-1)/2+1][(W-1)/2+1][Cout], skip / mask shaped like y; weights packed by
  * pesr_pack_conv3x3_bf16 mode 0 (the stride-1 forward's packing).  Its weight gradient stays on the fp32 kernels.

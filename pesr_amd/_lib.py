@@ -42,6 +42,10 @@ SIGNATURES.update({
     "pesr_conv3x3_wino4": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
                                    c_int, _P, c_size_t, _P]),
     "pesr_conv3x3_bf16_score": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pesr_conv3x3_bf16x3_score": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pesr_pack_conv3x3_bf16x3": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pesr_conv3x3_bf16x3": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
+                                    c_int, _P]),
     "pesr_pack_conv3x3_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "pesr_conv3x3_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
                                   c_int, _P]),

@@ -213,6 +213,18 @@ PESR_API int pesr_conv3x3_bf16(const float* x, const void* w_packed, const float
     return pesr_conv3x3_bf16_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, ps_out, ps_in,
                                     (hipStream_t)stream);
 }
+PESR_API int pesr_conv3x3_bf16x3_score(int N, int H, int W, int Cin, int Cout, int min_wgs) {
+    return pesr_conv3x3_bf16x3_score_impl(N, H, W, Cin, Cout, min_wgs);
+}
+PESR_API int pesr_pack_conv3x3_bf16x3(const float* w, void* w_packed, int Cout, int Cin, int mode, int ps, void* stream) {
+    return pesr_pack_conv3x3_bf16x3_launch(w, w_packed, Cout, Cin, mode, ps, (hipStream_t)stream);
+}
+PESR_API int pesr_conv3x3_bf16x3(const float* x, const void* w_packed, const float* bias, const float* skip, const float* mask,
+                                 float* y, int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps_out,
+                                 int ps_in, void* stream) {
+    return pesr_conv3x3_bf16x3_launch(x, w_packed, bias, skip, mask, y, N, H, W, Cin, Cout, alpha, act, slope, ps_out, ps_in,
+                                      (hipStream_t)stream);
+}
 PESR_API int pesr_conv3x3_bf16_s2_score(int N, int H, int W, int Cin, int Cout, int min_wgs) {
     return pesr_conv3x3_bf16_s2_score_impl(N, H, W, Cin, Cout, min_wgs);
 }

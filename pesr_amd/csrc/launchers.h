@@ -95,6 +95,12 @@ int pesr_pack_conv3x3_bf16_launch(const float* w, void* out, int O, int I, int m
 int pesr_conv3x3_bf16_launch(const float* x, const void* wp, const float* bias, const float* skip, const float* mask, float* y,
                              int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
                              hipStream_t stream);
+// split-bf16 mode (conv3x3_bf16x3.hip): every operand as hi + lo bf16 terms, three products, fp32 accumulation
+int pesr_conv3x3_bf16x3_score_impl(int N, int H, int W, int Cin, int Cout, int min_wgs);
+int pesr_pack_conv3x3_bf16x3_launch(const float* w, void* out, int O, int I, int mode, int ps, hipStream_t stream);
+int pesr_conv3x3_bf16x3_launch(const float* x, const void* wp, const float* bias, const float* skip, const float* mask, float* y,
+                               int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
+                               hipStream_t stream);
 int pesr_conv3x3_bf16_s2_score_impl(int N, int H, int W, int Cin, int Cout, int min_wgs);
 int pesr_conv3x3_bf16_s2_launch(const float* x, const void* wp, const float* bias, const float* skip, const float* mask, float* y,
                                 int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, hipStream_t stream);

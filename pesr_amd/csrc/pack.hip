@@ -35,14 +35,16 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
 
 // Batched form: one launch packs many convs (all of a network's, right after its optimizer step).  desc[d] (8 int64):
 // {src ptr, dst ptr, O, I, mode, ps, R, Nn}; blockIdx.y = d.  mode 2 / 3: the Winograd F(2,3) packing of mode 0 / 1, 4 / 5: F(4,3),
-// 7 / 8: bf16.
+// 7 / 8: bf16, 9 / 10: split-bf16 (hi plane + lo plane).
 __global__ void pack_conv3x3_batched_kernel(const long long* __restrict__ desc) {
     const long long* d = desc + (size_t)blockIdx.y * 8;
     const float* __restrict__ w = (const float*)d[0];
     float* __restrict__ out = (float*)d[1];
     const int O = (int)d[2], I = (int)d[3], mode = (int)d[4], ps = (int)d[5], R = (int)d[6], Nn = (int)d[7];
-    if (mode >= 7) {   // bf16 packing (conv3x3_bf16.hip): mode 7 = forward, 8 = dgrad; out[t][c][n][k], 32-channel chunks
-        const int m = mode - 7;
+    if (mode >= 7) {   // bf16 packing (conv3x3_bf16.hip): mode 7 = forward, 8 = dgrad; out[t][c][n][k], 32-channel chunks;
+        //                    9 / 10: the split-bf16 packing (conv3x3_bf16x3.hip): a hi plane (= modes 7 / 8) and a lo plane behind it
+        const bool split = mode >= 9;
+        const int m = split ? mode - 9 : mode - 7;
         const int Rr = m == 0 ? I : O, Nr = m == 0 ? O : I;
         __bf16* const ob = (__bf16*)out;
         const long total_b = 9L * Rr * Nr;
@@ -56,7 +58,10 @@ __global__ void pack_conv3x3_batched_kernel(const long long* __restrict__ desc) 
             int o = m == 0 ? n : red;
             const int i = m == 0 ? red : n;
             if (ps) { const int C = O >> 2; const int sub = o / C, cc = o - sub * C; o = 4 * cc + sub; }
-            ob[e] = (__bf16)w[((long)o * I + i) * 9 + (m == 0 ? t : 8 - t)];
+            const float v = w[((long)o * I + i) * 9 + (m == 0 ? t : 8 - t)];
+            const __bf16 h = (__bf16)v;
+            ob[e] = h;
+            if (split) ob[total_b + e] = (__bf16)(v - (float)h);
         }
         return;
     }

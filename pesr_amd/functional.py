@@ -88,12 +88,13 @@ _ALL_PACKS = []   # weak registry of every PackedConvWeights (for the batched re
 
 class _PackSlot:
     """The packed layouts of one weight tensor ON ONE DEVICE."""
-    __slots__ = ("fwd", "dgrad", "bias", "wfwd", "wdgrad", "w4fwd", "w4dgrad", "bfwd", "bdgrad", "kf", "kd", "kb", "kwf", "kwd", "k4f",
-                 "k4d", "kbf", "kbd", "wref", "bref")
+    __slots__ = ("fwd", "dgrad", "bias", "wfwd", "wdgrad", "w4fwd", "w4dgrad", "bfwd", "bdgrad", "sfwd", "sdgrad", "kf", "kd", "kb", "kwf",
+                 "kwd", "k4f", "k4d", "kbf", "kbd", "ksf", "ksd", "wref", "bref")
 
     def __init__(self):
         self.fwd = self.dgrad = self.bias = self.wfwd = self.wdgrad = self.w4fwd = self.w4dgrad = self.bfwd = self.bdgrad = None
-        self.kf = self.kd = self.kb = self.kwf = self.kwd = self.k4f = self.k4d = self.kbf = self.kbd = None
+        self.sfwd = self.sdgrad = None
+        self.kf = self.kd = self.kb = self.kwf = self.kwd = self.k4f = self.k4d = self.kbf = self.kbd = self.ksf = self.ksd = None
         self.wref = None            # weakref to the weight tensor this slot was last built from
         self.bref = None            # ... and to the bias tensor of its PixelShuffle-permuted copy
 
@@ -169,11 +170,19 @@ class PackedConvWeights:
     def bf16_dgrad(self, w: torch.Tensor):
         return self._get(w, "bdgrad", "kbd", lambda: ops.pack_conv3x3_bf16(w.detach(), 1, self.ps))
 
+    def bf16x3_fwd(self, w: torch.Tensor):
+        return self._get(w, "sfwd", "ksf", lambda: ops.pack_conv3x3_bf16x3(w.detach(), 0, self.ps))
+
+    def bf16x3_dgrad(self, w: torch.Tensor):
+        return self._get(w, "sdgrad", "ksd", lambda: ops.pack_conv3x3_bf16x3(w.detach(), 1, self.ps))
+
     def for_fwd(self, w: torch.Tensor, x_shape, stride: int = 1):
         """Packed weights for y = conv(x, w): Winograd F(4,3) where that kernel applies and fills the chip, else F(2,3)
         where THAT applies, else the direct packing.  (ops.PRECISION == "bf16": the bf16 kernel where IT applies, first.)"""
         N, H, W, Cin = x_shape
         assert tuple(w.shape[2:]) == (3, 3), f"PackedConvWeights: 3x3 kernels only, got a weight of shape {tuple(w.shape)}"
+        if ops.bf16x3_eligible(N, H, W, Cin, w.shape[0], stride, ps_out=self.ps):
+            return self.bf16x3_fwd(w)
         if ops.bf16_eligible(N, H, W, Cin, w.shape[0], stride, ps_out=self.ps):
             return self.bf16_fwd(w)
         if ops.wino4_eligible(N, H, W, Cin, w.shape[0], stride, ps_out=self.ps):
@@ -186,6 +195,8 @@ class PackedConvWeights:
         """Packed weights for dx of y = conv(x, w) with x of NHWC shape x_shape."""
         N, H, W, Cin = x_shape
         assert tuple(w.shape[2:]) == (3, 3), f"PackedConvWeights: 3x3 kernels only, got a weight of shape {tuple(w.shape)}"
+        if stride == 1 and ops.bf16x3_eligible(N, H, W, w.shape[0], Cin, 1, ps_in=self.ps):
+            return self.bf16x3_dgrad(w)
         if stride == 1 and ops.bf16_eligible(N, H, W, w.shape[0], Cin, 1, ps_in=self.ps):
             return self.bf16_dgrad(w)
         if stride == 2 and not self.ps and ops.bf16_s2_dgrad_eligible(N, H, W, w.shape[0], Cin):
@@ -295,7 +306,7 @@ _REPACK_TABLES_MAX = 8
 _REPACK_RECORD = None
 
 _SLOT_FIELD = {0: ("fwd", "kf"), 1: ("dgrad", "kd"), 2: ("wfwd", "kwf"), 3: ("wdgrad", "kwd"), 4: ("w4fwd", "k4f"), 5: ("w4dgrad", "k4d"),
-               6: ("bias", "kb"), 7: ("bfwd", "kbf"), 8: ("bdgrad", "kbd")}      # 6: the PixelShuffle-permuted bias (its source tensor is the slot's bref, not wref)
+               6: ("bias", "kb"), 7: ("bfwd", "kbf"), 8: ("bdgrad", "kbd"), 9: ("sfwd", "ksf"), 10: ("sdgrad", "ksd")}      # 6: the PixelShuffle-permuted bias (its source tensor is the slot's bref, not wref)
 
 
 def _slot_buffer(sl, mode):
@@ -339,9 +350,10 @@ def repack_all(params) -> None:
                 R, Nn = (I, O) if mode == 0 else (O, I)
                 jobs.append((sl, w, mode, (w.data_ptr(), buf.data_ptr(), O, I, mode, int(c.ps), (R + 15) // 16 * 16, 16 if Nn <= 16 else (Nn + 63) // 64 * 64)))
             # Winograd packings (batched kernel modes 2 / 3: F(2,3), 4 / 5: F(4,3))
-            for mode, wpk in ((2, sl.wfwd), (3, sl.wdgrad), (4, sl.w4fwd), (5, sl.w4dgrad), (7, sl.bfwd), (8, sl.bdgrad)):
+            for mode, wpk in ((2, sl.wfwd), (3, sl.wdgrad), (4, sl.w4fwd), (5, sl.w4dgrad), (7, sl.bfwd), (8, sl.bdgrad), (9, sl.sfwd),
+                              (10, sl.sdgrad)):
                 if wpk is not None:
-                    fwd_like = mode in (2, 4, 7)
+                    fwd_like = mode in (2, 4, 7, 9)
                     jobs.append((sl, w, mode, (w.data_ptr(), wpk.t.data_ptr(), O, I, mode, int(c.ps), I if fwd_like else O, O if fwd_like else I)))
     # PixelShuffle-permuted biases of these parameters: refreshed in place too (two tiny launches for the Generator).  Left to the
     # lazy per-forward check they were re-packed on every forward - and a captured step whose capture happened to find the key

@@ -141,6 +141,8 @@ FLOPS = _FlopCount()
 
 
 def _conv_family(wp):
+    if isinstance(wp, Bf16x3Packed):
+        return 3.0, "split-bf16 (3 bf16 products per multiply)"
     if isinstance(wp, Bf16Packed):
         return 1.0, "bf16"
     if isinstance(wp, Wino4Packed):
@@ -289,10 +291,13 @@ _BF16_NO_S2 = __import__("os").environ.get("PESR_BF16_NO_S2", "0") == "1"      #
 BF16_MIN_WGS = int(__import__("os").environ.get("PESR_BF16_MIN_WGS", "64"))
 
 
+PRECISIONS = ("fp32", "bf16", "split-bf16")
+
+
 def set_precision(p: str) -> None:
     global PRECISION
-    if p not in ("fp32", "bf16"):
-        raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}")
+    if p not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {p!r}")
     PRECISION = p
 
 
@@ -302,6 +307,46 @@ class Bf16Packed:
 
     def __init__(self, t: torch.Tensor):
         self.t = t
+
+
+# ---- the OPTIONAL split-bf16 mode (round 4) ---------------------------------------------------------------------------
+# PRECISION = "split-bf16": forward and input gradient of the stride-1 convs with Cin % 32 == 0 and Cout % 128 == 0 run on the bf16
+# MFMA with every operand split into hi + lo bf16 terms and three products per multiply (conv3x3_bf16x3.hip): 3.6 .. 4.7e-6 of the
+# output maximum against fp64 - inside the fp32 kernels' own tolerances, so the mode is tested against the fp32 oracle.  Weight
+# gradients, stride-2 convs, 64-channel layers and everything else stay on the fp32 kernels.
+class Bf16x3Packed:
+    """Weights split into hi + lo bf16 planes and packed for conv3x3_bf16x3_kernel (pesr_pack_conv3x3_bf16x3)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
+_B3_SCORE = {}
+BF16X3_MIN_WGS = 128
+
+
+def bf16x3_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps_out: bool = False, ps_in: bool = False) -> bool:
+    """PRECISION is "split-bf16" and the split kernel covers the problem it would run (an input gradient: Cin / Cout swapped)."""
+    # (ps_out: an n-tile - 256 or 128 channels, the planner's choice - must stay inside one of the four sub-pixel planes)
+    if PRECISION != "split-bf16" or stride != 1 or Cin % 32 or Cout % 128 or (ps_out and Cout % 1024) or (ps_in and Cin % 128):
+        return False
+    key = (N, H, W, Cin, Cout)
+    sc = _B3_SCORE.get(key)
+    if sc is None:
+        sc = _B3_SCORE[key] = _lib.lib().pesr_conv3x3_bf16x3_score(N, H, W, Cin, Cout, BF16X3_MIN_WGS)
+    return sc >= 780
+
+
+def pack_conv3x3_bf16x3(w: torch.Tensor, mode: int, ps: bool = False) -> Bf16x3Packed:
+    """OIHW [O, I, 3, 3] fp32 -> [2 (hi, lo)][9, R/32, Nn, 32] bf16 (mode 0: forward, mode 1: dgrad with flipped taps; ps: sub-pixel-major O)."""
+    _chk(w, "pack_conv3x3_bf16x3.w")
+    O, I = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3), f"pack_conv3x3_bf16x3: a 3x3 kernel is required, got {tuple(w.shape)}"
+    out = torch.empty(2 * 9 * O * I, dtype=torch.bfloat16, device=w.device)
+    rc = _lib.lib().pesr_pack_conv3x3_bf16x3(_p(w), _p(out), O, I, mode, int(ps), _stream())
+    _lib.check(rc, f"pesr_pack_conv3x3_bf16x3[{O}x{I},mode{mode}]")
+    return Bf16x3Packed(out)
 
 
 def bf16_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps_out: bool = False, ps_in: bool = False) -> bool:
@@ -346,6 +391,11 @@ def _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, sl
     """Both Winograd kernels (WinoPacked -> F(2,3), Wino4Packed -> F(4,3)) and the bf16 kernel (Bf16Packed): same arguments,
     same fused epilogue."""
     L = _lib.lib()
+    if isinstance(wp, Bf16x3Packed):
+        rc = L.pesr_conv3x3_bf16x3(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope,
+                                   int(ps_out), int(ps_in), _stream())
+        _lib.check(rc, f"pesr_conv3x3_bf16x3[{what} {N}x{H}x{W}x{Cin}->{cout}]")
+        return
     if isinstance(wp, Bf16Packed):
         rc = L.pesr_conv3x3_bf16(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope,
                                  int(ps_out), int(ps_in), _stream())
@@ -410,7 +460,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     if isinstance(wp, Bf16Packed) and stride == 2:
         assert not ps_out
         rc = L.pesr_conv3x3_bf16_s2(_p(x), _p(wp.t), _p(bias), _p(skip), _p(mask), _p(y), N, H, W, Cin, cout, alpha, act, slope, _stream())
-    elif isinstance(wp, (WinoPacked, Wino4Packed, Bf16Packed)):
+    elif isinstance(wp, (WinoPacked, Wino4Packed, Bf16Packed, Bf16x3Packed)):
         assert stride == 1
         _conv3x3_wino(x, wp, bias, skip, mask, y, N, H, W, Cin, cout, alpha, act, slope, "fwd", ps_out=ps_out)
         rc = 0
@@ -446,7 +496,7 @@ def conv3x3_dgrad(dy: torch.Tensor, wpd: torch.Tensor, in_shape, stride: int = 1
         KERNEL_EVENTS.end(br)
         _lib.check(rc, f"pesr_conv3x3_bf16_s2_dgrad[{N}x{H}x{W}x{Cin}<-{cout}]")
         return dx
-    if isinstance(wpd, (WinoPacked, Wino4Packed, Bf16Packed)):     # the input gradient is the conv of dy with the flipped, transposed kernel
+    if isinstance(wpd, (WinoPacked, Wino4Packed, Bf16Packed, Bf16x3Packed)):     # the input gradient is the conv of dy with the flipped, transposed kernel
         assert stride == 1
         _conv3x3_wino(dy, wpd, None, skip, mask, dx, N, H, W, cout, Cin, alpha, ACT_NONE, 0.0, "dgrad", ps_in=ps_in)
         KERNEL_EVENTS.end(br)

@@ -31,7 +31,7 @@ def build_parser():
     for name, typ, default, text in _FLAGS:
         parser.add_argument("--" + name, type=typ, default=default, help=text)
     # an addition (not a reference flag): the optional bf16-operand mode of the build, DESIGN.md section 4c
-    parser.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16"],
+    parser.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16", "split-bf16"],
                         help="bf16: the generator's 3x3 convs round their operands to bf16 (fp32 accumulation and tensors): ~3x faster, "
                              "pixel values differ from the fp32 result by <= 1 grey level on a small fraction of pixels")
     return parser

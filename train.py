@@ -67,10 +67,12 @@ def build_parser():
                    help="under torch.distributed: how the gradient all-reduces are scheduled against the backward kernels.  auto = "
                         "measured during the first iterations (Trainer.calibrate_dp_policy: eager overlap, G's exchange deferred behind "
                         "its backward pass, both deferred, and - unless --hip_graph false - the captured step) and the fastest kept")
-    p.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16"],
+    p.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16", "split-bf16"],
                    help="fp32 (default): the reference's arithmetic.  bf16: OPTIONAL mixed-precision mode - the stride-1 3x3 convs with "
                         "32-multiple input / 64-multiple output channels run on the bf16 MFMA (both operands rounded to bf16, fp32 "
-                        "accumulation, fp32 tensors and optimizer): ~2.4x the step rate, NOT the reference's numerics")
+                        "accumulation, fp32 tensors and optimizer): ~2.4x the step rate, NOT the reference's numerics.  split-bf16: "
+                        "OPTIONAL - forward and input gradient of the stride-1 convs with Cout % 128 == 0 as THREE bf16 products per "
+                        "multiply (hi / lo operand split): 4e-6 of the output maximum, inside the fp32 kernels' own tolerances")
     p.add_argument("--gpu_pipeline", type=str2bool, default=False,
                    help="keep the uint8 training images in HBM and crop/augment on the GPU (pesr_amd.input_pipeline)")
     return p
