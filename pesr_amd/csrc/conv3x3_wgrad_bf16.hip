@@ -41,9 +41,7 @@ struct WgB16Args {
     int ps_in;
 };
 
-#ifndef WB_TARGET_WGS
-#define WB_TARGET_WGS 256      // workgroups (tiles x split-K) aimed at: one round; 384 / 512 measured 25-35 % slower (slab traffic)
-#endif
+constexpr int WB_TARGET_WGS = 256;      // workgroups (tiles x split-K) aimed at: one round; 384 / 512 measured 25-35 % slower (slab traffic)
 namespace {
 constexpr int WB_CW = 48, WB_XP = 64;                    // segment columns; x halo row pitch in LDS (pixels: 2 staging passes of 32 column slots)
 constexpr int WB_XBYTES = 4 * WB_XP * 128;               // x halo: 4 rows x 64 pixels (50 used) x 64 ci bf16

@@ -210,10 +210,7 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     // One common store point for all waves, two thirds into the segment, with the next loads issued right behind it.  Measured
     // alternatives: different store points for the two waves of a SIMD 1.4 % slower; the loads spread over three k-steps instead
     // of one burst 12 % slower (those issued two k-steps before the store have not landed - a loaded L2 round trip is > 1 us).
-#ifndef G4_STORE_STEP
-#define G4_STORE_STEP 4
-#endif
-    constexpr int store_step = G4_STORE_STEP;
+    constexpr int store_step = 4;
 
 #pragma unroll 1
     for (int seg = seg_begin; seg < seg_end; ++seg) {
@@ -505,9 +502,7 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     // LDS read bursts and MFMA blocks de-phase (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): 209.6 -> 206.2 us; three
     // levels (w, w + 4, w + 8 share a SIMD) 206.9, the first half raised instead 208.8 (profiles/r03_wgrad_variants.txt).
     if (cot2) __builtin_amdgcn_s_setprio(1);
-#ifndef X4_STORE_STEP
-#define X4_STORE_STEP 3
-#endif
+    constexpr int X4_STORE_STEP = 3;    // the staging stores sit behind this k-step (2 / 3 / 4 measured: 207 - 209 us, profiles/r03_wgrad_variants.txt)
 
     // Two nested loops - strips outside, a strip's segments inside - instead of one loop over segments with a cold "next strip"
     // branch: the staging registers' value for the next iteration then has ONE definition inside the hot loop (the load_stage

@@ -22,10 +22,7 @@
 
 namespace {
 constexpr int RO_TH = 12;         // output rows per workgroup (input rows read: TH + 2)
-#ifndef RO_NW_
-#define RO_NW_ 4
-#endif
-constexpr int RO_NW = RO_NW_;     // waves per workgroup
+constexpr int RO_NW = 4;          // waves per workgroup (6 / 12 with 2 / 1 column tiles each measured 3 % / 20 % slower)
 constexpr int RO_MT = 12 / RO_NW; // column tiles per wave
 constexpr int RO_NT = RO_NW * 64; // threads
 constexpr int RO_COLS = RO_NW * RO_MT * 16;   // 192 input columns per strip

@@ -77,10 +77,7 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma_kernel(const float* __res
     const bool xok = i < M;
     // LU 16-k steps per trip, all their loads issued before the first MFMA (the two 64-byte halves of every 128-byte line of W
     // are then in flight together): LU * (NB + 1) KiB per wave
-#ifndef LF_U
-#define LF_U 2
-#endif
-    constexpr int LU = LF_U;
+    constexpr int LU = 2;
     for (long k = k0 + 4 * g; k < k1 + 4 * g; k += 16 * LU) {   // uniform trip count; a lane's piece may lie past k1
         f32x4 a[LU], w[LU][NB];
 #pragma unroll
@@ -130,13 +127,9 @@ __global__ void linear_fwd_final_kernel(const float* __restrict__ part, const fl
 
 // ---- dgrad -------------------------------------------------------------------------------------
 // thread: 4 consecutive k, all M rows; loops over an N slice; dy values are wave-uniform (scalar loads).
+constexpr int LD_BT = 256;        // threads per block of the input-gradient kernel
+constexpr int LD_U = 4;           // weight rows in flight per step (8: 134 / 124 us, 16: 146 / 149 against 111 / 101; profiles/r03_linear_sweep.txt)
 template <int MB>
-#ifndef LD_BT
-#define LD_BT 256
-#endif
-#ifndef LD_U
-#define LD_U 4
-#endif
 __global__ __launch_bounds__(LD_BT) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ W,
                                                              float* __restrict__ part, int M, int N, long K, int nchunk) {
     const long k = ((long)blockIdx.x * LD_BT + threadIdx.x) * 4;
@@ -233,12 +226,7 @@ static void lin_plan(int M, int N, long K, LinPlan* p) {
     }
     // dgrad: one-wave blocks, ceil(K/256) * nsplit ~ 1024 of them (every N slice writes an M x K partial: keep them few)
     const long kb = (K + 4 * LD_BT - 1) / (4 * LD_BT);
-#ifndef LD_NS_TARGET
-#define LD_NS_TARGET 1024
-#endif
-#ifndef LD_NS_MAX
-#define LD_NS_MAX 16
-#endif
+    constexpr int LD_NS_TARGET = 1024, LD_NS_MAX = 16;    // (the 16 x 4 point of the sweep in profiles/r03_linear_sweep.txt)
     int ns = (int)((LD_NS_TARGET * 256 / LD_BT + kb - 1) / kb); if (ns < 1) ns = 1; if (ns > N) ns = N; if (ns > LD_NS_MAX) ns = LD_NS_MAX;
     p->nchunk = (N + ns - 1) / ns; p->nsplit = (N + p->nchunk - 1) / p->nchunk;
     (void)M;

@@ -7,6 +7,8 @@ bash scripts/gpu_job.sh bench bench --steps 20 --warmup 5
 bash scripts/gpu_job.sh dp1 bench_forced_dp --steps 20 --warmup 5 --no-cpu-baseline --no-side
 bash scripts/gpu_job.sh bench bench_hip_graph --steps 20 --warmup 5 --no-cpu-baseline --no-side --hip-graph
 bash scripts/gpu_job.sh bench bench_lr5e-5 --steps 20 --warmup 5 --no-cpu-baseline --no-side --lr 5e-5
+bash scripts/gpu_job.sh bench bench_split_bf16 --steps 20 --warmup 5 --precision split-bf16
+bash scripts/gpu_job.sh bench bench_bf16 --steps 20 --warmup 5 --precision bf16
 bash scripts/gpu_job.sh stats
 bash scripts/gpu_job.sh trace
 bash scripts/gpu_job.sh pmc k1 scripts/profile_w4.py
@@ -15,3 +17,4 @@ bash scripts/gpu_job.sh py phase_times scripts/phase_times.py
 bash scripts/gpu_job.sh py layer_times scripts/layer_times.py
 bash scripts/gpu_job.sh py linear_time scripts/linear_time.py
 bash scripts/gpu_job.sh py rgb_layer_time scripts/rgb_layer_time.py
+bash scripts/gpu_job.sh py split_bf16_kernel_times scripts/bf16x3_time.py
