@@ -285,12 +285,22 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # TEST HOOK (tests/test_dp_gpu.py): PESR_DP_SHARE_GPU=1 + PESR_DP_BACKEND=gloo lets N ranks time-share cuda:0 over gloo, so that
+    # every world > 1 branch of this script runs on a one-GPU box.  Not a measurement mode: the JSON says so (`test_hook`).
+    share_gpu = os.environ.get("PESR_DP_SHARE_GPU") == "1"
+    backend = os.environ.get("PESR_DP_BACKEND", "nccl")
+    if share_gpu:
+        assert backend == "gloo", "RCCL refuses two ranks on one device"
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     n_seen = 1
     if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)                     # the GPU count RCCL really spans
         n_seen = int(ones.item())
@@ -449,6 +459,8 @@ def main():
         "host_done_ms_before_gpu": round(1e3 * (my_elapsed - host_done), 1),
         "force_dp": os.environ.get("PESR_FORCE_DP") == "1",
     }
+    if share_gpu:
+        out["test_hook"] = f"{world} ranks time-sharing cuda:0 over {backend}: exercises the multi-rank code path, NOT a measurement"
     if dp_info is not None:
         out["dp_policy"] = dp_info
         out["dp_policy_note"] = ("data-parallel schedule measured inside the warm-up (ms per step, max over ranks): overlap = bucketed "

@@ -331,3 +331,29 @@ def test_nn_dataparallel_two_devices_matches_single_device():
     close(out, ref, 1e-5, what="DataParallel D forward")
     out.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in D.parameters())
+
+
+def test_bench_py_two_ranks_share_one_gpu(tmp_path):
+    """Every world > 1 branch of bench.py (rank / world from the launcher, broadcast of the initial weights, the schedule
+    calibration with its max-over-ranks exchange, barriers around the timed region, per-rank gather, rank 0's JSON line, transport
+    shutdown) on a one-GPU box: two ranks time-share cuda:0 over gloo (test hook PESR_DP_SHARE_GPU=1).  The 8-GPU run is the
+    driver's; this is the rehearsal of its script path at a toy model size."""
+    import json
+    env = dict(os.environ)
+    env.pop("PESR_FORCE_DP", None)
+    env.update(PESR_DP_BACKEND="gloo", PESR_DP_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+           "--batch", "4", "--patch_size", "24", "--num_channels", "64", "--num_blocks", "2", "--calib-steps", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["steps"] == 2 and "test_hook" in d
+    pol = d["dp_policy"]
+    assert pol["transport"] == "torch.distributed[gloo]" and pol["chosen"] in ("overlap", "defer_g", "defer_all")
+    assert set(pol["ms_per_step"]) == {"overlap", "defer_g", "defer_all"} and pol["graph_error"] is None      # gloo: no graph candidate
+    assert d["per_rank_ms_per_step"]["max"] >= d["per_rank_ms_per_step"]["min"] > 0
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    assert "cpu_baseline" not in d and "side" not in d            # rank 0 of a multi-rank run reports the step only
