@@ -357,3 +357,23 @@ def test_bench_py_two_ranks_share_one_gpu(tmp_path):
     assert d["per_rank_ms_per_step"]["max"] >= d["per_rank_ms_per_step"]["min"] > 0
     assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
     assert "cpu_baseline" not in d and "side" not in d            # rank 0 of a multi-rank run reports the step only
+
+
+def test_train_py_two_ranks_share_one_gpu(tmp_path):
+    """train.py under torch.distributed.run with two ranks (time-sharing cuda:0 over gloo): per-rank shard of the global batch,
+    broadcast of the initial weights and of the seeded VGG features, `--dp_policy auto` calibrating the schedule during the first
+    epoch (its line is printed by rank 0), epoch losses reduced over the ranks, checkpoint written by rank 0."""
+    env = dict(os.environ)
+    env.pop("PESR_FORCE_DP", None)
+    env.update(PESR_DP_BACKEND="gloo", PESR_DP_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ck = tmp_path / "ck"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "train.py"), "--phase", "train", "--synthetic", "160", "--num_channels", "64",
+           "--num_blocks", "2", "--patch_size", "8", "--batch_size", "4", "--num_epochs", "1", "--check_point", str(ck),
+           "--snapshot_every", "1", "--hip_graph", "false"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "data-parallel schedule:" in r.stdout and "'transport': 'torch.distributed[gloo]'" in r.stdout, r.stdout[-2000:]
+    assert "Epoch [1/1]" in r.stdout and "Finish valid [1/1]" in r.stdout
+    sd = torch.load(ck / "train" / "model_1.pt", map_location="cpu")
+    assert all(bool(torch.isfinite(v).all()) for v in sd.values())

@@ -204,10 +204,19 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # TEST HOOK (tests/test_dp_gpu.py): PESR_DP_SHARE_GPU=1 + PESR_DP_BACKEND=gloo lets the ranks time-share cuda:0 over gloo, so
+    # that the multi-rank branches of this script run on a one-GPU box
+    backend = os.environ.get("PESR_DP_BACKEND", "nccl")
+    if os.environ.get("PESR_DP_SHARE_GPU") == "1":
+        assert backend == "gloo", "RCCL refuses two ranks on one device"
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     check_limits(args, world)
     if rank == 0:
         print("_____________YOUR SETTINGS_____________")
