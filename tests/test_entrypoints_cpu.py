@@ -4,6 +4,7 @@ import importlib.util
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from helpers import load_golden
@@ -216,3 +217,58 @@ def test_spectral_norm_discriminator_schema_matches_torch():
     assert list(mine.keys()) == list(ref.keys())
     for k in ref:
         assert mine[k].shape == ref[k].shape and torch.equal(mine[k], ref[k]), k
+
+
+def test_bench_refuses_stale_pmc_summary(tmp_path, monkeypatch):
+    """bench.py quotes roofline.traffic from a committed rocprofv3 --pmc summary only if the summary's side-car says it was taken on
+    the CURRENT source of that kernel (a stale CSV must be refused, not quoted)."""
+    import hashlib
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)
+    prof = tmp_path / "profiles"; prof.mkdir()
+    src = tmp_path / "pesr_amd" / "csrc"; os.makedirs(src)
+    (src / "conv3x3_wino4.hip").write_text("// kernel v1\n")
+    monkeypatch.setattr(B, "ROOT", str(tmp_path))
+    monkeypatch.setattr(B, "PMC_SUMMARIES", ("rXX_k1_pmc_summary.csv",))
+    (prof / "rXX_k1_pmc_summary.csv").write_text("kernel,counter,launches,mean_per_launch\n"
+                                                 "\"void conv3x3_wino4_kernel<false, 12>(Wino4Args)\",FETCH_SIZE,12,1000.0\n"
+                                                 "\"void conv3x3_wino4_kernel<false, 12>(Wino4Args)\",WRITE_SIZE,12,500.0\n")
+    # no side-car: refused
+    by, name, why = B.k1_hbm_traffic_bytes("conv3x3_wino4_kernel")
+    assert by is None and name is None and "stale" in why
+    h = hashlib.sha256((src / "conv3x3_wino4.hip").read_bytes()).hexdigest()
+    (prof / "rXX_k1_pmc_summary.meta.json").write_text(json.dumps({"sources_sha256": {"conv3x3_wino4.hip": h}}))
+    by, name, stamp = B.k1_hbm_traffic_bytes("conv3x3_wino4_kernel")
+    assert by == int((2 * 1000.0 + 500.0) * 1024) and name == "rXX_k1_pmc_summary.csv" and stamp == h[:16]
+    (src / "conv3x3_wino4.hip").write_text("// kernel v2\n")               # the kernel changed after the counters were taken
+    by, name, why = B.k1_hbm_traffic_bytes("conv3x3_wino4_kernel")
+    assert by is None and "stale" in why
+
+
+def test_comm_torch_group_single_rank_gloo():
+    """pesr_amd/comm.py on the CPU: the torch.distributed transport (what the gloo tests and shared-GPU rehearsals use) sums in
+    place, agrees host scalars by MAX, and refuses a hipGraph capture; make_transport picks it for a gloo group."""
+    import socket
+    import torch.distributed as dist
+    from pesr_amd import comm
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        tr = comm.get_transport(torch.device("cpu"))
+        assert isinstance(tr, comm.TorchGroup) and tr.name == "torch.distributed[gloo]" and not tr.capturable and tr.world == 1
+        assert comm.get_transport(torch.device("cpu")) is tr                      # one transport per group: shared by the optimizers
+        t = torch.arange(6, dtype=torch.float32)
+        tr.wait([tr.all_reduce_async(t)])
+        assert torch.equal(t, torch.arange(6, dtype=torch.float32))
+        assert tr.host_max([1.5, -2.0]) == [1.5, -2.0]
+        with pytest.raises(comm.CommError, match="cannot be captured"):
+            tr.begin_capture()
+        with pytest.raises(ValueError):
+            comm.make_transport(torch.device("cpu"), prefer="smoke-signals")
+    finally:
+        comm.close_transports()
+        dist.destroy_process_group()
