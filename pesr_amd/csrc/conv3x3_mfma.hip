@@ -67,8 +67,10 @@ __device__ __forceinline__ unsigned tap_code(const ConvArgs& a, int t) {
     return t < 8 ? (unsigned)(a.tap_lo >> (8 * t)) & 0xffu : a.tap_hi;
 }
 
+// The kernel body as a device function of (args, logical block id, blocks in this problem's grid): conv3x3_mfma_kernel is the
+// one-problem launch; conv3x3_s2dgrad4_kernel runs the four parity classes of a stride-2 input gradient in ONE launch.
 template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL, int MODE>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv3x3_mfma_body(const ConvArgs& a, const int block_id, const int grid_blocks) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BN = WAVES_N * WN * 16;
     constexpr int WL = (BN * 4 + NT - 1) / NT;  // float4 units per thread per weight slab
@@ -79,7 +81,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     char* const halo0 = smem;
     char* const halo1 = smem + halo_bytes;
     char* const wb0 = smem + 2 * halo_bytes;
-    char* const wb1 = wb0 + BN * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
 
     // Workgroups b and b + 8 share an XCD (round-robin dispatch): give every XCD a contiguous range of logical tiles, n-tile
     // fastest, so that the n-tiles of one pixel tile - which read the same halo - share an L2.
-    int lb = blockIdx.x;
-    if ((gridDim.x & 7) == 0) lb = (lb & 7) * (gridDim.x >> 3) + (lb >> 3);
+    int lb = block_id;
+    if ((grid_blocks & 7) == 0) lb = (lb & 7) * (grid_blocks >> 3) + (lb >> 3);
     const int tiles_total = a.n_tiles * a.tiles_x * a.tiles_y * a.N;
     const int ks = lb / tiles_total;                    // split-K slice (0 when ksplit == 1)
     int bid = lb - ks * tiles_total;
@@ -283,17 +284,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
         // MODE 1: fragments prefetched one slab ahead (2-3 taps per chunk, or the 3-channel RGB input);
         // MODE 0: one tap per chunk (a parity class of the stride-2 dgrad): the next chunk's halo is staged in the
         //         same iteration that would prefetch from it, so fragments are read in-iteration.
+        // Weight buffer of slab s: MODE 1 alternates two (slab s + 2 overwrites slab s, whose fragments every wave read one barrier
+        // earlier); MODE 0 reads slab s IN the iteration that stages slab s + 2, so it rotates THREE buffers - with two, a wave that
+        // finishes its MFMA block early overwrote slab s under a wave that had not read it yet.  (Round 4: a real bug of rounds 1 - 3
+        // for the one configuration whose staging crosses waves - 256-channel workgroups, where waves 0 - 3 store the rows waves 4 - 5
+        // read: the one-tap parity class of a stride-2 input gradient with >= 192 such tiles, e.g. dx [3,192,192,256], came out
+        // wrong by O(1) in channels 128 - 191.  No layer of the benchmarked networks takes that configuration.)
+        auto wslot = [&](int s_) -> char* { return wb0 + (MODE == 0 ? s_ % 3 : (s_ & 1)) * (BN * 64); };
         load_halo(0);
         load_w(0, tap_code(a, 0) >> 4);
         store_halo(halo0);
-        store_w(wb0);
+        store_w(wslot(0));
         if (nslab > 1) {
             int c1 = 0, t1 = 0; adv(c1, t1);
             load_w(c1, tap_code(a, t1) >> 4);
-            store_w(wb1);
+            store_w(wslot(1));
         }
         __syncthreads();
-        if (MODE == 1) PESR_READ_FRAGS(fa0, fb0, 0, 0, wb0)
+        if (MODE == 1) PESR_READ_FRAGS(fa0, fb0, 0, 0, wslot(0))
         int c = 0, t = 0;
 #define PESR_STEP(CA, CB_, NA, NB, SL)                                                          \
         {                                                                                      \
@@ -302,13 +310,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
             const bool halo_now = (t == 0) && (c + 1 < C16);                                   \
             load_w(c2, tap_code(a, t2) >> 4);                                                  \
             if (halo_now) load_halo(c + 1);                                                    \
-            if (MODE == 1) PESR_READ_FRAGS(NA, NB, c1, t1, (((SL) + 1) & 1) ? wb1 : wb0)       \
-            else PESR_READ_FRAGS(CA, CB_, c, t, ((SL) & 1) ? wb1 : wb0)                        \
+            if (MODE == 1) PESR_READ_FRAGS(NA, NB, c1, t1, wslot((SL) + 1))                    \
+            else PESR_READ_FRAGS(CA, CB_, c, t, wslot(SL))                                     \
             PESR_MFMA_BLOCK(CA, CB_)                                                           \
             /* keep the staging ds_writes (and their vmcnt waits) BEHIND the MFMA block: hipcc otherwise hoists   \
                them to its top and exposes the global-load latency once per slab */            \
             __builtin_amdgcn_sched_barrier(0);                                                 \
-            store_w(((SL) & 1) ? wb1 : wb0); /* slab SL+2 reuses slab SL's buffer */            \
+            store_w(wslot((SL) + 2)); /* MODE 1: slab SL's buffer; MODE 0: the third one */       \
             if (halo_now) store_halo((c & 1) ? halo0 : halo1);                                 \
             __syncthreads();                                                                   \
             c = c1; t = t1;                                                                    \
@@ -429,6 +437,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(con
     }
 }
 
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL, int MODE>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(const ConvArgs a) {
+    conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, S, HL, MODE>(a, blockIdx.x, gridDim.x);
+}
+
+// Input gradient of a stride-2 conv: its four output parity classes (1 / 2 / 2 / 4 taps, conv3x3_mfma.hip's host side) as ONE
+// launch, blockIdx.y = class with the four-tap class first (round 4).  As four launches each class was a small grid with its own
+// ramp, tail and launch boundary (the 24 x 24 <- 12 x 12 x 512 layer: 196 us for 10.9 GFLOP); one grid lets the classes fill each
+// other's tails.  Every class keeps its own tap table, tile shape and pipeline MODE (4 taps: LDS-DMA ring; 2 taps: prefetched
+// fragments; 1 tap: in-iteration), i.e. the same instruction stream per class as before: same bits.
+struct ConvArgs4 {
+    ConvArgs c[4];          // order: (py, px) = (1,1), (1,0), (0,1), (0,0)
+    int tiles[4];
+};
+template <int WAVES_M, int WAVES_N, int WM, int WN, int HL>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_s2dgrad4_kernel(const ConvArgs4 a4) {
+    const int bx = blockIdx.x;
+    switch (blockIdx.y) {
+        case 0: if (bx < a4.tiles[0]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 2>(a4.c[0], bx, a4.tiles[0]); break;
+        case 1: if (bx < a4.tiles[1]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 1>(a4.c[1], bx, a4.tiles[1]); break;
+        case 2: if (bx < a4.tiles[2]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 1>(a4.c[2], bx, a4.tiles[2]); break;
+        default: if (bx < a4.tiles[3]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 0>(a4.c[3], bx, a4.tiles[3]); break;
+    }
+}
+
 // y = act(alpha * (sum_ks slab[ks] + bias) [masked] + skip): fixed-order sum of the split-K partials + the epilogue
 __global__ void conv_splitk_finish_kernel(const float* __restrict__ slab, const float* __restrict__ bias, const float* __restrict__ skip,
                                           const float* __restrict__ mask, float* __restrict__ y, long total, int C, int ksplit,
@@ -519,9 +552,10 @@ static bool choose_tile(int MT, int S, int hext, int wext, int GH, int GW, int m
     return best >= 0;
 }
 
+// Fill in the tile shape, halo extent, split-K decision of one problem for a kernel configuration; -> LDS bytes, pipeline mode.
 // target_wgs: the workgroup count the split-K rule aims at (256 = one per CU; 768 for the 48-pixel tiles, three per CU)
 template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL>
-static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int target_wgs = 256) {
+static int prep_cfg(ConvArgs& a, int hext, int wext, int target_wgs, size_t* lds_out, int* mode_out, long* grid_out) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int MT = WAVES_M * WM * 16;
     constexpr int BN = WAVES_N * WN * 16;
@@ -537,9 +571,9 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int t
     // MODE 2 (LDS-DMA, 4-slot weight ring, one barrier per two slabs) needs >= 4 taps per chunk so that a chunk's halo
     // is resident a full double-step before its first fragment read, and a >= 16-channel input (16-byte DMA pieces)
     const int mode = (a.ntaps >= 4 && a.cin_real != 3) ? 2 : (a.ntaps > 1 ? 1 : 0);
-    size_t lds = 2 * (size_t)halo_bytes + (mode == 2 ? 4 : 2) * (size_t)BN * 64;
-    const size_t lds_out = (size_t)MT * (BN * 4 + 16);     // accumulator tile staged for the coalesced epilogue
-    if (lds_out > lds) lds = lds_out;
+    size_t lds = 2 * (size_t)halo_bytes + (mode == 2 ? 4 : (mode == 0 ? 3 : 2)) * (size_t)BN * 64;
+    const size_t lds_acc = (size_t)MT * (BN * 4 + 16);     // accumulator tile staged for the coalesced epilogue
+    if (lds_acc > lds) lds = lds_acc;
     if (lds > 160 * 1024) return PESR_EINVAL;
     const long tiles = (long)a.N * a.tiles_y * a.tiles_x * a.n_tiles;
     // split-K over the Cin chunks when the tiles alone cannot fill the 256 CUs (12x12 / 24x24 512-channel layers)
@@ -556,7 +590,17 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int t
             a.ksplit = (C16T + a.chunks_per_split - 1) / a.chunks_per_split;
         }
     }
-    const long grid = tiles * a.ksplit;
+    *lds_out = lds; *mode_out = mode; *grid_out = tiles * a.ksplit;
+    return PESR_OK;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL>
+static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int target_wgs = 256) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    size_t lds; int mode; long grid;
+    const int rc = prep_cfg<WAVES_M, WAVES_N, WM, WN, S, HL>(a, hext, wext, target_wgs, &lds, &mode, &grid);
+    if (rc) return rc;
+    const size_t out_bytes = (size_t)a.N * a.OH * a.OW * a.cout_store * sizeof(float);
     const float* bias = a.bias; const float* skip = a.skip; const float* mask = a.mask;
 #define PESR_LAUNCH_MODE(M_)                                                                              \
     {                                                                                                      \
@@ -572,6 +616,30 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int t
     if (a.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)a.slab, bias, skip, mask, a.y, (long)(out_bytes / sizeof(float)), a.cout_store,
                                               a.ksplit, a.alpha, a.act, a.slope, stream);
+    return pesr_launch_status();
+}
+
+// The four parity classes of a stride-2 input gradient (cls[0..3] = (1,1), (1,0), (0,1), (0,0)) as one launch of one configuration.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int HL>
+static int launch_s2dgrad4(ConvArgs4& a4, const int* hext, const int* wext, hipStream_t stream) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    size_t lds = 0; long gmax = 0;
+    for (int k = 0; k < 4; ++k) {
+        a4.tiles[k] = 0;
+        if (a4.c[k].GH <= 0 || a4.c[k].GW <= 0) continue;
+        size_t l; int mode; long grid;
+        const int rc = prep_cfg<WAVES_M, WAVES_N, WM, WN, 1, HL>(a4.c[k], hext[k], wext[k], 256, &l, &mode, &grid);
+        if (rc) return rc;
+        if (mode != (k == 0 ? 2 : (k == 3 ? 0 : 1)) || a4.c[k].ksplit != 1) return PESR_EINVAL;
+        a4.tiles[k] = (int)grid;
+        if (l > lds) lds = l;
+        if (grid > gmax) gmax = grid;
+    }
+    if (gmax == 0) return PESR_OK;
+    auto kern = conv3x3_s2dgrad4_kernel<WAVES_M, WAVES_N, WM, WN, HL>;
+    static PesrDeviceOnce attr_once;
+    attr_once([&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    hipLaunchKernelGGL(kern, dim3((unsigned)gmax, 4), dim3(NT), lds, stream, a4);
     return pesr_launch_status();
 }
 
@@ -644,31 +712,49 @@ int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* 
     // H, W: spatial size of dx (the forward input); dy is [N][OH][OW][Cout_fwd]
     if (Cout_fwd % 16) return PESR_EINVAL;
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-    for (int py = 0; py < 2; ++py)
-        for (int px = 0; px < 2; ++px) {
-            ConvArgs a{};
-            a.x = dy; a.wp = wp; a.bias = nullptr; a.skip = nullptr; a.mask = mask; a.y = dx;
-            a.N = N; a.H = OH; a.W = OW; a.Cin = Cout_fwd; a.Cout = Cin_fwd;
-            a.OH = H; a.OW = W;
-            a.GH = (H - py + 1) / 2; a.GW = (W - px + 1) / 2;  // number of u with 2u+py < H
-            if (a.GH <= 0 || a.GW <= 0) continue;
-            a.in_oy = 0; a.in_ox = 0;
-            a.out_my = 2; a.out_ay = py; a.out_mx = 2; a.out_ax = px;
-            // rows: py==0 -> ky=1 reads dy row u ; py==1 -> ky=0 reads u+1, ky=2 reads u
-            int kys[2], dys[2], nky, kxs[2], dxs[2], nkx;
-            if (py == 0) { nky = 1; kys[0] = 1; dys[0] = 0; } else { nky = 2; kys[0] = 0; dys[0] = 1; kys[1] = 2; dys[1] = 0; }
-            if (px == 0) { nkx = 1; kxs[0] = 1; dxs[0] = 0; } else { nkx = 2; kxs[0] = 0; dxs[0] = 1; kxs[1] = 2; dxs[1] = 0; }
-            a.ntaps = 0;
-            for (int i = 0; i < nky; ++i)
-                for (int j = 0; j < nkx; ++j) {
-                    set_tap(a, a.ntaps, dys[i], dxs[j], kys[i] * 3 + kxs[j]);
-                    ++a.ntaps;
-                }
-            a.alpha = alpha; a.slope = 0.f; a.act = PESR_ACT_NONE; a.ps = 0; a.ps_in = 0;
-            a.cin_real = Cout_fwd; a.cout_store = Cin_fwd;
-            a.slab = nullptr; a.slab_bytes = 0; a.ksplit = 1;
-            const int rc = dispatch<1>(a, py + 1, px + 1, stream);
+    ConvArgs4 a4{};
+    int hext[4], wext[4];
+    for (int k = 0; k < 4; ++k) {
+        const int py = k < 2 ? 1 : 0, px = (k == 0 || k == 2) ? 1 : 0;      // (1,1), (1,0), (0,1), (0,0): most taps first
+        ConvArgs& a = a4.c[k];
+        a.x = dy; a.wp = wp; a.bias = nullptr; a.skip = nullptr; a.mask = mask; a.y = dx;
+        a.N = N; a.H = OH; a.W = OW; a.Cin = Cout_fwd; a.Cout = Cin_fwd;
+        a.OH = H; a.OW = W;
+        a.GH = (H - py + 1) / 2; a.GW = (W - px + 1) / 2;  // number of u with 2u+py < H
+        a.in_oy = 0; a.in_ox = 0;
+        a.out_my = 2; a.out_ay = py; a.out_mx = 2; a.out_ax = px;
+        // rows: py==0 -> ky=1 reads dy row u ; py==1 -> ky=0 reads u+1, ky=2 reads u
+        int kys[2], dys[2], nky, kxs[2], dxs[2], nkx;
+        if (py == 0) { nky = 1; kys[0] = 1; dys[0] = 0; } else { nky = 2; kys[0] = 0; dys[0] = 1; kys[1] = 2; dys[1] = 0; }
+        if (px == 0) { nkx = 1; kxs[0] = 1; dxs[0] = 0; } else { nkx = 2; kxs[0] = 0; dxs[0] = 1; kxs[1] = 2; dxs[1] = 0; }
+        a.ntaps = 0;
+        for (int i = 0; i < nky; ++i)
+            for (int j = 0; j < nkx; ++j) {
+                set_tap(a, a.ntaps, dys[i], dxs[j], kys[i] * 3 + kxs[j]);
+                ++a.ntaps;
+            }
+        a.alpha = alpha; a.slope = 0.f; a.act = PESR_ACT_NONE; a.ps = 0; a.ps_in = 0;
+        a.cin_real = Cout_fwd; a.cout_store = Cin_fwd;
+        a.slab = nullptr; a.slab_bytes = 0; a.ksplit = 1;
+        hext[k] = py + 1; wext[k] = px + 1;
+    }
+    // One configuration for the four classes.  The 48-pixel tiles wherever ONE class alone would leave the 144-pixel tiles at about
+    // one workgroup per CU (measured with the four classes in one grid, same box: 256 <- 256 @48: 112.7 us against 154.6 with the
+    // 144 x 256 tiles; 512 <- 512 @24: 120.6 against 183.2; four launches: 139.7 / 185.8), else the largest tile that fills the chip
+    // with the four classes counted together.
+    const int Cout = Cin_fwd;
+    const long M = (long)N * a4.c[0].GH * a4.c[0].GW;          // pixels of one class
+    if (Cout % 64) {
+        // (channel counts the merged kernel has no configuration for: one launch per class, as before)
+        for (int k = 0; k < 4; ++k) {
+            if (a4.c[k].GH <= 0 || a4.c[k].GW <= 0) continue;
+            const int rc = dispatch<1>(a4.c[k], hext[k], wext[k], stream);
             if (rc) return rc;
         }
-    return PESR_OK;
+        return PESR_OK;
+    }
+    if (Cout >= 128 && (long)pesr_cdiv(M, 144) * (Cout / 64) <= 320) return launch_s2dgrad4<1, 4, 3, 1, 2>(a4, hext, wext, stream);
+    if (Cout % 256 == 0 && 4 * (M / 144) * (Cout / 256) >= 192) return launch_s2dgrad4<1, 8, 9, 2, 2>(a4, hext, wext, stream);
+    if (Cout % 128 == 0 && 4 * (M / 144) * (Cout / 128) >= 192) return launch_s2dgrad4<1, 8, 9, 1, 2>(a4, hext, wext, stream);
+    return launch_s2dgrad4<1, 4, 9, 1, 4>(a4, hext, wext, stream);
 }

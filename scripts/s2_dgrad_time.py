@@ -10,7 +10,9 @@ handles = []
 for path in libs:
     l = ctypes.CDLL(os.path.join(R, path))
     for name, (res, a) in _lib.SIGNATURES.items():
-        f = getattr(l, name); f.restype = res; f.argtypes = a
+        f = getattr(l, name, None)          # (an older variant library lacks the newest entry points)
+        if f is not None:
+            f.restype = res; f.argtypes = a
     handles.append(l)
 s = torch.cuda.current_stream().cuda_stream
 ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")

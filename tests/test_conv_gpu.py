@@ -427,3 +427,23 @@ def test_basic_block_with_5x5_conv_vs_torch():
     assert float((ours[0].weight.grad.cpu() - ref[0].weight.grad).abs().max()) <= 2e-5 * sc(ref[0].weight.grad)
     assert float((ours[1].weight.grad.cpu() - ref[1].weight.grad).abs().max()) <= 2e-5 * sc(ref[1].weight.grad)
     assert torch.allclose(ours[1].running_mean.cpu(), ref[1].running_mean, rtol=1e-5, atol=1e-7)
+
+
+def test_conv3x3_s2_dgrad_256_channel_tiles_one_tap_class():
+    """Stride-2 input gradient on the 144-pixel x 256-channel tiles (>= 192 of them: dx [3,192,192,256]).  Its one-tap parity class
+    reads a weight slab in the same iteration that stages the slab two ahead; with two weight buffers the early waves overwrote
+    rows the late waves had not read (rounds 1 - 3: channels 128 - 191 of the (even, even) pixels wrong by O(1); found in round 4,
+    when the four classes became one launch) - now three buffers.  Every parity class against the oracle."""
+    from pesr_amd import ops
+    N, H, W, Cin, Cout = 3, 192, 192, 256, 256
+    x = _rand(N, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.1)
+    dy = _rand(N, Cout, 96, 96, seed=5)
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    dx_ref, _, _ = O.conv3x3_grads(x, w, dy, 2)
+    dx = _nchw(ops.conv3x3_dgrad(_nhwc(dy), ops.pack_conv3x3(w.cuda(), 1), (N, H, W, Cin), 2))
+    for py in (0, 1):
+        for px in (0, 1):
+            _close(dx[:, :, py::2, px::2], dx_ref[:, :, py::2, px::2], 1e-5)
+    for rep in range(3):        # and bit-reproducible (a race would not be)
+        assert torch.equal(dx, _nchw(ops.conv3x3_dgrad(_nhwc(dy), ops.pack_conv3x3(w.cuda(), 1), (N, H, W, Cin), 2)))
