@@ -580,7 +580,8 @@ def side_measurements(args, trainer, G, batches, device):
 def roofline_objects(args, kern):
     """`roofline` (the dominant kernel: forward of the G body conv) + `roofline_kernels` (the other two body kernels).
     achieved = ALGORITHMIC flops of the conv / mean HIP-event duration of its launches inside the timed steps;
-    frac = flops the kernel ISSUES on the matrix pipe (1/2 of the algorithmic ones for the 1-D Winograd F(4,3) kernel, 2/3 for F(2,3))
+    frac = flops the kernel ISSUES on the matrix pipe (1/2 of the algorithmic ones for the 1-D Winograd F(4,3) kernels, 2/3 for F(2,3),
+    1/3 for the weight gradient's y-nested form)
     / duration / peak, i.e. matrix-pipe utilisation - the honest hardware fraction; algorithmic_frac = achieved / peak."""
     from pesr_amd import ops as _ops
     scale = (args.batch / 16) * (args.patch_size / 48) ** 2 * (args.num_channels / 256) ** 2
@@ -636,8 +637,9 @@ def roofline_objects(args, kern):
             o["frac"] = round(issued / PEAK_F32_MFMA_TFLOPS, 4)
             o["algorithmic_frac"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
         if issue_frac < 1.0:
-            o["note"] = (f"1-D Winograd {'F(4,3)' if issue_frac == 0.5 else 'F(2,3)'}: the kernel issues "
-                         f"{'1/2' if issue_frac == 0.5 else '2/3'} of the direct conv's MFMA flops; frac counts the ISSUED flops "
+            form, part = (("1-D Winograd F(4,3)", "1/2") if issue_frac == 0.5 else
+                          ("Winograd F(4,3) along x nested with F(2,3) along y", "1/3") if issue_frac < 0.4 else ("1-D Winograd F(2,3)", "2/3"))
+            o["note"] = (f"{form}: the kernel issues {part} of the direct conv's MFMA flops; frac counts the ISSUED flops "
                          "(matrix-pipe utilisation), algorithmic_frac the conv's algorithmic flops")
         objs[kind] = o
     out = {}

@@ -67,8 +67,8 @@ int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float
 
 /* dw[O][I][3][3] (OIHW, the parameter's own layout) = alpha * sum_pixels dy (x) x ;  db[O] = alpha * sum dy.
  * db may be NULL.  ps_in as above.  Workspace: pesr_conv3x3_wgrad_workspace_bytes (same algo).
- * algo: PESR_WGRAD_AUTO = the transposed Winograd F(4,3) kernel (on v_mfma_f32_32x32x2_f32) where it applies (stride 1, width % 4 == 0 and >= 48,
- * 64-multiple channels; half the multiplies), else the F(2,3) one (even width >= 48; 2/3), else the direct kernel;
+ * algo: PESR_WGRAD_AUTO = the transposed Winograd kernel (on v_mfma_f32_32x32x2_f32; F(4,3) along x nested with F(2,3) along y: a third of
+ * the multiplies) where it applies (stride 1, width % 4 == 0 and >= 48, 64-multiple channels), else the F(2,3) one (even width >= 48; 2/3), else the direct kernel;
  * PESR_WGRAD_DIRECT = the direct kernel everywhere; PESR_WGRAD_WINO23 = F(2,3) where it applies, else direct.  All produce
  * the same gradient up to fp32 rounding (measured vs fp64: <= 2e-6 of the gradient's maximum); the choice is an argument,
  * never process state.
@@ -81,6 +81,7 @@ int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float
 #define PESR_WGRAD_WINO23 2
 #define PESR_WGRAD_WINO4_16X16 3 /* as AUTO, but the F(4,3) kernel in round 2's v_mfma_f32_16x16x4_f32 form (8 waves) instead of the
                                   * 32x32x2 form AUTO uses since round 3: same transform, same results up to rounding (cross-checks, A/B) */
+#define PESR_WGRAD_WINO4_1D 4    /* (ABI 13) as AUTO, but with round 3's 1-D F(4,3) transform (half the multiplies) on the 32x32x2 kernel (cross-checks, A/B) */
 size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo);
 int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                        int stride, float alpha, int ps_in, int algo, int accumulate, void* workspace, size_t ws_bytes, void* stream);

@@ -353,6 +353,20 @@ constexpr int X4_NT = 768;
 constexpr int X4_VPLANE = G4_TXT * 32, X4_VROW = 6 * X4_VPLANE;       // floats: V row slot [6 xi][12 x-tiles][32 ci]
 constexpr int X4_DPLANE = G4_TXT * 64, X4_DROW = 6 * X4_DPLANE;       // floats: dM row     [6 xi][12 x-tiles][64 co]
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4, NEST = true (the default): the transform NESTED in y - F(2,3) along y on top of F(4,3) along x - at no cost in staging.
+// A segment is two output rows; per k-step a wave already holds, for its xi plane, the x-transformed gradients D0, D1 of the two
+// rows and the x-transformed inputs X0 .. X3 of the four input rows they touch, and the 1-D form spends SIX MFMAs on
+//     dU[ky] += D0 * X[ky] + D1 * X[ky + 1],  ky = 0, 1, 2
+// - a 3-tap correlation of 2 against 4 values, i.e. exactly the F(2,3) weight-gradient problem.  Its four products
+//     P0 += D0 * (X0 - X2)    P1 += (D0 + D1) * (X1 + X2)    P2 += (D0 - D1) * (X2 - X1)    P3 += D1 * (X3 - X1)
+// give dU[0] = P0 + (P1 + P2) / 2, dU[1] = (P1 - P2) / 2, dU[2] = (P1 + P2) / 2 + P3 (G2^T, applied once, in registers, in front of
+// the G4^T epilogue): FOUR MFMAs per k-step for the same fragment reads, the same staging, ring and LDS image - five VALU adds per
+// k-step buy a third of the matrix work (24 products per 2 x 4 output pixels: 1/3 of the direct form's 72).  One more accumulator
+// tile per wave (64 VGPRs).  Numerics (scripts/wino2d_wgrad_study.py, fp32 emulation vs fp64 at 16 x 48 x 48 pixels): 2.0 - 2.3e-6
+// of the gradient's maximum against 2.1 - 3.5e-6 for the 1-D form - the F(2,3) matrices are 0, +-1, 1/2.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <bool NEST>
 __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const vring = lds;                             // [6 slots] V rows
@@ -373,9 +387,10 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     int seg_end = seg_begin + a.segs_per_split;
     if (seg_end > a.total_segs) seg_end = a.total_segs;
 
-    f32x16 acc[3];
+    constexpr int NACC = NEST ? 4 : 3;
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
     float bsum = 0.f;
@@ -532,11 +547,20 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
             _Pragma("unroll") for (int rw = 0; rw < 4; ++rw) FB[rw] = vb[rw][(Q) * 64];          \
         }
 #define X4_MFMA(FA, FB)                                                                          \
-        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                       \
-            acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0);     \
-            acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
-        }                                                                                        \
-        if (xi == 1) bsum += FA[0] + FA[1];                 /* dM_1 = dy0+dy1+dy2+dy3 */
+        if (NEST) {                                                                              \
+            const float ds_ = FA[0] + FA[1], dd_ = FA[0] - FA[1];                                \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[0] - FB[2], acc[0], 0, 0, 0); \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds_, FB[1] + FB[2], acc[1], 0, 0, 0);  \
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dd_, FB[2] - FB[1], acc[2], 0, 0, 0);  \
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[3] - FB[1], acc[3], 0, 0, 0); \
+            if (xi == 1) bsum += ds_;                       /* dM_1 = dy0+dy1+dy2+dy3, both rows */ \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                   \
+                acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0); \
+                acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
+            }                                                                                    \
+            if (xi == 1) bsum += FA[0] + FA[1];             /* dM_1 = dy0+dy1+dy2+dy3 */          \
+        }
         X4_READ(fa0, fb0, 0)
 #pragma unroll
         for (int q = 0; q < KQ; q += 2) {
@@ -594,6 +618,13 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     }
     // ---- G^T: park the accumulators as ob[cot2][xi][ky][row 32][col 32], then every thread finishes 8 (co, ci) positions ------
     float* const ob = lds;
+    if (NEST) {      // G2^T first, in registers: the four y-planes of this wave's (co half, xi) become its three ky taps
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float hs = 0.5f * (acc[1][j] + acc[2][j]), hd = 0.5f * (acc[1][j] - acc[2][j]);
+            acc[0][j] = acc[0][j] + hs; acc[1][j] = hd; acc[2][j] = hs + acc[3][j];
+        }
+    }
     {
         float* o = ob + ((cot2 * 6 + xi) * 3) * 1024 + c32;
 #pragma unroll
@@ -652,7 +683,7 @@ size_t pesr_conv3x3_wgrad_wino4_ws_bytes(int N, int H, int W, int Cin, int Cout)
 }
 
 // returns PESR_EINVAL when the shape is not covered (the caller then tries the F(2,3) form / the direct kernel)
-// variant 0: the 16x16x4 kernel (8 waves); 1: the 32x32x2 kernel (12 waves)
+// variant 0: the 16x16x4 kernel (8 waves); 1: the 32x32x2 kernel (12 waves), 1-D transform; 2: the same kernel with the transform nested in y
 int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                                     float alpha, int ps_in, int accumulate, int variant, void* ws, size_t ws_bytes, hipStream_t stream) {
     Wg4Plan p;
@@ -676,10 +707,12 @@ int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, 
     static_assert(ldsx >= (size_t)(G4_RING * X4_VROW + 4 * X4_DROW) * sizeof(float) && ldsx <= 160 * 1024, "wgrad-wino4x LDS budget");
     static PesrDeviceOnce attr_once_x;
     attr_once_x([&] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int grid = p.split * p.co_tiles * p.ci_tiles;
-    if (variant == 1) hipLaunchKernelGGL(conv3x3_wgrad_wino4x_kernel, dim3(grid), dim3(X4_NT), ldsx, stream, a);
+    if (variant == 2) hipLaunchKernelGGL(conv3x3_wgrad_wino4x_kernel<true>, dim3(grid), dim3(X4_NT), ldsx, stream, a);
+    else if (variant == 1) hipLaunchKernelGGL(conv3x3_wgrad_wino4x_kernel<false>, dim3(grid), dim3(X4_NT), ldsx, stream, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_wino4_kernel, dim3(grid), dim3(G4_NT), lds, stream, a);
     int rc = pesr_launch_status();
     if (rc) return rc;

@@ -209,7 +209,9 @@ def wgrad_kernel_for(N, H, W, Cin, Cout):
     """(kernel name, fraction of the algorithmic flops it issues on the matrix pipe) of the stride-1 weight gradient."""
     if USE_WGRAD_WINO and Cin % 64 == 0 and Cout % 64 == 0 and W >= 48:
         if USE_WINO4 and USE_WGRAD_WINO4 and W % 4 == 0 and ((W // 4 + 11) // 12) * 12 * 8 <= (W // 4) * 9:
-            return ("conv3x3_wgrad_wino4_kernel" if USE_WGRAD_WINO4_16X16 else "conv3x3_wgrad_wino4x_kernel"), 0.5
+            if USE_WGRAD_WINO4_16X16:
+                return "conv3x3_wgrad_wino4_kernel", 0.5
+            return "conv3x3_wgrad_wino4x_kernel", (0.5 if USE_WGRAD_WINO4_1D else 1.0 / 3.0)
         if W % 2 == 0 and ((W // 2 + 23) // 24) * 24 * 8 <= (W // 2) * 9:
             return "conv3x3_wgrad_wino_kernel", 2.0 / 3.0
     return "conv3x3_wgrad_kernel", 1.0
@@ -553,9 +555,11 @@ def _out(t, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23, WGRAD_WINO4_16X16 = 0, 1, 2, 3      # include/pesr_hip.h PESR_WGRAD_*
+WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23, WGRAD_WINO4_16X16, WGRAD_WINO4_1D = 0, 1, 2, 3, 4      # include/pesr_hip.h PESR_WGRAD_*
 # PESR_WGRAD_WINO4_16X16=1: round 2's 16x16x4-MFMA form of the F(4,3) weight gradient instead of the 32x32x2 form (A/B switch)
 USE_WGRAD_WINO4_16X16 = __import__("os").environ.get("PESR_WGRAD_WINO4_16X16", "0") == "1"
+# PESR_WGRAD_WINO4_1D=1: round 3's 1-D F(4,3) transform on the 32x32x2 kernel instead of the y-nested one (A/B switch)
+USE_WGRAD_WINO4_1D = __import__("os").environ.get("PESR_WGRAD_WINO4_1D", "0") == "1"
 
 
 def wgrad_bf16_eligible(N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1, ps_in: bool = False) -> bool:
@@ -605,7 +609,8 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
         return conv3x3_wgrad_bf16(x, dy, alpha, want_bias, ps_in, dw_out, db_out, accumulate)
     L = _lib.lib()
     if algo is None:
-        algo = ((WGRAD_WINO4_16X16 if USE_WGRAD_WINO4_16X16 else WGRAD_AUTO) if (USE_WINO4 and USE_WGRAD_WINO4) else 2) if USE_WGRAD_WINO else 1
+        algo = ((WGRAD_WINO4_16X16 if USE_WGRAD_WINO4_16X16 else (WGRAD_WINO4_1D if USE_WGRAD_WINO4_1D else WGRAD_AUTO))
+                if (USE_WINO4 and USE_WGRAD_WINO4) else 2) if USE_WGRAD_WINO else 1
     nbytes = L.pesr_conv3x3_wgrad_workspace_bytes(N, H, W, Cin, cout, stride, algo)
     if nbytes == 0:
         raise _lib.PesrHipError(f"pesr_conv3x3_wgrad: unsupported shape Cin={Cin} Cout={cout} stride={stride}")
@@ -617,7 +622,7 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, stride: int = 1, alpha: flo
         if algo == WGRAD_WINO23 and frac == 0.5:
             frac = 2.0 / 3.0
         FLOPS.add(18.0 * N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * Cin * cout, frac,
-                  {0.5: "F(4,3)", 1.0: "direct"}.get(frac, "F(2,3)"))
+                  {0.5: "F(4,3)", 1.0: "direct", 1.0 / 3.0: "F(2,3)y x F(4,3)x"}.get(frac, "F(2,3)"))
     br = KERNEL_EVENTS.begin("wgrad", N, H, W, Cin, cout, stride)
     rc = L.pesr_conv3x3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, H, W, Cin, cout, stride, alpha, int(ps_in), algo, int(accumulate),
                               _p(ws), ws.numel(), _stream())

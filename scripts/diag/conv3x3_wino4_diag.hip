@@ -1,5 +1,5 @@
-// DIAGNOSTIC COPY (ablation switches W4_ABL_* / G4_ABL_*, -DPESR_TIMING phase stamps) of the product kernel in pesr_amd/csrc:
-// built only by scripts/build_timing.sh / scripts/build_variant.sh into exp/lib*.so for A/B timing; never linked into libpesr_hip.so.
+// DIAGNOSTIC copy of pesr_amd/csrc/conv3x3_wino4.hip (timing experiments with WRONG results): -DW4D_NO_AREAD drops the loop's LDS fragment
+// reads, -DW4D_NO_BLOAD its weight loads, -DW4D_NO_STAGE its staging loads / transform / LDS stores.  scripts/build_variant.sh.
 // 3x3 stride-1 convolution with a 1-D Winograd F(4,3) transform along x, on the fp32-input MFMA, gfx950.
 //
 // Same contract as conv3x3_mfma.hip / conv3x3_wino.hip (reference nn.Conv2d(k=3, padding=1), model/basic.py:4-7, forward
@@ -27,8 +27,8 @@
 // The 16-byte k-groups of a V entry are XOR-swizzled by ((x-tile >> 1) ^ row term) so that the ds_read_b128 fragment reads
 // are bank-conflict free for TXT = 12 (48-wide images: row term 2 * (halo row & 1)) and TXT = 8 / 16 / 24 (no row term).
 // Layers with too few tiles split the Cin chunks over workgroups (raw partial sums + the direct kernel's finish kernel).
+#include <mutex>
 #include "common.h"
-#include "timing.h"
 #include "launchers.h"
 #include "wino4_pack.h"
 
@@ -54,35 +54,33 @@ struct Wino4Args {
     int stack;          // 0, or H + 1: the N images are tiled as ONE image of N * (H + 1) - 1 rows, a zero row between neighbours
     int stack_n;        //   (that row is the bottom halo of one image and the top halo of the next); N above is then 1
     int v_row;          // bytes of one V row: 6 * TXT * 64, plus the pad of the dense layout
-};
+    };
 
 constexpr int W4_BN = 64, W4_MG = 9;
 
 // Wave w owns the 16 channels w & 3 and HALF of the xi planes (w >> 2: xi 0..2 / 3..5): 27 accumulator tiles, 2 waves per SIMD.
 // (A 12-wave variant - a third of the xi planes per wave, 3 waves per SIMD in the 168-VGPR budget - measured 2 % slower.)
-#ifdef PESR_TIMING
-__device__ unsigned long long w4_timing[4096 * PESR_TIMING_SLOTS];
-PESR_API int pesr_debug_timing_wino4(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(w4_timing), (size_t)n * sizeof(unsigned long long));
-}
-#endif
 
 // DENSE = false: the swizzle key of the rows of 8 / 12 / 16 / 24 x-tiles (the layers that matter), a_off ^ kxor for odd ky.
 // DENSE = true: any row length.  A V row is padded so that the 64-byte entries of consecutive x-tiles m = row * TXT + txt of one
 // xi plane fall into 64-byte slots m mod 4 of the 256-byte bank window, and the 16-byte sub-slot is rotated by (m >> 2) & 3:
 // the 16 lanes of a fragment read (16 consecutive m) then touch every bank once.  The key of the row ky below is a different
 // function of the lane, so its XOR with the ky = 0 key comes from two packed per-lane tables (2 bits per m-tile and ky).
-template <bool DENSE>
+// TXTC: the row length in x-tiles as a compile-time constant (12 / 24: the 48- and 96-wide layers, i.e. the G body and upsample.2),
+// or 0 = a.TXT at run time.  With it the (ky, xi) part of a fragment read's address is an immediate of the ds_read and "this
+// chunk's V buffer" is one add per fragment offset and chunk: the loop loses its per-read address add (87 -> 38 v_add_u32 per
+// chunk and wave; G body forward 185.1 -> 182.6 us, 227.7 -> 229.4 patches/s).
+template <bool DENSE, int TXTC>
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
-    PESR_STAMP(w4_timing, 0);
-    PESR_STAMP_CLK(w4_timing, 6);
+    static_assert(!(DENSE && TXTC), "the constant-row-length form is for the non-dense layout");
     constexpr int NT = 512;                                // threads of the workgroup
     constexpr int NXL = 3;                                 // xi planes per wave
     constexpr int NSLAB = 3 * NXL;                         // weight slabs per wave and chunk: (ky, xl)
     constexpr int NU = 2;                                  // staging items per thread (HT * TXT * 4 <= NU * NT)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int plane = a.TXT * 64;                          // bytes of one xi plane of a V row
-    const int v_row = a.v_row;
+    const int TXTv = TXTC ? TXTC : a.TXT;                   // (a compile-time row length also turns the index divisions below into multiplies)
+    const int plane = TXTv * 64;       // bytes of one xi plane of a V row
+    const int v_row = TXTC ? 6 * TXTC * 64 : a.v_row;
     const int v_bytes = a.HT * v_row;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,41 +100,52 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     const int tx = bid % a.tiles_x;  bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
-    const int gy0 = ty * a.TR, gt0 = tx * a.TXT;          // first output row / first x-tile of the tile
+    const int gy0 = ty * a.TR, gt0 = tx * TXTv;          // first output row / first x-tile of the tile
     const int n0 = nt * W4_BN;
     const int C16T = a.Cin >> 4;
     const int CB = ks * a.chunks_per_split;                // this workgroup's chunk range [CB, CB + C16)
     const int C16 = (C16T - CB) < a.chunks_per_split ? (C16T - CB) : a.chunks_per_split;
 
     // ---- A fragment offsets: lane (r, g) reads k-group g of x-tile m = 16 i + r (for an even ky; odd ky: ^ kxor) -------------
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of the dynamic segment (a multiple of 256)
     int a_off[W4_MG];
     unsigned ktab1 = 0, ktab2 = 0;                         // DENSE: (key(ky) ^ key(0)) << 4 for m-tile i at bits [2i + 4, 2i + 6)
+    // (filled in behind the prologue's loads: nothing needs the offsets before the first fragment read, and the index arithmetic
+    // then runs under the first chunk's load latency instead of in front of it)
+    auto compute_a_off = [&]() {
 #pragma unroll
-    for (int i = 0; i < W4_MG; ++i) {
-        const int m = i * 16 + r;
-        const int trow = m / a.TXT, txt = m - trow * a.TXT;
-        if (DENSE) {
-            const int k0 = (m >> 2) & 3;
-            a_off[i] = trow * v_row + txt * 64 + ((g ^ k0) & 3) * 16;
-            ktab1 |= (unsigned)((((m + a.TXT) >> 2) & 3) ^ k0) << (2 * i + 4);
-            ktab2 |= (unsigned)((((m + 2 * a.TXT) >> 2) & 3) ^ k0) << (2 * i + 4);
-        } else {
-            a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
+        for (int i = 0; i < W4_MG; ++i) {
+            const int m = i * 16 + r;
+            const int trow = m / TXTv, txt = m - trow * TXTv;
+            if (DENSE) {
+                const int k0 = (m >> 2) & 3;
+                a_off[i] = trow * v_row + txt * 64 + ((g ^ k0) & 3) * 16;
+                ktab1 |= (unsigned)((((m + TXTv) >> 2) & 3) ^ k0) << (2 * i + 4);
+                ktab2 |= (unsigned)((((m + 2 * TXTv) >> 2) & 3) ^ k0) << (2 * i + 4);
+            } else {
+                a_off[i] = trow * v_row + txt * 64 + ((g ^ (txt >> 1) ^ (a.row_key * (trow & 1))) & 3) * 16;
+                if (TXTC) a_off[i] += xt * 3 * plane;          // the wave's xi half: the rest of (ky, xi) is an immediate
+            }
+            a_off[i] += (int)lds0;
         }
-    }
+    };
     const int kxor = a.row_key * 16;                       // the key's row term flips with the parity of ky
 
     // ---- B: this lane's 16 bytes of slab (ky, xi, chunk): wave-uniform slab base (SGPRs) + one per-lane 32-bit byte offset ----
-    const size_t slab_stride = (size_t)a.Cout * 16;        // floats between consecutive chunks of one (ky, xi)
+    // (a buffer load: the slab offset is a scalar operand, so a weight fetch needs no 64-bit vector address arithmetic; the packed
+    // weights are < 4 GB: 18 * Cin * Cout floats)
+    const unsigned slab_bytes = (unsigned)a.Cout * 64;     // bytes between consecutive chunks of one (ky, xi)
     const unsigned b_lane = (unsigned)(((n0 + cb * 16 + r) * 16 + g * 4) * 4);
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (unsigned)((size_t)18 * a.Cin * a.Cout * 4), 0x00020000);
     auto ldb = [&](int ky, int xl, int cc) -> f32x4 {      // cc = absolute chunk
-        const char* const base = (const char*)(a.wp + ((size_t)((ky * 6 + xi_of(xl)) * C16T + cc)) * slab_stride);
-        return *(const f32x4*)(base + b_lane);
+        const unsigned so = (unsigned)((ky * 6 + xi_of(xl)) * C16T + cc) * slab_bytes;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_lane, so, 0));
     };
 
     // ---- staging items: (halo row, x-tile, 4-channel group); six input columns each; NU items per thread --------------------
     const float* const x_img = a.x + (size_t)img * a.H * a.W * a.Cin;    // stacked: img == 0, rows run over all images
-    const int n_items = a.HT * a.TXT * 4;
+    const int n_items = a.HT * TXTv * 4;
     const int Cq = a.Cin >> 2;
     // Out-of-image columns (and whole halo rows) are fetched at offset 2^31, beyond the buffer descriptor's range: the load
     // returns zeros, no masking afterwards.  (Raw buffer: the range check is on the VGPR offset; images are < 2 GB - w4_plan.)
@@ -144,9 +153,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     int st_dst[NU];                                        // < 0: the item does not exist
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
+#ifdef W4D_ILV
+        const int it0 = tid + u * NT;
+        const int it = (it0 >= n_items && it0 - lane < n_items) ? it0 - 64 : it0;
+#else
         const int it = tid + u * NT;
+#endif
         const int q = it & 3, rest = it >> 2;
-        const int hrow = rest / a.TXT, txt = rest - hrow * a.TXT;
+        const int hrow = rest / TXTv, txt = rest - hrow * TXTv;
         int iy = gy0 - 1 + hrow;
         const int ix0 = 4 * (gt0 + txt) - 1;
         bool item_ok = it < n_items && iy >= 0 && iy < a.H;
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             const int pix = a.ps_in ? ((2 * iy) * (2 * a.W) + 2 * ix) * Cq : (iy * a.W + ix) * a.Cin;
             st_off[u][j] = ok ? (unsigned)((pix + q * 4) * 4) : 0x80000000u;
         }
-        const int skey = DENSE ? ((hrow * a.TXT + txt) >> 2) : ((txt >> 1) ^ (a.row_key * (hrow & 1)));
+        const int skey = DENSE ? ((hrow * TXTv + txt) >> 2) : ((txt >> 1) ^ (a.row_key * (hrow & 1)));
         st_dst[u] = it < n_items ? hrow * v_row + txt * 64 + ((q ^ skey) & 3) * 16 : -1;
     }
     const __amdgpu_buffer_rsrc_t x_rsrc =
@@ -177,6 +191,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     };
     // The two items of a thread go through the SAME six staging registers one after the other: item 0 is loaded
     // at the top of a chunk and stored a third in, item 1 is loaded right there and stored two thirds in.
+#ifdef W4D_ILV
+    const bool has1 = __builtin_amdgcn_readfirstlane((int)(tid - lane + NT < n_items)) != 0;   // this wave owns second items (wave-uniform)
+#endif
     u32x4 sx[6];
     auto stage_load = [&](int u, int cc) {
         const int so = __builtin_amdgcn_readfirstlane(chunk_off(cc));
@@ -184,7 +201,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         for (int j = 0; j < 6; ++j) sx[j] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_off[u][j], so, 0);
     };
     auto stage_store = [&](int u, char* vdst) {
+#ifdef W4D_ILV
+        {
+            // pin the transform HERE: the arithmetic is pure, and without this LLVM hoists it to right behind the loads (top of the chunk)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(sx[j]));
+#else
         if (st_dst[u] >= 0) {
+#endif
             const f32x4 d0 = __builtin_bit_cast(f32x4, sx[0]), d1 = __builtin_bit_cast(f32x4, sx[1]),
                         d2 = __builtin_bit_cast(f32x4, sx[2]), d3 = __builtin_bit_cast(f32x4, sx[3]),
                         d4 = __builtin_bit_cast(f32x4, sx[4]), d5 = __builtin_bit_cast(f32x4, sx[5]);
@@ -207,6 +231,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         for (int i = 0; i < W4_MG; ++i) acc[xl][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 fa[2][3], fb[3];
+#ifdef W4D_MFMA32
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc32[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[j][e] = 0.f;
+#endif
     // the xor of the odd-ky reads is redone at every use: hoisted out of the loop it would cost nine more live registers
     auto opaque = [](int v) -> int { asm volatile("" : "+s"(v)); return v; };
     auto a_key = [&](const int i, const int ky) -> int {   // fragment offset of m-tile i for the V row ky below the tile row
@@ -217,16 +249,25 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         }
         return (ky & 1) ? (a_off[i] ^ opaque(kxor)) : a_off[i];
     };
+    // Fragment reads through 32-bit LDS addresses (a_off carries the dynamic-LDS base, added once): written as `smem + offset`
+    // every read paid a v_add_u32 of the base's relocation - a literal 0 hipcc cannot fold (36 per chunk and wave).
 #define W4_READ_A(FA, VB, KY, XL, GRP)                                                                   \
     {                                                                                                    \
-        const char* const vb_ = (VB) + (KY) * v_row + xi_of(XL) * plane;                                 \
+        const unsigned vb_ = TXTC ? (unsigned)((KY) * v_row + (XL) * plane)                              \
+                                  : (unsigned)((VB) - smem) + (unsigned)((KY) * v_row + xi_of(XL) * plane); \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
-            FA[i] = *(const f32x4*)(vb_ + a_key((GRP) * 3 + i, KY));                                      \
+            FA[i] = *(const __attribute__((address_space(3))) f32x4*)(size_t)((unsigned)a_key((GRP) * 3 + i, KY) + vb_); \
     }
+#ifdef W4D_MFMA32   /* the same flops on six 32x32x2 MFMAs per group instead of twelve 16x16x4 (operands: whatever the registers hold) */
+#define W4_MFMA(FA, FB, XL, GRP)                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                        \
+        acc32[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FB[j & 3], FA[j >> 1][j & 3], acc32[j], 0, 0, 0);
+#else
 #define W4_MFMA(FA, FB, XL, GRP)                                                                         \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
             acc[XL][(GRP) * 3 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(FB[kk], FA[i][kk], acc[XL][(GRP) * 3 + i], 0, 0, 0);
+#endif
 
     // ---- prologue: chunk CB staged synchronously, the first two weight slabs -------------------------------------------------
     {
@@ -237,74 +278,104 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         for (int j = 0; j < 6; ++j) sy[j] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_off[1][j], so, 0);
         fb[0] = ldb(0, 0, CB);
         fb[1] = ldb(0, 1, CB);
+        compute_a_off();
         stage_store(0, smem);
 #pragma unroll
         for (int j = 0; j < 6; ++j) sx[j] = sy[j];
+#ifdef W4D_ILV
+        if (has1)
+#endif
         stage_store(1, smem);
     }
     __syncthreads();
-    PESR_STAMP(w4_timing, 1);
+#ifdef W4D_NO_BLOAD
+    fb[2] = ldb(0, 2, CB);
+#endif
+#ifdef W4D_NO_AREAD
+    { char* const vcur = smem; W4_READ_A(fa[0], vcur, 0, 0, 0) W4_READ_A(fa[1], vcur, 0, 0, 1) }
+#endif
 
 #pragma unroll 1
     for (int c = 0; c < C16; ++c) {
-        char* const vcur = smem + (c & 1) * v_bytes;
+        char* const vcur = smem + (c & 1) * v_bytes;      // (TXTC: the fragment offsets carry the buffer, moved below)
         char* const vnext = smem + ((c & 1) ^ 1) * v_bytes;
-#ifdef W4_ABL_STAGE     // timing-only ablation builds (scripts/wino4_ab.py): the condition is false at run time, nothing is DCE'd
-        const bool more = c + 1 < C16 && a.slope == 12345.f;
-#else
-        const bool more = c + 1 < C16;
+        // No branch in the loop: the last chunk "prefetches" itself again (loads, transforms and LDS stores nobody consumes).  With
+        // the prefetch under `if (more)` the staging registers and weight fragments had two definitions merging at the loop header,
+        // and hipcc could not count the outstanding loads exactly.
+        const int cn = CB + (c + 1 < C16 ? c + 1 : c);
+#ifndef W4D_NO_STAGE
+        stage_load(0, cn);
 #endif
-        if (more) stage_load(0, CB + c + 1);               // lands while this chunk computes
-#ifdef W4_ABL_READS
-#undef W4_READ_A
-#define W4_READ_A(FA, VB, KY, XL, GRP) if (a.slope == 12345.f) { _Pragma("unroll") for (int i = 0; i < 3; ++i) FA[i] = *(const f32x4*)((VB) + a_off[(GRP) * 3 + i] + (KY) * 64 + (XL) * 16); }
-        if (c == 0) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { fa[0][i] = (f32x4){1.f, 2.f, 3.f, 4.f}; fa[1][i] = (f32x4){1.f, 2.f, 3.f, 4.f}; }
-        }
-#endif
+#ifndef W4D_NO_AREAD
         W4_READ_A(fa[0], vcur, 0, 0, 0)
+#endif
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {                  // slab s = (ky, xl)
             const int ky = s / NXL, xl = s - ky * NXL;
             // weight slab s + 2 (of this chunk, or the first ones of the next)
-#ifdef W4_ABL_B
-            if (a.slope == 12345.f)
-#endif
+#ifndef W4D_NO_BLOAD
             {
                 if (s + 2 < NSLAB) fb[(s + 2) % 3] = ldb((s + 2) / NXL, (s + 2) % NXL, CB + c);
-                else if (c + 1 < C16) fb[(s + 2) % 3] = ldb(0, s + 2 - NSLAB, CB + c + 1);
+                else fb[(s + 2) % 3] = ldb(0, s + 2 - NSLAB, cn);
             }
+#endif
 #pragma unroll
             for (int grp = 0; grp < 3; ++grp) {
                 const int t = s * 3 + grp, cur = t & 1;
+#ifndef W4D_NO_AREAD
                 if (grp < 2) W4_READ_A(fa[cur ^ 1], vcur, ky, xl, grp + 1)
                 else if (s + 1 < NSLAB) W4_READ_A(fa[cur ^ 1], vcur, (s + 1) / NXL, (s + 1) % NXL, 0)
+#endif
                 __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of the MFMA group (hipcc sinks it next to its use)
+#ifdef W4D_ILV
+#define W4_PIPE()                                                                                        \
+                _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                      \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+                    __builtin_amdgcn_sched_group_barrier(0x002, W4D_ILV, 0);                             \
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                   \
+                }
+                if (grp == 2 && s == 2) {                  // item 0's transform + LDS stores woven into this group's twelve MFMAs
+                    stage_store(0, vnext);
+                    W4_MFMA(fa[cur], fb[s % 3], xl, grp)
+                    W4_PIPE()
+                } else if (grp == 2 && s == 6 && has1) {
+                    stage_store(1, vnext);
+                    W4_MFMA(fa[cur], fb[s % 3], xl, grp)
+                    W4_PIPE()
+                } else
+#endif
                 W4_MFMA(fa[cur], fb[s % 3], xl, grp)
                 __builtin_amdgcn_sched_barrier(0);
             }
             // A third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs.
-            if (s == 2 && more) { stage_store(0, vnext); stage_load(1, CB + c + 1); __builtin_amdgcn_sched_barrier(0); }
-            if (s == 6 && more) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
-        }
-#ifdef W4_ABL_BARRIER
-        if (a.slope == 12345.f)
+#ifdef W4D_ILV
+            if (s == 2) { stage_load(1, cn); __builtin_amdgcn_sched_barrier(0); }
+#elif !defined(W4D_NO_STAGE)
+            if (s == 2) { stage_store(0, vnext); stage_load(1, cn); __builtin_amdgcn_sched_barrier(0); }
+            if (s == 6) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
 #endif
+        }
+        if (TXTC) {
+            const int dv = (c & 1) ? -v_bytes : v_bytes;
+#pragma unroll
+            for (int i = 0; i < W4_MG; ++i) a_off[i] += dv;
+        }
         __syncthreads();                                   // V[next] complete and visible; everyone is done with V[cur]
     }
 #undef W4_READ_A
 #undef W4_MFMA
-    PESR_STAMP(w4_timing, 2);
+#ifdef W4D_MFMA32
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j % 3][(j * 16 + e) % W4_MG][e & 3] += acc32[j][e];
+#endif
     // ---- epilogue ------------------------------------------------------------------------------------------------------------
     // With the weights as the MFMA's A operand a lane holds, per m-tile i, FOUR CONSECUTIVE CHANNELS (cb*16 + 4g ..) of x-tile
     // 16 i + r for its three xi planes.  y0 = M0 + (M1+M2) + (M3+M4), y1 = (M1-M2) + 2(M3-M4), y2 = (M1+M2) + 4(M3+M4),
     // y3 = (M1-M2) + 8(M3-M4) + M5: the xi 0..2 wave finishes y0, y1 and the xi 3..5 wave y2, y3; each passes the other its two
     // partial terms through LDS (lane-linear 16-byte slots: same lane of the partner wave), adds what it receives and stores
     // 16 bytes per lane straight to global memory - the four channel-block waves fill a pixel's 256-byte line between them.
-#ifdef W4_ABL_EPI
-    if (a.slope != 12345.f) return;
-#endif
     char* const xb = smem;
     // slot (sender xh, i, k, cb, lane)
     auto slot = [&](int sender, int i, int k) -> char* { return xb + ((((sender * W4_MG + i) * 2 + k) * 4 + cb) * 64 + lane) * 16; };
@@ -323,12 +394,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         }
     }
     __syncthreads();
-    PESR_STAMP(w4_timing, 3);
     const size_t img_out = (size_t)img * a.H * a.W;
     const int co = n0 + cb * 16 + g * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias && a.ksplit == 1) bias4 = *(const f32x4*)(a.bias + co);
-    // batches of three m-tiles x two outputs: a batch's LDS reads and skip / mask loads are issued before its first store
+    // batches of three m-tiles x two outputs: a batch's LDS reads and skip / mask loads are issued before its first store.
+    // (Round 4 measured the skip / mask loads issued ONE BATCH AHEAD, the first batch's in front of the exchange barrier: 175.9 vs
+    // 172.6 us with bias + ReLU, 179.4 vs 177.1 with the skip, 179.0 vs 177.3 with the mask - slower in every form; and a PERSISTENT
+    // launch form for the layers with several rounds of workgroups per CU - 256 workgroups walking their tiles, the next tile's first
+    // chunk staged under the last chunk, the exchange in three batches inside the dead V buffer: bit-identical and 7 - 32 % SLOWER
+    // (scripts/diag/conv3x3_wino4_persist.hip): a wave's vmcnt retires in order, so a persistent wave cannot wait for its next loads
+    // without waiting for its own output stores, while the NEXT workgroup's prologue on the same CU overlaps them for free.
+    // profiles/r04_ab_notes.txt)
 #pragma unroll
     for (int ib = 0; ib < W4_MG; ib += 3) {
         f32x4 v[6], mkv[6], skv[6];
@@ -338,7 +415,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         for (int e = 0; e < 6; ++e) {
             const int i = ib + (e >> 1), k = e & 1;
             const int m = i * 16 + r;
-            const int trow = m / a.TXT, txt = m - trow * a.TXT;
+            const int trow = m / TXTv, txt = m - trow * TXTv;
             int oy = gy0 + trow;
             const int ox = 4 * (gt0 + txt) + 2 * xt + k;
             ok[e] = oy < a.H && ox < a.W;
@@ -386,8 +463,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             *(f32x4*)(a.y + idx[e]) = o;
         }
     }
-    PESR_STAMP(w4_timing, 4);
-    PESR_STAMP_CLK(w4_timing, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -507,14 +582,18 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     a.ksplit = p.ksplit; a.chunks_per_split = p.chunks_per_split; a.slab = (float*)ws;
     a.stack = p.stack; a.stack_n = N; a.v_row = p.v_row;
     if (p.stack) a.N = 1;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    if (p.dense) hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
-    else hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3((unsigned)(p.tiles * p.ksplit)), dim3(512), p.lds, stream, a);
+    static PesrDeviceOnce attr_once;
+    attr_once([&] {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    const dim3 grid((unsigned)(p.tiles * p.ksplit));
+    if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0>), grid, dim3(512), p.lds, stream, a);
+    else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12>), grid, dim3(512), p.lds, stream, a);
+    else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24>), grid, dim3(512), p.lds, stream, a);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0>), grid, dim3(512), p.lds, stream, a);
     if (p.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, act,
                                               slope, stream);

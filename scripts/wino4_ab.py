@@ -1,6 +1,6 @@
 """Same-session interleaved A/B of builds of the F(4,3) conv kernel (each a separate libpesr_hip*.so, scripts/build_variant.sh):
     python scripts/wino4_ab.py [fwd|skip|mask|both|wgrad] pesr_amd/libpesr_hip.so exp/libX.so ...     (G-body shape, batch 16)
-fwd = bias + ReLU (ResBlock conv1); skip = bias, x 0.1, + skip (conv2, and the input gradient of conv1 without bias); mask = x 0.1 and
+wgrad / wgrad1d / wgrad16 = the weight gradient (auto / 1-D F(4,3) on 32x32x2 / on 16x16x4); fwd = bias + ReLU (ResBlock conv1); skip = bias, x 0.1, + skip (conv2, and the input gradient of conv1 without bias); mask = x 0.1 and
 ReLU mask (input gradient of conv2); both = mask + skip (tests only)."""
 import ctypes, os, statistics, sys
 import torch
@@ -9,7 +9,7 @@ sys.path.insert(0, R)
 from pesr_amd import _lib
 what = "fwd"
 args = sys.argv[1:]
-if args and args[0] in ("fwd", "skip", "mask", "both", "wgrad"):
+if args and args[0] in ("fwd", "skip", "mask", "both", "wgrad", "wgrad1d", "wgrad16"):
     what = args.pop(0)
 libs = args
 N, H, W, C = 16, 48, 48, 256
@@ -21,6 +21,7 @@ handles = []
 for path in libs:
     l = ctypes.CDLL(os.path.join(R, path))
     for name, (res, a) in _lib.SIGNATURES.items():
+        if not hasattr(l, name): continue      # (an older build)
         f = getattr(l, name); f.restype = res; f.argtypes = a
     handles.append(l)
 s = torch.cuda.current_stream().cuda_stream
@@ -31,8 +32,9 @@ def run(l, iters=20):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        if what == "wgrad":   # transposed F(4,3) weight gradient + its reduce kernel (algo 0 = auto)
-            rc = l.pesr_conv3x3_wgrad(x.data_ptr(), sk.data_ptr(), dw.data_ptr(), dbias.data_ptr(), N, H, W, C, C, 1, 1.0, 0, 0, 0, ws.data_ptr(), ws.numel(), s)
+        if what.startswith("wgrad"):   # transposed Winograd weight gradient + its reduce kernel (algo 0 = auto; wgrad1d: 4 = the 1-D F(4,3) form; wgrad16: 3)
+            rc = l.pesr_conv3x3_wgrad(x.data_ptr(), sk.data_ptr(), dw.data_ptr(), dbias.data_ptr(), N, H, W, C, C, 1, 1.0, 0,
+                                      {"wgrad": 0, "wgrad1d": 4, "wgrad16": 3}[what], 0, ws.data_ptr(), ws.numel(), s)
         elif what == "both":   # ReLU mask + residual add
             rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), None, sk.data_ptr(), x.data_ptr(), y.data_ptr(), N, H, W, C, C, 0.1, 0, 0.0, 0, 0, None, 0, s)
         elif what == "skip":

@@ -281,7 +281,7 @@ def test_conv3x3_wgrad_all_algorithms(N, H, W, Cin, Cout):
     x = _rand(N, Cin, H, W, seed=900); w = _rand(Cout, Cin, 3, 3, seed=910, scale=0.1)
     dy = _rand(N, Cout, H, W, seed=920)
     _, dw_ref, db_ref = O.conv3x3_grads(x.double(), w.double(), dy.double())
-    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO23, ops.WGRAD_DIRECT, ops.WGRAD_WINO4_16X16):
+    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO23, ops.WGRAD_DIRECT, ops.WGRAD_WINO4_16X16, ops.WGRAD_WINO4_1D):
         dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, alpha=0.5, algo=algo)
         _close(dw.cpu().double(), 0.5 * dw_ref, 1e-5); _close(db.cpu().double(), 0.5 * db_ref, 1e-5)
 
@@ -294,7 +294,7 @@ def test_conv3x3_wgrad_winograd4_pixel_shuffle_fused():
     x = _rand(N, C, H, W, seed=1); w = _rand(4 * C, C, 3, 3, seed=2, scale=0.1)
     dys = _rand(N, C, 2 * H, 2 * W, seed=4)
     _, dw_ref, db_ref = O.conv3x3_grads(x.double(), w.double(), F.pixel_unshuffle(dys, 2).double())
-    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO23, ops.WGRAD_WINO4_16X16):
+    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO23, ops.WGRAD_WINO4_16X16, ops.WGRAD_WINO4_1D):
         dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dys), 1, ps_in=True, algo=algo)
         _close(dw.cpu().double(), dw_ref, 1e-5); _close(db.cpu().double(), db_ref, 1e-5)
 
