@@ -1,5 +1,5 @@
-// DIAGNOSTIC COPY (ablation switches W4_ABL_* / G4_ABL_*, -DPESR_TIMING phase stamps) of the product kernel in pesr_amd/csrc:
-// built only by scripts/build_timing.sh / scripts/build_variant.sh into exp/lib*.so for A/B timing; never linked into libpesr_hip.so.
+// DIAGNOSTIC copy of pesr_amd/csrc/conv3x3_wgrad_wino4.hip (timing experiments with WRONG results): -DX4D_NO_READ drops the loop's LDS fragment
+// reads, -DX4D_NO_STAGE its staging (loads, transforms, LDS stores), -DX4D_NO_BARRIER the per-segment barrier.  scripts/build_variant.sh.
 // Weight gradient of the stride-1 3x3 conv with the transposed 1-D Winograd F(4,3) along x, fp32-input MFMA, gfx950.
 //
 // Same contract as conv3x3_wgrad.hip (ATen convolution_backward's grad_weight for the reference `Conv`,
@@ -25,8 +25,8 @@
 // has the direct kernel's [split][9][Cout][Cin] layout and its fixed-order reduce kernel (alpha, PixelShuffle channel
 // un-permutation, OIHW store, bias) is shared.  The bias gradient is accumulated on the VALU from the dM_1 fragments
 // (dy0+dy1+dy2+dy3).
+#include <mutex>
 #include "common.h"
-#include "timing.h"
 #include "launchers.h"
 
 struct Wg4Args {
@@ -48,16 +48,8 @@ constexpr int G4_VPLANE = G4_K4 * 128, G4_VROW = 6 * G4_VPLANE;       // floats:
 constexpr int G4_DPLANE = G4_K4 * 256, G4_DROW = 6 * G4_DPLANE;       // floats: dM row     [6 xi][3 blocks][4 x-tiles x 64 co]
 constexpr int G4_RING = 6;
 
-#ifdef PESR_TIMING
-__device__ unsigned long long g4_timing[4096 * PESR_TIMING_SLOTS];
-PESR_API int pesr_debug_timing_wgrad4(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_timing), (size_t)n * sizeof(unsigned long long));
-}
-#endif
 
 __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Args a) {
-    PESR_STAMP(g4_timing, 0);
-    PESR_STAMP_CLK(g4_timing, 6);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const vring = lds;                             // [6 slots] V rows
     float* const dmbuf = lds + G4_RING * G4_VROW;         // [2 buffers][2 rows] dM rows
@@ -154,13 +146,6 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             const f32x4 d0 = __builtin_bit_cast(f32x4, vx[0]), d1 = __builtin_bit_cast(f32x4, vx[1]), d2 = __builtin_bit_cast(f32x4, vx[2]),
                         d3 = __builtin_bit_cast(f32x4, vx[3]), d4 = __builtin_bit_cast(f32x4, vx[4]), d5 = __builtin_bit_cast(f32x4, vx[5]);
             float* p = vring + slot * G4_VROW + v_pos;
-#if defined(G4_ABL_XFORM)      // timing-only: raw values, no transform arithmetic
-            *(f32x4*)(p) = d0; *(f32x4*)(p + G4_VPLANE) = d1; *(f32x4*)(p + 2 * G4_VPLANE) = d2;
-            *(f32x4*)(p + 3 * G4_VPLANE) = d3; *(f32x4*)(p + 4 * G4_VPLANE) = d4; *(f32x4*)(p + 5 * G4_VPLANE) = d5;
-#elif defined(G4_ABL_LDSW)     // timing-only: the arithmetic, one ds_write instead of six
-            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
-            *(f32x4*)(p) = ((4.0f * d0 + (d4 - 5.0f * d2)) * (t1 + t2)) * ((t1 - t2) * (t3 + 2.0f * t4)) * ((t3 - 2.0f * t4) * (4.0f * d1 + (d5 - 5.0f * d3)));
-#else
             const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
             *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
             *(f32x4*)(p + G4_VPLANE) = t1 + t2;
@@ -168,7 +153,6 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             *(f32x4*)(p + 3 * G4_VPLANE) = t3 + 2.0f * t4;
             *(f32x4*)(p + 4 * G4_VPLANE) = t3 - 2.0f * t4;
             *(f32x4*)(p + 5 * G4_VPLANE) = 4.0f * d1 + (d5 - 5.0f * d3);
-#endif
         }
     };
     auto load_d = [&](int img, int oy) {                   // output-gradient row oy (>= H: zeros)
@@ -188,13 +172,6 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             const f32x4 g0 = __builtin_bit_cast(f32x4, dd[0]), g1 = __builtin_bit_cast(f32x4, dd[1]), g2 = __builtin_bit_cast(f32x4, dd[2]),
                         g3 = __builtin_bit_cast(f32x4, dd[3]);
             float* p = dmbuf + (buf * 2 + d_rr) * G4_DROW + d_pos;
-#if defined(G4_ABL_XFORM)
-            *(f32x4*)(p) = g0; *(f32x4*)(p + G4_DPLANE) = g1; *(f32x4*)(p + 2 * G4_DPLANE) = g2;
-            *(f32x4*)(p + 3 * G4_DPLANE) = g3; *(f32x4*)(p + 4 * G4_DPLANE) = g0; *(f32x4*)(p + 5 * G4_DPLANE) = g3;
-#elif defined(G4_ABL_LDSW)
-            const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
-            *(f32x4*)(p) = (g0 * (e02 + e13)) * ((e02 - e13) * (f02 + 2.0f * f13)) * ((f02 - 2.0f * f13) * g3);
-#else
             const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
             *(f32x4*)(p) = g0;
             *(f32x4*)(p + G4_DPLANE) = e02 + e13;
@@ -202,7 +179,6 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
             *(f32x4*)(p + 3 * G4_DPLANE) = f02 + 2.0f * f13;
             *(f32x4*)(p + 4 * G4_DPLANE) = f02 - 2.0f * f13;
             *(f32x4*)(p + 5 * G4_DPLANE) = g3;
-#endif
         }
     };
     auto seg_coords = [&](int seg, int& img, int& xs, int& row) {
@@ -232,15 +208,11 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
     // of segment s they were waited for a third of a segment later - under load an L2 / MALL round trip is longer than that.
     if (seg_begin + 1 < seg_end && row + 2 < a.H) { load_v(img, row + 3); load_d(img, row + 2 + d_rr); }
     __syncthreads();
-    PESR_STAMP(g4_timing, 1);
     int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
     // One common store point for all waves, two thirds into the segment, with the next loads issued right behind it.  Measured
     // alternatives: different store points for the two waves of a SIMD 1.4 % slower; the loads spread over three k-steps instead
     // of one burst 12 % slower (those issued two k-steps before the store have not landed - a loaded L2 round trip is > 1 us).
-#ifndef G4_STORE_STEP
-#define G4_STORE_STEP 4
-#endif
-    constexpr int store_step = G4_STORE_STEP;
+    constexpr int store_step = 4;
 
 #pragma unroll 1
     for (int seg = seg_begin; seg < seg_end; ++seg) {
@@ -275,14 +247,6 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
                     acc[ky * 3 + xl][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[xl * 2 + i], BV[ky * 3 + xl], acc[ky * 3 + xl][i], 0, 0, 0); \
         if (xh == 0) { _Pragma("unroll") for (int i = 0; i < 2; ++i) bsum[i] += AV[2 + i]; }   /* dM_1 = dy0+dy1+dy2+dy3 */
-#ifdef G4_ABL_READS
-#undef G4_READ
-#define G4_READ(AV, BV, STEP) if (a.ps_in == 12345) { _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) AV[q_] = db[q_ * 64 + (STEP)]; _Pragma("unroll") for (int q_ = 0; q_ < 9; ++q_) BV[q_] = vb[0][q_ * 64 + (STEP)]; }
-#pragma unroll
-        for (int q_ = 0; q_ < 6; ++q_) av0[q_] = av1[q_] = 1.0f;
-#pragma unroll
-        for (int q_ = 0; q_ < 9; ++q_) bv0[q_] = bv1[q_] = 1.0f;
-#endif
         G4_READ(av0, bv0, 0)
 #pragma unroll
         for (int stp = 0; stp < 2 * G4_K4; stp += 2) {
@@ -295,27 +259,9 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
                 // The staging stores go to LDS that nobody reads in this segment (the two free ring slots, the other dM
                 // buffer); right behind them the loads for the segment after next reuse the staging registers.
                 __builtin_amdgcn_sched_barrier(0);
-#if defined(G4_ABL_STAGE)     // timing-only ablation builds (scripts/wino4_ab.py wgrad): false at run time, nothing is DCE'd
-                if (cont && a.ps_in == 12345) {
-#else
                 if (cont) {
-#endif
                     int sl = base + 4 + v_rr; if (sl >= G4_RING) sl -= G4_RING;
-#ifdef G4_ABL_STORES
-                    if (a.ps_in == 12345)
-#endif
                     { store_v(sl); store_d(par ^ 1); }
-#ifdef G4_ABL_STORES
-                    else {
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(vx[j]));
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(dd[j]));
-                    }
-#endif
-#ifdef G4_ABL_LOADS
-                    if (a.ps_in == 12345)
-#endif
                     if (cont2) { load_v(img, row + 5); load_d(img, row + 4 + d_rr); }
                 }
             }
@@ -326,26 +272,20 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
 #undef G4_READ
 #undef G4_MFMA
         if (cont) {                                         // rows +3, +4 went to the slots of rows -1, 0, which the next segment drops
-#ifdef G4_ABL_BARRIER
-            if (a.ps_in == 12345)
-#endif
             __syncthreads();
             base += 2; if (base >= G4_RING) base -= G4_RING;
             row += 2;
         } else if (more) {                                  // new strip / image: its four halo rows are staged from scratch
             __syncthreads();
-            PESR_STAMP(g4_timing, 4);
             seg_coords(seg + 1, img, xs, row);
             set_strip(xs);
             stage_strip_start(img, row, par ^ 1);
             if (seg + 2 < seg_end && row + 2 < a.H) { load_v(img, row + 3); load_d(img, row + 2 + d_rr); }
             __syncthreads();
-            PESR_STAMP(g4_timing, 5);
             base = 0;
         }
     }
     __syncthreads();
-    PESR_STAMP(g4_timing, 2);
 
     if (a.bias_part && cit == 0) {   // combine the 4 k-slot lane groups through LDS (the staging buffers are free now), fixed order
         float* red = lds;
@@ -397,8 +337,343 @@ __global__ __launch_bounds__(G4_NT) void conv3x3_wgrad_wino4_kernel(const Wg4Arg
         }
         if (ph == 0) __syncthreads();
     }
-    PESR_STAMP(g4_timing, 3);
-    PESR_STAMP_CLK(g4_timing, 7);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round-3 variant on v_mfma_f32_32x32x2_f32 (PESR_WGRAD_WINO4X): same transform, same 64(co) x 32(ci) x 18 block, same segment
+// sweep, ring, split-K slab and reduce.  What changes is who owns what: TWELVE waves = 2 co halves (32 channels each) x the 6 xi
+// planes; a wave keeps dU_xi[ky = 0..2] of its 32 x 32 tile (3 accumulator tiles = 48 VGPRs) and, per k-step (TWO x-tiles),
+// reads 2 dM fragments (the segment's two rows) and 4 V fragments (input rows r-1 .. r+2) for SIX 64-cycle MFMAs - one
+// ds_read_b32 per MFMA where the 16x16x4 form above needs 15 per 18 32-cycle MFMAs, i.e. 0.4 of the LDS read bytes per flop.
+// The LDS planes are plain [x-tile][channel] arrays: a fragment read touches 2 x 32 consecutive floats, an item's staging store
+// 8 lanes x 16 bytes contiguous - conflict-free without any swizzle.  Three waves per SIMD hide what two could not.
+// G^T needs all six xi of a tap: the waves park their accumulators in LDS (147 KB, the staging buffers are free by then) and all
+// 768 threads finish the nine taps of the block in the same order of additions as the kernel above.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int X4_NT = 768;
+constexpr int X4_VPLANE = G4_TXT * 32, X4_VROW = 6 * X4_VPLANE;       // floats: V row slot [6 xi][12 x-tiles][32 ci]
+constexpr int X4_DPLANE = G4_TXT * 64, X4_DROW = 6 * X4_DPLANE;       // floats: dM row     [6 xi][12 x-tiles][64 co]
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4, NEST = true (the default): the transform NESTED in y - F(2,3) along y on top of F(4,3) along x - at no cost in staging.
+// A segment is two output rows; per k-step a wave already holds, for its xi plane, the x-transformed gradients D0, D1 of the two
+// rows and the x-transformed inputs X0 .. X3 of the four input rows they touch, and the 1-D form spends SIX MFMAs on
+//     dU[ky] += D0 * X[ky] + D1 * X[ky + 1],  ky = 0, 1, 2
+// - a 3-tap correlation of 2 against 4 values, i.e. exactly the F(2,3) weight-gradient problem.  Its four products
+//     P0 += D0 * (X0 - X2)    P1 += (D0 + D1) * (X1 + X2)    P2 += (D0 - D1) * (X2 - X1)    P3 += D1 * (X3 - X1)
+// give dU[0] = P0 + (P1 + P2) / 2, dU[1] = (P1 - P2) / 2, dU[2] = (P1 + P2) / 2 + P3 (G2^T, applied once, in registers, in front of
+// the G4^T epilogue): FOUR MFMAs per k-step for the same fragment reads, the same staging, ring and LDS image - five VALU adds per
+// k-step buy a third of the matrix work (24 products per 2 x 4 output pixels: 1/3 of the direct form's 72).  One more accumulator
+// tile per wave (64 VGPRs).  Numerics (scripts/wino2d_wgrad_study.py, fp32 emulation vs fp64 at 16 x 48 x 48 pixels): 2.0 - 2.3e-6
+// of the gradient's maximum against 2.1 - 3.5e-6 for the 1-D form - the F(2,3) matrices are 0, +-1, 1/2.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <bool NEST>
+__global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const vring = lds;                             // [6 slots] V rows
+    float* const dmbuf = lds + G4_RING * X4_VROW;         // [2 buffers][2 rows] dM rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c32 = lane & 31, ks = lane >> 5;            // fragment lane: channel, k-slot (x-tile 2q + ks of k-step q)
+    const int cot2 = wave / 6, xi = wave - cot2 * 6;
+
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int cit = bid % a.ci_tiles;  bid /= a.ci_tiles;
+    const int cot = bid % a.co_tiles;
+    const int sp = bid / a.co_tiles;
+    const int ci0 = cit * 32, co0 = cot * 64;
+
+    const int seg_begin = sp * a.segs_per_split;
+    int seg_end = seg_begin + a.segs_per_split;
+    if (seg_end > a.total_segs) seg_end = a.total_segs;
+
+    constexpr int NACC = NEST ? 4 : 3;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    float bsum = 0.f;
+
+    // ---- staging roles: threads 0..191 (waves 0..2) the 192 V items (2 rows x 12 x-tiles x 8 ci groups, six input columns each),
+    //      threads 192..575 (waves 3..8) the 384 dM items (2 rows x 12 x-tiles x 16 co groups, four columns each); one register set
+    //      waves 9..11 idle in the loop; at a strip start they take the V role for the strip's SECOND pair of halo rows, so that its
+    //      four halo rows arrive in one load round instead of two dependent ones
+    const bool v_thr = tid < 192 || tid >= 576, d_thr = tid >= 192 && tid < 576;
+    const int vi = tid < 192 ? tid : (tid >= 576 ? tid - 576 : 0);
+    const int v_rr = vi / 96, vt = (vi % 96) >> 3, vc4 = vi & 7;
+    const int di = d_thr ? tid - 192 : 0;
+    const int d_rr = di / 192, dt = (di % 192) >> 4, dc4 = di & 15;
+    const int v_pos = vt * 32 + vc4 * 4;
+    const int d_pos = dt * 64 + dc4 * 4;
+    const int d_C = a.ps_in ? (a.Cout >> 2) : a.Cout;
+    int d_choff;
+    {
+        const int pch = co0 + dc4 * 4;
+        if (a.ps_in) { const int sub = pch / d_C, cc = pch - sub * d_C; d_choff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * d_C + cc; }
+        else d_choff = pch;
+    }
+    u32x4 st[6];                  // V thread: six input columns; dM thread: four gradient columns
+    unsigned off[6];
+    auto set_strip = [&](int xs) {
+        if (v_thr) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ix = xs * 48 + 4 * vt - 1 + j;
+                off[j] = (ix >= 0 && ix < a.W) ? (unsigned)((ix * a.Cin + ci0 + vc4 * 4) * 4) : 0x80000000u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ox = xs * 48 + 4 * dt + j;
+                off[j] = (d_thr && ox < a.W) ? (unsigned)(((a.ps_in ? 2 * ox * d_C : ox * a.Cout) + d_choff) * 4) : 0x80000000u;
+            }
+            off[4] = off[5] = 0x80000000u;
+        }
+    };
+    const unsigned x_row_bytes = (unsigned)a.W * a.Cin * 4;
+    const unsigned d_row_bytes = (unsigned)a.W * a.Cout * 4;
+    auto uniform_ptr = [](const float* p) -> const float* {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const float*)(((unsigned long long)hi << 32) | lo);
+    };
+    // (descriptors wave-uniform, as above: the V descriptor spans the two rows that mix inside wave 1, lanes add their row's
+    // pitch; the dM rows change at thread 384 = a wave boundary)
+    auto load_stage = [&](int img, int v_iy0, int d_oy0, const bool hi = false) {   // V rows v_iy0, v_iy0 + 1; dM rows d_oy0, d_oy0 + 1
+        if (hi ? wave >= 9 : wave < 3) {                                              // (hi: the V role on waves 9..11, no dM role)
+            const float* const rowp = a.x + ((long)img * a.H + v_iy0) * ((long)a.W * a.Cin);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0, 2 * x_row_bytes, 0x00020000);
+            const int iy = v_iy0 + v_rr;
+            const bool row_ok = iy >= 0 && iy < a.H;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                st[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? off[j] + (unsigned)v_rr * x_row_bytes : 0x80000000u, 0, 0);
+        } else if (!hi && wave >= 3 && wave < 9) {
+            const int oy = d_oy0 + d_rr;
+            const bool row_ok = oy < a.H;
+            const int ry = row_ok ? oy : 0;
+            const float* const rowp = a.ps_in ? a.dy + ((size_t)img * (2 * a.H) + 2 * ry) * (2 * a.W) * d_C
+                                              : a.dy + ((size_t)img * a.H + ry) * a.W * a.Cout;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0,
+                                                                                __builtin_amdgcn_readfirstlane(row_ok ? d_row_bytes : 0u), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, 0);
+        }
+    };
+    auto store_stage = [&](int v_slot0, int d_buf, const bool hi = false) {   // V rows -> ring slots v_slot0 + v_rr (mod 6); dM rows -> buffer d_buf
+        if (hi ? wave >= 9 : wave < 3) {
+            const f32x4 d0 = __builtin_bit_cast(f32x4, st[0]), d1 = __builtin_bit_cast(f32x4, st[1]), d2 = __builtin_bit_cast(f32x4, st[2]),
+                        d3 = __builtin_bit_cast(f32x4, st[3]), d4 = __builtin_bit_cast(f32x4, st[4]), d5 = __builtin_bit_cast(f32x4, st[5]);
+            int sl = v_slot0 + v_rr; if (sl >= G4_RING) sl -= G4_RING;
+            float* p = vring + sl * X4_VROW + v_pos;
+            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
+            *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
+            *(f32x4*)(p + X4_VPLANE) = t1 + t2;
+            *(f32x4*)(p + 2 * X4_VPLANE) = t1 - t2;
+            *(f32x4*)(p + 3 * X4_VPLANE) = t3 + 2.0f * t4;
+            *(f32x4*)(p + 4 * X4_VPLANE) = t3 - 2.0f * t4;
+            *(f32x4*)(p + 5 * X4_VPLANE) = 4.0f * d1 + (d5 - 5.0f * d3);
+        } else if (!hi && wave >= 3 && wave < 9) {
+            const f32x4 g0 = __builtin_bit_cast(f32x4, st[0]), g1 = __builtin_bit_cast(f32x4, st[1]), g2 = __builtin_bit_cast(f32x4, st[2]),
+                        g3 = __builtin_bit_cast(f32x4, st[3]);
+            float* p = dmbuf + (d_buf * 2 + d_rr) * X4_DROW + d_pos;
+            const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
+            *(f32x4*)(p) = g0;
+            *(f32x4*)(p + X4_DPLANE) = e02 + e13;
+            *(f32x4*)(p + 2 * X4_DPLANE) = e02 - e13;
+            *(f32x4*)(p + 3 * X4_DPLANE) = f02 + 2.0f * f13;
+            *(f32x4*)(p + 4 * X4_DPLANE) = f02 - 2.0f * f13;
+            *(f32x4*)(p + 5 * X4_DPLANE) = g3;
+        }
+    };
+    auto seg_coords = [&](int seg, int& img, int& xs, int& row) {
+        const int strip = seg / a.segs_y;
+        row = 2 * (seg - strip * a.segs_y);
+        img = strip / a.segs_x;
+        xs = strip - img * a.segs_x;
+    };
+    auto stage_strip_start = [&](int img, int row, int buf) {   // halo rows row-1 .. row+2 -> slots 0 .. 3; dM(row, row+1) -> buf
+        load_stage(img, row - 1, row);                            // waves 0..2: V rows row-1, row; waves 3..8: both dM rows
+        load_stage(img, row + 1, 0, true);                        // waves 9..11: V rows row+1, row+2 - the same load round
+        store_stage(0, buf); store_stage(2, buf, true);
+    };
+
+    // ---- fragment addresses (floats): lane (c32, ks) reads x-tile 2q + ks, channel c32 of its tile ---------------------------
+    const int b_lane = xi * X4_VPLANE + ks * 32 + c32;
+    const int a_lane = xi * X4_DPLANE + ks * 64 + cot2 * 32 + c32;
+
+    if (seg_begin >= seg_end) return;
+    int img, xs, row;
+    seg_coords(seg_begin, img, xs, row);
+    set_strip(xs);
+    stage_strip_start(img, row, 0);
+    if (seg_begin + 1 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
+    __syncthreads();
+    int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
+    constexpr int KQ = G4_TXT / 2;                          // k-steps per row
+    // Static priority for the second-dispatched half (waves 6..11), set once: the two halves run the same program in lockstep
+    // behind one barrier per segment, and the younger half loses every arbitration; raised, it pulls ahead and the halves'
+    // LDS read bursts and MFMA blocks de-phase (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): 209.6 -> 206.2 us; three
+    // levels (w, w + 4, w + 8 share a SIMD) 206.9, the first half raised instead 208.8 (profiles/r03_wgrad_variants.txt).
+    if (cot2) __builtin_amdgcn_s_setprio(1);
+    constexpr int X4_STORE_STEP = 3;    // the staging stores sit behind this k-step (2 / 3 / 4 measured: 207 - 209 us, profiles/r03_wgrad_variants.txt)
+
+    // Two nested loops - strips outside, a strip's segments inside - instead of one loop over segments with a cold "next strip"
+    // branch: the staging registers' value for the next iteration then has ONE definition inside the hot loop (the load_stage
+    // below, issued unconditionally), where it had two merging at the loop header - hipcc resolved that merge with s_waitcnt
+    // vmcnt(0) + 30 register copies at the end of every segment, i.e. the loads had half a segment to arrive, not a whole one.
+    int seg = seg_begin;
+#ifdef X4D_NO_READ
+    float fa0[2] = {0, 0}, fb0[4] = {0, 0, 0, 0}, fa1[2] = {0, 0}, fb1[4] = {0, 0, 0, 0};
+#endif
+#pragma unroll 1
+    for (;;) {
+#pragma unroll 1
+      for (;;) {
+        const int par = (seg - seg_begin) & 1;
+        const bool more = seg + 1 < seg_end;
+        const bool cont = more && row + 2 < a.H;
+        const bool cont2 = cont && seg + 2 < seg_end && row + 4 < a.H;
+        const float* const db = dmbuf + (par * 2) * X4_DROW + a_lane;
+        const float* vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int sl = base + q; if (sl >= G4_RING) sl -= G4_RING;
+            vb[q] = vring + sl * X4_VROW + b_lane;
+        }
+#ifndef X4D_NO_READ
+        float fa0[2], fb0[4], fa1[2], fb1[4];
+#endif
+#define X4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define X4_READ(FA, FB, Q)                                                                       \
+        {                                                                                        \
+            FA[0] = db[(Q) * 128]; FA[1] = db[X4_DROW + (Q) * 128];                              \
+            _Pragma("unroll") for (int rw = 0; rw < 4; ++rw) FB[rw] = vb[rw][(Q) * 64];          \
+        }
+#define X4_MFMA(FA, FB)                                                                          \
+        if (NEST) {                                                                              \
+            const float ds_ = FA[0] + FA[1], dd_ = FA[0] - FA[1];                                \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[0] - FB[2], acc[0], 0, 0, 0); \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds_, FB[1] + FB[2], acc[1], 0, 0, 0);  \
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dd_, FB[2] - FB[1], acc[2], 0, 0, 0);  \
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[3] - FB[1], acc[3], 0, 0, 0); \
+            if (xi == 1) bsum += ds_;                       /* dM_1 = dy0+dy1+dy2+dy3, both rows */ \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                   \
+                acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0); \
+                acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
+            }                                                                                    \
+            if (xi == 1) bsum += FA[0] + FA[1];             /* dM_1 = dy0+dy1+dy2+dy3 */          \
+        }
+#ifdef X4D_NO_READ
+        if (seg == seg_begin) { X4_READ(fa0, fb0, 0) X4_READ(fa1, fb1, 1) }
+#else
+        X4_READ(fa0, fb0, 0)
+#endif
+#pragma unroll
+        for (int q = 0; q < KQ; q += 2) {
+#ifndef X4D_NO_READ
+            X4_READ(fa1, fb1, q + 1)
+#endif
+            X4_FENCE();
+            X4_MFMA(fa0, fb0)
+            X4_FENCE();
+#ifndef X4D_NO_READ
+            if (q + 2 < KQ) X4_READ(fa0, fb0, q + 2)
+#endif
+            if (q + 1 == X4_STORE_STEP || q == X4_STORE_STEP) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef X4D_NO_STAGE
+                if (false) {
+#else
+                if (cont) {
+#endif
+#ifndef X4D_LOAD_ONLY
+                    store_stage(base + 4, par ^ 1);
+#endif
+                    (void)cont2;
+#ifndef X4D_STORE_ONLY
+                    load_stage(img, row + 5, row + 4);      // (rows past the image or the slice read zeros through a zero-size descriptor)
+#endif
+                }
+            }
+            X4_FENCE();
+            X4_MFMA(fa1, fb1)
+            X4_FENCE();
+        }
+#undef X4_READ
+#undef X4_MFMA
+#undef X4_FENCE
+        if (!cont) break;
+#ifndef X4D_NO_BARRIER
+        __syncthreads();
+#endif
+        base += 2; if (base >= G4_RING) base -= G4_RING;
+        row += 2;
+        ++seg;
+      }
+      if (seg + 1 >= seg_end) break;
+      // the slice continues in the next strip: its first segment is staged synchronously
+      {
+        const int par = (seg - seg_begin) & 1;
+        __syncthreads();
+        seg_coords(seg + 1, img, xs, row);
+        set_strip(xs);
+        stage_strip_start(img, row, par ^ 1);
+        if (seg + 2 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
+        __syncthreads();
+        base = 0;
+        ++seg;
+      }
+    }
+    __syncthreads();
+
+    if (a.bias_part && cit == 0) {     // the xi = 1 waves hold column sums of dy: lane pairs (c, c + 32) meet in LDS, fixed order
+        float* red = lds;
+        if (xi == 1) red[cot2 * 64 + lane] = bsum;
+        __syncthreads();
+        if (tid < 64 && co0 + tid < a.Cout) {
+            const int h = tid >> 5, c = tid & 31;
+            a.bias_part[(size_t)sp * a.Cout + co0 + tid] = red[h * 64 + c] + red[h * 64 + 32 + c];
+        }
+        __syncthreads();
+    }
+    // ---- G^T: park the accumulators as ob[cot2][xi][ky][row 32][col 32], then every thread finishes 8 (co, ci) positions ------
+    float* const ob = lds;
+    if (NEST) {      // G2^T first, in registers: the four y-planes of this wave's (co half, xi) become its three ky taps
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float hs = 0.5f * (acc[1][j] + acc[2][j]), hd = 0.5f * (acc[1][j] - acc[2][j]);
+            acc[0][j] = acc[0][j] + hs; acc[1][j] = hd; acc[2][j] = hs + acc[3][j];
+        }
+    }
+    {
+        float* o = ob + ((cot2 * 6 + xi) * 3) * 1024 + c32;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rw = (j >> 2) * 8 + ks * 4 + (j & 3);          // D layout of the 32x32 tile: row = co, col = lane & 31 = ci
+                o[ky * 1024 + rw * 32] = acc[ky][j];
+            }
+    }
+    __syncthreads();
+    float* const out = a.slab + (size_t)sp * 9 * a.Cout * a.Cin;
+    const unsigned tap = (unsigned)a.Cout * a.Cin;
+    for (int e = tid; e < 2 * 3 * 1024; e += X4_NT) {
+        const int col = e & 31, rw = (e >> 5) & 31, ky = (e >> 10) % 3, h = e / 3072;
+        const float* u = ob + (h * 6 * 3 + ky) * 1024 + rw * 32 + col;       // + xi * 3 * 1024
+        const float u0 = u[0], u1 = u[3072], u2 = u[2 * 3072], u3 = u[3 * 3072], u4 = u[4 * 3072], u5 = u[5 * 3072];
+        const float s12 = u1 + u2, d12 = u1 - u2, s34 = u3 + u4, d34 = u3 - u4;
+        const float w0 = (0.25f * u0 - (1.0f / 6.0f) * s12) + (1.0f / 24.0f) * s34;
+        const float w1 = ((-1.0f / 6.0f) * d12) + (1.0f / 12.0f) * d34;
+        const float w2 = ((-1.0f / 6.0f) * s12) + ((1.0f / 6.0f) * s34 + u5);
+        const unsigned go = ((unsigned)(ky * 3) * a.Cout + co0 + h * 32 + rw) * a.Cin + ci0 + col;
+        out[go] = w0; out[go + tap] = w1; out[go + 2 * tap] = w2;
+    }
 }
 
 namespace {
@@ -433,8 +708,9 @@ size_t pesr_conv3x3_wgrad_wino4_ws_bytes(int N, int H, int W, int Cin, int Cout)
 }
 
 // returns PESR_EINVAL when the shape is not covered (the caller then tries the F(2,3) form / the direct kernel)
+// variant 0: the 16x16x4 kernel (8 waves); 1: the 32x32x2 kernel (12 waves), 1-D transform; 2: the same kernel with the transform nested in y
 int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
-                                    float alpha, int ps_in, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                    float alpha, int ps_in, int accumulate, int variant, void* ws, size_t ws_bytes, hipStream_t stream) {
     Wg4Plan p;
     if (!wg4_plan(N, H, W, Cin, Cout, &p)) return PESR_EINVAL;
     if (!ws || ws_bytes < p.total_bytes) return PESR_EWORKSPACE;
@@ -448,13 +724,21 @@ int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, 
     constexpr size_t lds = (size_t)(G4_RING * G4_VROW + 4 * G4_DROW) * sizeof(float);
     static_assert(lds >= (size_t)9 * 64 * 32 * sizeof(float), "epilogue staging fits");
     static_assert(lds <= 160 * 1024, "wgrad-wino4 LDS budget");
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
+    static PesrDeviceOnce attr_once;
+    attr_once([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
+    constexpr size_t ldsx = (size_t)2 * 6 * 3 * 1024 * sizeof(float);      // the variant's G^T staging (147 KB) exceeds its ring (129 KB)
+    static_assert(ldsx >= (size_t)(G4_RING * X4_VROW + 4 * X4_DROW) * sizeof(float) && ldsx <= 160 * 1024, "wgrad-wino4x LDS budget");
+    static PesrDeviceOnce attr_once_x;
+    attr_once_x([&] {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
     const int grid = p.split * p.co_tiles * p.ci_tiles;
-    hipLaunchKernelGGL(conv3x3_wgrad_wino4_kernel, dim3(grid), dim3(G4_NT), lds, stream, a);
+    if (variant == 2) hipLaunchKernelGGL(conv3x3_wgrad_wino4x_kernel<true>, dim3(grid), dim3(X4_NT), ldsx, stream, a);
+    else if (variant == 1) hipLaunchKernelGGL(conv3x3_wgrad_wino4x_kernel<false>, dim3(grid), dim3(X4_NT), ldsx, stream, a);
+    else hipLaunchKernelGGL(conv3x3_wgrad_wino4_kernel, dim3(grid), dim3(G4_NT), lds, stream, a);
     int rc = pesr_launch_status();
     if (rc) return rc;
     // the partial blocks already are dw in tap order: the direct kernel's fixed-order reduce finishes the job
