@@ -68,7 +68,8 @@ int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float
 /* dw[O][I][3][3] (OIHW, the parameter's own layout) = alpha * sum_pixels dy (x) x ;  db[O] = alpha * sum dy.
  * db may be NULL.  ps_in as above.  Workspace: pesr_conv3x3_wgrad_workspace_bytes (same algo).
  * algo: PESR_WGRAD_AUTO = the transposed Winograd kernel (on v_mfma_f32_32x32x2_f32; F(4,3) along x nested with F(2,3) along y: a third of
- * the multiplies) where it applies (stride 1, width % 4 == 0 and >= 48, 64-multiple channels), else the F(2,3) one (even width >= 48; 2/3), else the direct kernel;
+ * the multiplies) where it applies (stride 1, 64-multiple channels, width % 4 == 0 and >= 48 - or a width of 24 / 16 / 12 / 8 pixels, whose images are
+ * laid side by side in the kernel's 48-pixel strips), else the F(2,3) one (even width >= 48; 2/3), else the direct kernel;
  * PESR_WGRAD_DIRECT = the direct kernel everywhere; PESR_WGRAD_WINO23 = F(2,3) where it applies, else direct.  All produce
  * the same gradient up to fp32 rounding (measured vs fp64: <= 2e-6 of the gradient's maximum); the choice is an argument,
  * never process state.

@@ -497,7 +497,7 @@ int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float*
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return PESR_EINVAL;
     if (ws_bytes < p.total_bytes || !ws) return PESR_EWORKSPACE;
     if (ps_in && (stride != 1 || Cout % 16)) return PESR_EINVAL;
-    if (stride == 1 && (algo == 0 || algo == 3 || algo == 4)) {   // Winograd F(4,3) where it applies (width % 4 == 0 and >= 48, 64-multiple channels)
+    if (stride == 1 && (algo == 0 || algo == 3 || algo == 4)) {   // Winograd F(4,3) where it applies (width % 4 == 0 and >= 48 - the 32x32x2 kernel also 24 / 16 / 12 / 8 -, 64-multiple channels)
         // auto: the 32x32x2-MFMA form with the transform nested in y (round 4: F(2,3)y x F(4,3)x, 1/3 of the direct form's multiplies);
         // PESR_WGRAD_WINO4_1D (4): round 3's 1-D F(4,3) transform on the same kernel; PESR_WGRAD_WINO4_16X16 (3): round 2's 16x16x4
         // form of the 1-D transform - both kept as cross-checks

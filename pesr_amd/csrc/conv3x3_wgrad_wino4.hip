@@ -1,7 +1,8 @@
 // Weight gradient of the stride-1 3x3 conv with the transposed 1-D Winograd F(4,3) along x, fp32-input MFMA, gfx950.
 //
 // Same contract as conv3x3_wgrad.hip (ATen convolution_backward's grad_weight for the reference `Conv`,
-// model/basic.py:4-7) for widths that are multiples of 4 (>= 48) and channel counts that are multiples of 64, with HALF of the
+// model/basic.py:4-7) for widths that are multiples of 4 (>= 48; the 32x32x2 kernel also 24 / 16 / 12 / 8: images side by side in a strip)
+// and channel counts that are multiples of 64, with HALF of the
 // direct kernel's multiplies.  It is the adjoint of conv3x3_wino4.hip: with V = B^T d of the six input columns of an x-tile
 // (four output pixels) and dM = A dy of the tile's four output gradients,
 //     dM = [dy0, dy0+dy1+dy2+dy3, dy0-dy1+dy2-dy3, dy0+2dy1+4dy2+8dy3, dy0-2dy1+4dy2-8dy3, dy3]
@@ -39,6 +40,9 @@ struct Wg4Args {
     int co_tiles, ci_tiles;
     int ps_in;
     float* bias_part;  // [split][Cout] partial column sums of dy, or null
+    int side;          // 32x32x2 kernel only: images per strip.  1, or (rows of W / 4 < 12 x-tiles: W = 24 / 16 / 12 ...) 12 / (W / 4) images
+                       // laid SIDE BY SIDE in one 12-x-tile strip (x-tile vt = image vt / (W/4), tile vt % (W/4)); `image` indices of the
+                       // segment walk are then groups of `side` images, N the real image count
 };
 
 constexpr int G4_NT = 512, G4_TXT = 12, G4_K4 = G4_TXT / 4;
@@ -415,24 +419,33 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     }
     u32x4 st[6];                  // V thread: six input columns; dM thread: four gradient columns
     unsigned off[6];
-    auto set_strip = [&](int xs) {
+    // side > 1: x-tile t of the strip is tile t % XTW of image (group * side + t / XTW); its columns never leave that image (the
+    // neighbour's pixels are NOT its halo: out-of-image columns read zeros as at a real image border)
+    const int XTW = a.W >> 2;
+    auto set_strip = [&](int xs, int grp) {
         if (v_thr) {
+            const int sub = a.side > 1 ? vt / XTW : 0, lt = a.side > 1 ? vt - sub * XTW : vt;
+            const bool img_ok = a.side == 1 || grp * a.side + sub < a.N;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const int ix = xs * 48 + 4 * vt - 1 + j;
-                off[j] = (ix >= 0 && ix < a.W) ? (unsigned)((ix * a.Cin + ci0 + vc4 * 4) * 4) : 0x80000000u;
+                const int ix = xs * 48 + 4 * lt - 1 + j;
+                off[j] = (img_ok && ix >= 0 && ix < a.W) ? (unsigned)((((sub * a.H) * a.W + ix) * a.Cin + ci0 + vc4 * 4) * 4) : 0x80000000u;
             }
         } else {
+            const int sub = a.side > 1 ? dt / XTW : 0, lt = a.side > 1 ? dt - sub * XTW : dt;
+            const bool img_ok = a.side == 1 || grp * a.side + sub < a.N;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int ox = xs * 48 + 4 * dt + j;
-                off[j] = (d_thr && ox < a.W) ? (unsigned)(((a.ps_in ? 2 * ox * d_C : ox * a.Cout) + d_choff) * 4) : 0x80000000u;
+                const int ox = xs * 48 + 4 * lt + j;
+                off[j] = (d_thr && img_ok && ox < a.W) ? (unsigned)(((a.ps_in ? 2 * ox * d_C : (sub * a.H * a.W + ox) * a.Cout) + d_choff) * 4) : 0x80000000u;
             }
             off[4] = off[5] = 0x80000000u;
         }
     };
     const unsigned x_row_bytes = (unsigned)a.W * a.Cin * 4;
     const unsigned d_row_bytes = (unsigned)a.W * a.Cout * 4;
+    const unsigned x_side_bytes = (unsigned)(a.side - 1) * a.H * x_row_bytes;     // the descriptors reach over the strip's other images
+    const unsigned d_side_bytes = (unsigned)(a.side - 1) * a.H * d_row_bytes;
     auto uniform_ptr = [](const float* p) -> const float* {
         const unsigned long long v = (unsigned long long)p;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -442,8 +455,8 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     // pitch; the dM rows change at thread 384 = a wave boundary)
     auto load_stage = [&](int img, int v_iy0, int d_oy0, const bool hi = false) {   // V rows v_iy0, v_iy0 + 1; dM rows d_oy0, d_oy0 + 1
         if (hi ? wave >= 9 : wave < 3) {                                              // (hi: the V role on waves 9..11, no dM role)
-            const float* const rowp = a.x + ((long)img * a.H + v_iy0) * ((long)a.W * a.Cin);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0, 2 * x_row_bytes, 0x00020000);
+            const float* const rowp = a.x + ((long)img * a.side * a.H + v_iy0) * ((long)a.W * a.Cin);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0, x_side_bytes + 2 * x_row_bytes, 0x00020000);
             const int iy = v_iy0 + v_rr;
             const bool row_ok = iy >= 0 && iy < a.H;
 #pragma unroll
@@ -454,9 +467,9 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
             const bool row_ok = oy < a.H;
             const int ry = row_ok ? oy : 0;
             const float* const rowp = a.ps_in ? a.dy + ((size_t)img * (2 * a.H) + 2 * ry) * (2 * a.W) * d_C
-                                              : a.dy + ((size_t)img * a.H + ry) * a.W * a.Cout;
+                                              : a.dy + ((size_t)img * a.side * a.H + ry) * a.W * a.Cout;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0,
-                                                                                __builtin_amdgcn_readfirstlane(row_ok ? d_row_bytes : 0u), 0x00020000);
+                                                                                __builtin_amdgcn_readfirstlane(row_ok ? d_side_bytes + d_row_bytes : 0u), 0x00020000);
 #pragma unroll
             for (int j = 0; j < 4; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, 0);
         }
@@ -506,7 +519,7 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     if (seg_begin >= seg_end) return;
     int img, xs, row;
     seg_coords(seg_begin, img, xs, row);
-    set_strip(xs);
+    set_strip(xs, img);
     stage_strip_start(img, row, 0);
     if (seg_begin + 1 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
     __syncthreads();
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
         const int par = (seg - seg_begin) & 1;
         __syncthreads();
         seg_coords(seg + 1, img, xs, row);
-        set_strip(xs);
+        set_strip(xs, img);
         stage_strip_start(img, row, par ^ 1);
         if (seg + 2 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
         __syncthreads();
@@ -652,16 +665,30 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
 }
 
 namespace {
-struct Wg4Plan { int co_tiles, ci_tiles, segs_x, segs_y, total_segs, split, segs_per_split; size_t slab_bytes, total_bytes; };
+struct Wg4Plan { int co_tiles, ci_tiles, segs_x, segs_y, total_segs, split, segs_per_split, side; size_t slab_bytes, total_bytes; };
 
 static bool wg4_plan(int N, int H, int W, int Cin, int Cout, Wg4Plan* p) {
-    if (W % 4 || W < 48 || Cin % 64 || Cout % 64 || N < 1 || H < 1) return false;
+    if (W % 4 || Cin % 64 || Cout % 64 || N < 1 || H < 1) return false;
     p->co_tiles = Cout / 64; p->ci_tiles = Cin / 32;
-    p->segs_x = (W / 4 + G4_TXT - 1) / G4_TXT;
     p->segs_y = (H + 1) / 2;
-    // a ragged last strip wastes MFMAs on zeros: accept up to ~1/8
-    if ((long)p->segs_x * G4_TXT * 8 > (long)(W / 4) * 9) return false;
-    p->total_segs = N * p->segs_x * p->segs_y;
+    p->side = 1;
+    if (W < 48) {
+        // Rows shorter than a strip (round 4; the 32x32x2 kernel only): 12 / (W / 4) images side by side in one strip, e.g. two of the
+        // Discriminator's 24-pixel-wide images (features.6: 194 us on the direct kernel, which issues three times the multiplies).
+        const int xtw = W / 4;
+        if (xtw < 2 || G4_TXT % xtw) return false;
+        p->side = G4_TXT / xtw;
+        if ((size_t)p->side * H * W * (Cin > Cout ? Cin : Cout) * 4 >= ((size_t)1 << 31)) return false;   // 32-bit offsets inside a strip
+        const int groups = (N + p->side - 1) / p->side;
+        if ((long)groups * G4_TXT * 8 > (long)N * xtw * 9) return false;          // a mostly empty last group
+        p->segs_x = 1;
+        p->total_segs = groups * p->segs_y;
+    } else {
+        p->segs_x = (W / 4 + G4_TXT - 1) / G4_TXT;
+        // a ragged last strip wastes MFMAs on zeros: accept up to ~1/8
+        if ((long)p->segs_x * G4_TXT * 8 > (long)(W / 4) * 9) return false;
+        p->total_segs = N * p->segs_x * p->segs_y;
+    }
     const int tiles = p->co_tiles * p->ci_tiles;
     int split = (256 + tiles - 1) / tiles;
     if (split > p->total_segs) split = p->total_segs;
@@ -688,13 +715,14 @@ int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, 
                                     float alpha, int ps_in, int accumulate, int variant, void* ws, size_t ws_bytes, hipStream_t stream) {
     Wg4Plan p;
     if (!wg4_plan(N, H, W, Cin, Cout, &p)) return PESR_EINVAL;
+    if (p.side > 1 && (variant == 0 || ps_in)) return PESR_EINVAL;     // side-by-side strips: the 32x32x2 kernel, plain gradients
     if (!ws || ws_bytes < p.total_bytes) return PESR_EWORKSPACE;
     if (ps_in && Cout % 256) return PESR_EINVAL;
     Wg4Args a{};
     a.x = x; a.dy = dy; a.slab = (float*)ws;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.segs_x = p.segs_x; a.segs_y = p.segs_y; a.total_segs = p.total_segs; a.segs_per_split = p.segs_per_split;
-    a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.ps_in = ps_in;
+    a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.ps_in = ps_in; a.side = p.side;
     a.bias_part = db ? (float*)((char*)ws + p.slab_bytes + (((size_t)Cout * sizeof(double) + 255) / 256) * 256) : nullptr;
     constexpr size_t lds = (size_t)(G4_RING * G4_VROW + 4 * G4_DROW) * sizeof(float);
     static_assert(lds >= (size_t)9 * 64 * 32 * sizeof(float), "epilogue staging fits");

@@ -205,14 +205,43 @@ USE_WGRAD_WINO = __import__("os").environ.get("PESR_WGRAD_WINO", "1") != "0"
 USE_WGRAD_WINO4 = __import__("os").environ.get("PESR_WGRAD_WINO4", "1") != "0"   # =0: F(2,3) weight gradient instead of F(4,3)
 
 
+def _wg4_plan_ok(N, H, W, Cin, Cout):
+    """wg4_plan of csrc/conv3x3_wgrad_wino4.hip: (covered, images per strip)."""
+    if W % 4 or Cin % 64 or Cout % 64 or N < 1 or H < 1:
+        return False, 1
+    xtw, segs_y, side = W // 4, (H + 1) // 2, 1
+    if W < 48:
+        if xtw < 2 or 12 % xtw:
+            return False, 1
+        side = 12 // xtw
+        groups = (N + side - 1) // side
+        if groups * 12 * 8 > N * xtw * 9 or side * H * W * max(Cin, Cout) * 4 >= 1 << 31:
+            return False, side
+        total = groups * segs_y
+    else:
+        segs_x = (xtw + 11) // 12
+        if segs_x * 12 * 8 > xtw * 9:
+            return False, 1
+        total = N * segs_x * segs_y
+    tiles = (Cout // 64) * (Cin // 32)
+    split = max(1, min((256 + tiles - 1) // tiles, total))
+    sps = (total + split - 1) // split
+    if sps > segs_y:
+        sps = (sps + segs_y - 1) // segs_y * segs_y
+    split = (total + sps - 1) // sps
+    return tiles * split >= 8, side
+
+
 def wgrad_kernel_for(N, H, W, Cin, Cout):
     """(kernel name, fraction of the algorithmic flops it issues on the matrix pipe) of the stride-1 weight gradient."""
-    if USE_WGRAD_WINO and Cin % 64 == 0 and Cout % 64 == 0 and W >= 48:
-        if USE_WINO4 and USE_WGRAD_WINO4 and W % 4 == 0 and ((W // 4 + 11) // 12) * 12 * 8 <= (W // 4) * 9:
-            if USE_WGRAD_WINO4_16X16:
+    if USE_WGRAD_WINO and Cin % 64 == 0 and Cout % 64 == 0:
+        if USE_WINO4 and USE_WGRAD_WINO4:
+            ok, side = _wg4_plan_ok(N, H, W, Cin, Cout)
+            if ok and side == 1 and USE_WGRAD_WINO4_16X16:
                 return "conv3x3_wgrad_wino4_kernel", 0.5
-            return "conv3x3_wgrad_wino4x_kernel", (0.5 if USE_WGRAD_WINO4_1D else 1.0 / 3.0)
-        if W % 2 == 0 and ((W // 2 + 23) // 24) * 24 * 8 <= (W // 2) * 9:
+            if ok and not USE_WGRAD_WINO4_16X16:     # (rows shorter than a strip - images side by side - exist on the 32x32x2 kernel only)
+                return "conv3x3_wgrad_wino4x_kernel", (0.5 if USE_WGRAD_WINO4_1D else 1.0 / 3.0)
+        if W >= 48 and W % 2 == 0 and ((W // 2 + 23) // 24) * 24 * 8 <= (W // 2) * 9:
             return "conv3x3_wgrad_wino_kernel", 2.0 / 3.0
     return "conv3x3_wgrad_kernel", 1.0
 

@@ -286,6 +286,31 @@ def test_conv3x3_wgrad_all_algorithms(N, H, W, Cin, Cout):
         _close(dw.cpu().double(), 0.5 * dw_ref, 1e-5); _close(db.cpu().double(), 0.5 * db_ref, 1e-5)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(16, 24, 24, 256, 512), (4, 9, 24, 64, 128), (9, 6, 24, 64, 64), (6, 7, 16, 64, 64),
+                                             (4, 12, 12, 128, 64), (12, 5, 8, 64, 64)])
+def test_conv3x3_wgrad_narrow_images_side_by_side(N, H, W, Cin, Cout):
+    """Rows shorter than the transposed-Winograd kernel's 48-pixel strip: 12 / (W / 4) images are laid side by side in one strip
+    (the Discriminator's 24-pixel-wide features.6; an odd image count leaves the last strip half empty).  A pixel's halo must stop
+    at its own image's border - the neighbour in the strip is another image -, odd heights end in a half-empty row pair.  Both
+    transforms (y-nested, 1-D) against the oracle, with and without accumulation; the result must differ in its bits from the
+    direct kernel's (i.e. the shape really ran on the Winograd kernel), and repeat bit-identically."""
+    from pesr_amd import ops
+    assert ops.wgrad_kernel_for(N, H, W, Cin, Cout)[0] == "conv3x3_wgrad_wino4x_kernel"
+    x = _rand(N, Cin, H, W, seed=930); w = _rand(Cout, Cin, 3, 3, seed=931, scale=0.1)
+    dy = _rand(N, Cout, H, W, seed=932)
+    _, dw_ref, db_ref = O.conv3x3_grads(x.double(), w.double(), dy.double())
+    dw_d, _ = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, algo=ops.WGRAD_DIRECT)
+    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO4_1D):
+        dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, algo=algo)
+        _close(dw.cpu().double(), dw_ref, 1e-5); _close(db.cpu().double(), db_ref, 1e-5)
+        assert not torch.equal(dw, dw_d)
+        dw2, db2 = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, algo=algo)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+        acc_w, acc_b = dw.clone(), db.clone()
+        ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, algo=algo, dw_out=acc_w, db_out=acc_b, accumulate=True)
+        _close(acc_w.cpu().double(), 2 * dw_ref, 1e-5); _close(acc_b.cpu().double(), 2 * db_ref, 1e-5)
+
+
 def test_conv3x3_wgrad_winograd4_pixel_shuffle_fused():
     """Weight gradient of an upsampler conv (its output gradient arrives pixel-shuffled) on the F(4,3) kernel."""
     import torch.nn.functional as F
