@@ -286,6 +286,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         if (has1)
 #endif
         stage_store(1, smem);
+#ifdef W4D_EARLY0
+        stage_load(0, CB + (1 < C16 ? 1 : 0));             // item 0 of chunk CB + 1: in flight across the first chunk's first third
+#endif
     }
     __syncthreads();
 #ifdef W4D_NO_BLOAD
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
         // the prefetch under `if (more)` the staging registers and weight fragments had two definitions merging at the loop header,
         // and hipcc could not count the outstanding loads exactly.
         const int cn = CB + (c + 1 < C16 ? c + 1 : c);
-#ifndef W4D_NO_STAGE
+#if !defined(W4D_NO_STAGE) && !defined(W4D_STORE_ONLY) && !defined(W4D_EARLY0)
         stage_load(0, cn);
 #endif
 #ifndef W4D_NO_AREAD
@@ -350,6 +353,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             // A third / two thirds in, the staged loads have landed: transform them into the other V buffer under the MFMAs.
 #ifdef W4D_ILV
             if (s == 2) { stage_load(1, cn); __builtin_amdgcn_sched_barrier(0); }
+#elif defined(W4D_LOAD_ONLY)
+            if (s == 2) { stage_load(1, cn); __builtin_amdgcn_sched_barrier(0); }
+#elif defined(W4D_STORE_ONLY)
+            if (s == 2) { stage_store(0, vnext); __builtin_amdgcn_sched_barrier(0); }
+            if (s == 6) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
+#elif defined(W4D_EARLY0)
+            // item 0 of chunk c + 2 is requested as soon as item 1's store has freed the staging registers (two thirds into chunk c)
+            // and stored a third into chunk c + 1: four ninths of a chunk in flight instead of three
+            if (s == 2) { stage_store(0, vnext); stage_load(1, cn); __builtin_amdgcn_sched_barrier(0); }
+            if (s == W4D_EARLY0) { stage_store(1, vnext); stage_load(0, CB + (c + 2 < C16 ? c + 2 : C16 - 1)); __builtin_amdgcn_sched_barrier(0); }
 #elif !defined(W4D_NO_STAGE)
             if (s == 2) { stage_store(0, vnext); stage_load(1, cn); __builtin_amdgcn_sched_barrier(0); }
             if (s == 6) { stage_store(1, vnext); __builtin_amdgcn_sched_barrier(0); }
