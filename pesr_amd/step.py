@@ -301,19 +301,21 @@ class Trainer:
         self.set_dp_policy(best)
         self.dp_step, chosen, graph_error = eager, best, None
         if graph and tr.capturable:
-            t_graph, err = float("inf"), None
+            fn, err = None, None
             try:
                 lr, hr = next_batch()
                 fn = self.capture_gan_step(lr, hr) if kind == "gan" else self.capture_pretrain_step(lr, hr)
-                t_graph = timed(fn)
             except Exception as e:                      # (decided together below: every rank still takes part in host_max)
                 err = f"{type(e).__name__}: {e}"
-            bad, t_all = tr.host_max([0.0 if err is None else 1.0, t_graph if err is None else 0.0])
+            # Agree on the capture BEFORE anybody replays: a replay runs the captured all-reduces, and a rank whose capture failed
+            # would not be there to take part in them.
+            (bad,) = tr.host_max([0.0 if err is None else 1.0])
             if bad:
                 graph_error = err or "the capture failed on another rank"
                 if self._graph:
                     self._graph.pop(kind, None)
             else:
+                (t_all,) = tr.host_max([timed(fn)])
                 ms["graph+" + best] = t_all
                 if t_all < ms[best]:
                     self.dp_step, chosen = fn, "graph+" + best
