@@ -222,6 +222,16 @@ size_t pesr_bn_workspace_bytes(long M, int C);
 int pesr_bn_lrelu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_invstd,
                       float* running_mean, float* running_var, long long* num_batches, int N, int H, int W, int C, float eps,
                       float momentum, float slope, int y_nchw, void* workspace, size_t ws_bytes, void* stream);
+/* (ABI 14) conv 3 -> C (pad 1, stride 1, NO bias) -> BatchNorm2d(train) -> LeakyReLU in one call, for the layer where the statistics
+ * pass costs most (the Discriminator's features.0, reference model/pesr.py:53 + model/basic.py:26-30: 16 x 192 x 192 x 64): the conv
+ * kernel (that of pesr_conv3x3_rgb_fwd, OIHW weights [C][3][3][3]) leaves per-workgroup sums / sums of squares of its result, the
+ * finalize step reduces them in a fixed order in double - no pass over z for the statistics (SURVEY K10's first half).  Writes z
+ * (the conv output, saved for backward) AND y; everything else as pesr_bn_lrelu_fwd.  C % 4 == 0 and 256 % (C / 4) == 0. */
+size_t pesr_conv3x3_rgb_bn_workspace_bytes(int N, int H, int W, int C);
+int pesr_conv3x3_rgb_bn_lrelu_fwd(const float* x, const float* w, float* z, const float* gamma, const float* beta, float* y,
+                                  float* mean_invstd, float* running_mean, float* running_var, long long* num_batches, int N, int H,
+                                  int W, int C, float eps, float momentum, float slope, int y_nchw, void* workspace, size_t ws_bytes,
+                                  void* stream);
 /* accumulate = 1: dgamma / dbeta are added to instead of overwritten (second use of the layer in one backward pass). */
 int pesr_bn_lrelu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
                       float* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw,

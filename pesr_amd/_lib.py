@@ -69,6 +69,9 @@ SIGNATURES.update({
     "pesr_bn_workspace_bytes": (c_size_t, [c_long, c_int]),
     "pesr_bn_lrelu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                                   c_int, _P, c_size_t, _P]),
+    "pesr_conv3x3_rgb_bn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "pesr_conv3x3_rgb_bn_lrelu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float,
+                                              c_float, c_int, _P, c_size_t, _P]),
     "pesr_bn_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P, c_size_t,
                                   _P]),
     "pesr_bn_lrelu_eval_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),

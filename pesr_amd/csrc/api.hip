@@ -8,7 +8,7 @@ static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 // "n" channel padding of the packed weights: <= 16 channels (the C -> 3 layers) pad to 16, everything else to a multiple of 64
 static inline int pad64(int c) { return c <= 16 ? 16 : (c + 63) / 64 * 64; }
 
-PESR_API int pesr_abi_version(void) { return 13; }
+PESR_API int pesr_abi_version(void) { return 14; }
 
 PESR_API int pesr_pack_conv3x3(const float* w, float* out, int O, int I, int mode, int ps, void* stream) {
     return pesr_pack_conv3x3_launch(w, out, O, I, mode, ps, (hipStream_t)stream);
@@ -99,6 +99,14 @@ PESR_API int pesr_bn_lrelu_fwd(const float* x, const float* gamma, const float* 
                                float eps, float momentum, float slope, int y_nchw, void* workspace, size_t ws_bytes, void* stream) {
     return pesr_bn_lrelu_fwd_launch(x, gamma, beta, y, mean_invstd, running_mean, running_var, num_batches, (long)N * H * W, C,
                                     (long)H * W, eps, momentum, slope, y_nchw, workspace, ws_bytes, (hipStream_t)stream);
+}
+PESR_API size_t pesr_conv3x3_rgb_bn_workspace_bytes(int N, int H, int W, int C) { return pesr_conv_rgb_bn_ws_bytes(N, H, W, C); }
+PESR_API int pesr_conv3x3_rgb_bn_lrelu_fwd(const float* x, const float* w, float* z, const float* gamma, const float* beta, float* y,
+                                           float* mean_invstd, float* running_mean, float* running_var, long long* num_batches, int N,
+                                           int H, int W, int C, float eps, float momentum, float slope, int y_nchw, void* workspace,
+                                           size_t ws_bytes, void* stream) {
+    return pesr_conv_rgb_bn_lrelu_fwd_launch(x, w, z, gamma, beta, y, mean_invstd, running_mean, running_var, num_batches, N, H, W, C, eps,
+                                             momentum, slope, y_nchw, workspace, ws_bytes, (hipStream_t)stream);
 }
 PESR_API int pesr_bn_lrelu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
                                float* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, float slope, int dy_nchw,

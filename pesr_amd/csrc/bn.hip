@@ -193,6 +193,37 @@ int pesr_bn_lrelu_fwd_launch(const float* x, const float* gamma, const float* be
     return pesr_launch_status();
 }
 
+// conv 3 -> C (no bias) -> BatchNorm (training) -> LeakyReLU with the statistics taken from the conv kernel's epilogue (SURVEY K10's
+// first half, for the layer where it pays most: the Discriminator's features.0, 16 x 192 x 192 x 64 = 151 MB): three launches - conv +
+// per-workgroup partial sums, finalize, apply - instead of four, and one pass over z less.  z (saved for backward) and y are both
+// written.  Workspace: pesr_conv_rgb_bn_ws_bytes.
+size_t pesr_conv_rgb_bn_ws_bytes(int N, int H, int W, int C) {
+    const int rows = pesr_conv_rgb_in_stats_rows(N, H, W, C);
+    return rows ? (size_t)rows * 2 * C * sizeof(float) + 512 : 0;
+}
+
+int pesr_conv_rgb_bn_lrelu_fwd_launch(const float* x, const float* w, float* z, const float* gamma, const float* beta, float* y,
+                                      float* mean_invstd, float* running_mean, float* running_var, long long* num_batches, int N, int H,
+                                      int W, int C, float eps, float momentum, float slope, int y_nchw, void* ws, size_t ws_bytes,
+                                      hipStream_t stream) {
+    const int rows = pesr_conv_rgb_in_stats_rows(N, H, W, C);
+    if (!rows) return PESR_EINVAL;
+    if (!ws || ws_bytes < (size_t)rows * 2 * C * sizeof(float)) return PESR_EWORKSPACE;
+    float* part = (float*)ws;
+    int rc = pesr_conv_rgb_in_stats_launch(x, w, z, part, N, H, W, C, stream);
+    if (rc) return rc;
+    const long M = (long)N * H * W, HW = (long)H * W;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, rows, C, M, eps, momentum,
+                       mean_invstd, running_mean, running_var, num_batches);
+    const long total = M * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    long ysn = HW * C, ysc = 1, ysp = C;
+    if (y_nchw) { ysn = HW * C; ysc = HW; ysp = 1; }
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)z, (const float*)mean_invstd, gamma, beta, y, M, C,
+                       slope, HW, ysn, ysc, ysp);
+    return pesr_launch_status();
+}
+
 // backward: dy is the gradient w.r.t. the LeakyReLU output (NHWC, or NCHW when dy_nchw); dgamma/dbeta may be NULL
 int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
                              float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, int accumulate,

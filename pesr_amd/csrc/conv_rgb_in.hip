@@ -16,10 +16,15 @@
 #define RGB_TW 32
 
 // WMODE 0: w is OIHW [C][3][3][3] of this conv.   WMODE 1: w is OIHW [3][C][3][3] of the conv whose input gradient this is.
-template <int ACT, int WMODE>
+// STATS (round 4; the Discriminator's features.0 in front of its BatchNorm, reference model/basic.py:26-30): the workgroup also leaves
+// the per-channel sum and sum of squares of what it stored in part[blockIdx.x][2][C] - the layout of bn_reduce_kernel<0>'s partial
+// rows, so bn_finalize_kernel takes them as they are and the statistics need no pass of their own over the 151 MB result.  A thread
+// adds its (at most a few dozen) pixels in fp32, everything across threads and workgroups is added in double, in a fixed order.
+template <int ACT, int WMODE, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_rgb_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int N, int H,
-                                                          int W, int C, float slope, int tiles_x, int tiles_y) {
+                                                          int W, int C, float slope, int tiles_x, int tiles_y,
+                                                          float* __restrict__ part = nullptr) {
     constexpr int HW_ = RGB_TW + 2, HH_ = RGB_TH + 2;
     __shared__ f32x4 halo[HH_ * HW_];
     const int C4 = C >> 2;
@@ -39,6 +44,7 @@ __global__ __launch_bounds__(256) void conv_rgb_in_kernel(const float* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) br[q] = bias[cg * 4 + q];
     }
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
     const int ntiles = N * tiles_y * tiles_x;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
@@ -78,7 +84,22 @@ __global__ __launch_bounds__(256) void conv_rgb_in_kernel(const float* __restric
                     o[q] = s;
                 }
                 *(f32x4*)(y + (((size_t)n * H + oy) * W + ox) * C + cg * 4) = o;
+                if (STATS) { st1 += o; st2 += o * o; }
             }
+        }
+    }
+    if (STATS) {
+        __shared__ f32x4 sred[2][256];
+        sred[0][threadIdx.x] = st1; sred[1][threadIdx.x] = st2;          // (a thread past the pixel lanes holds zeros)
+        __syncthreads();
+        if (threadIdx.x < C4) {
+            f64x4 d1 = {0.0, 0.0, 0.0, 0.0}, d2 = {0.0, 0.0, 0.0, 0.0};
+            for (int k = 0; k < 256 / C4; ++k) {
+                d1 += __builtin_convertvector(sred[0][k * C4 + cg], f64x4);
+                d2 += __builtin_convertvector(sred[1][k * C4 + cg], f64x4);
+            }
+            f32x4* p = (f32x4*)part + (size_t)blockIdx.x * 2 * C4;
+            p[cg] = __builtin_convertvector(d1, f32x4); p[C4 + cg] = __builtin_convertvector(d2, f32x4);
         }
     }
 }
@@ -100,6 +121,23 @@ static int rgb_in_launch(const float* x, const float* w, const float* bias, floa
 int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
                             float slope, hipStream_t stream) {
     return rgb_in_launch<0>(x, w, bias, y, N, H, W, C, act, slope, stream);
+}
+
+// rows of per-workgroup BatchNorm partials the call below writes ([rows][2][C] floats), 0: shape not covered
+int pesr_conv_rgb_in_stats_rows(int N, int H, int W, int C) {
+    if (C % 4 || C > 1024 || 256 % (C / 4) || N < 1 || H < 1 || W < 1) return 0;
+    const long grid = (long)N * ((W + RGB_TW - 1) / RGB_TW) * ((H + RGB_TH - 1) / RGB_TH);
+    return (int)(grid > 256 * 8 ? 256 * 8 : grid);
+}
+
+// y = conv3x3(x[N][H][W][3], w) (no bias, no activation) + part[rows][2][C] = per-workgroup sums / sums of squares of y
+int pesr_conv_rgb_in_stats_launch(const float* x, const float* w, float* y, float* part, int N, int H, int W, int C, hipStream_t stream) {
+    const int rows = pesr_conv_rgb_in_stats_rows(N, H, W, C);
+    if (!rows || !part) return PESR_EINVAL;
+    const int tiles_x = (W + RGB_TW - 1) / RGB_TW, tiles_y = (H + RGB_TH - 1) / RGB_TH;
+    hipLaunchKernelGGL((conv_rgb_in_kernel<PESR_ACT_NONE, 0, true>), dim3((unsigned)rows), dim3(256), 0, stream, x, w, (const float*)nullptr, y,
+                       N, H, W, C, 0.f, tiles_x, tiles_y, part);
+    return pesr_launch_status();
 }
 
 // dx[N][H][W][C] of y = conv3x3(x, w[3][C][3][3]) given dy[N][H][W][3]

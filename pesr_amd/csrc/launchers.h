@@ -33,6 +33,11 @@ int pesr_maxpool2x2_fwd_launch(const float* x, float* y, int N, int H, int W, in
 int pesr_maxpool2x2_bwd_launch(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int relu_in, hipStream_t stream);
 
 size_t pesr_bn_ws_bytes(long M, int C);
+size_t pesr_conv_rgb_bn_ws_bytes(int N, int H, int W, int C);
+int pesr_conv_rgb_bn_lrelu_fwd_launch(const float* x, const float* w, float* z, const float* gamma, const float* beta, float* y,
+                                      float* mean_invstd, float* running_mean, float* running_var, long long* num_batches, int N, int H,
+                                      int W, int C, float eps, float momentum, float slope, int y_nchw, void* ws, size_t ws_bytes,
+                                      hipStream_t stream);
 int pesr_bn_lrelu_fwd_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean_invstd,
                              float* running_mean, float* running_var, long long* num_batches, long M, int C, long HW, float eps,
                              float momentum, float slope, int y_nchw, void* ws, size_t ws_bytes, hipStream_t stream);
@@ -124,6 +129,9 @@ int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, f
 int pesr_conv_rgb_out_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,
                                  float slope, hipStream_t stream);
 int pesr_conv_rgb_in_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream);
+// the same conv (no bias) leaving BatchNorm partial sums per workgroup: part[rows][2][C] (conv_rgb_in.hip)
+int pesr_conv_rgb_in_stats_rows(int N, int H, int W, int C);
+int pesr_conv_rgb_in_stats_launch(const float* x, const float* w, float* y, float* part, int N, int H, int W, int C, hipStream_t stream);
 int pesr_conv_rgb_out_dgrad_launch(const float* dy, const float* w, float* dx, int N, int H, int W, int C, hipStream_t stream);
 
 int pesr_conv_kxk_fwd_launch(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int Cin, int Cout, int k, int s,

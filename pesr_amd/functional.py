@@ -627,6 +627,13 @@ class ConvBnLReluFn(Function):
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches, cache, stride, eps, momentum,
                 slope, y_nchw, training):
         x = _c(x)
+        if training and bias is None and tuple(weight.shape[2:]) == (3, 3) and ops.conv_rgb_bn_eligible(x.shape[3], weight.shape[0], stride):
+            # the Discriminator's features.0: the statistics come out of the conv kernel's epilogue (no pass over z for them)
+            z, y, stats = ops.conv_rgb_bn_lrelu_fwd(x, weight.detach(), gamma.detach(), beta.detach(), running_mean, running_var,
+                                                    num_batches, eps, momentum, slope, y_nchw)
+            ctx.cache, ctx.stride, ctx.slope, ctx.y_nchw, ctx.training, ctx.bias_ref = cache, stride, slope, y_nchw, training, bias
+            ctx.save_for_backward(x, z, weight, gamma, beta, stats)
+            return y
         z = ops.conv3x3_fwd(x, lambda: cache.for_fwd(weight, x.shape, stride), None if bias is None else bias.detach(), weight.shape[0],
                             stride, w_oihw=weight.detach())
         if training:

@@ -770,6 +770,31 @@ def bn_lrelu_fwd(x, gamma, beta, running_mean, running_var, num_batches, eps=1e-
     return y, stats
 
 
+def conv_rgb_bn_eligible(cin: int, cout: int, stride: int) -> bool:
+    """Shapes of pesr_conv3x3_rgb_bn_lrelu_fwd (3 -> C conv whose kernel also leaves the BatchNorm partial sums)."""
+    return cin == 3 and stride == 1 and cout % 4 == 0 and 256 % (cout // 4) == 0
+
+
+def conv_rgb_bn_lrelu_fwd(x, w_oihw, gamma, beta, running_mean, running_var, num_batches, eps=1e-5, momentum=0.1, slope=0.2,
+                          y_nchw=False):
+    """(z, y, stats): z = conv3x3(x [N,H,W,3], w) without bias, y = act(bn_train(z)); the statistics come out of the conv kernel's
+    epilogue (no pass over z for them)."""
+    _chk(x, "conv_rgb_bn_lrelu_fwd.x"); _chk(w_oihw, "conv_rgb_bn_lrelu_fwd.w")
+    N, H, W, Cin = x.shape
+    C = w_oihw.shape[0]
+    assert tuple(w_oihw.shape) == (C, 3, 3, 3) and conv_rgb_bn_eligible(Cin, C, 1)
+    L = _lib.lib()
+    ws = workspace(L.pesr_conv3x3_rgb_bn_workspace_bytes(N, H, W, C), x.device)
+    z = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    y = torch.empty((N, C, H, W) if y_nchw else (N, H, W, C), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    FLOPS.add(18.0 * N * H * W * Cin * C, 0.0, "rgb (HBM-bound, VALU)")
+    rc = L.pesr_conv3x3_rgb_bn_lrelu_fwd(_p(x), _p(w_oihw), _p(z), _p(gamma), _p(beta), _p(y), _p(stats), _p(running_mean), _p(running_var),
+                                         _p(num_batches), N, H, W, C, eps, momentum, slope, int(y_nchw), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, f"pesr_conv3x3_rgb_bn_lrelu_fwd[{N}x{H}x{W}x3->{C}]")
+    return z, y, stats
+
+
 def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param_grads=True, dgamma_out=None, dbeta_out=None,
                  accumulate=False):
     """accumulate: add to dgamma_out / dbeta_out (which then must be given) instead of overwriting them."""

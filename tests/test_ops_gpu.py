@@ -164,6 +164,34 @@ def test_bn_lrelu(N, C, H, W, nchw):
     _close(_nchw(dx), xr.grad, 5e-5, "bn dx"); _close(dg.cpu(), gr.grad, 5e-5, "dgamma"); _close(db.cpu(), br.grad, 5e-5, "dbeta")
 
 
+@pytest.mark.parametrize("N,H,W,C,nchw", [(16, 192, 192, 64, False), (2, 37, 50, 64, False), (3, 9, 33, 32, True), (1, 8, 32, 256, False)])
+def test_conv_rgb_bn_lrelu_fused_statistics(N, H, W, C, nchw):
+    """The 3 -> C conv whose kernel leaves the BatchNorm partial sums (the Discriminator's features.0, reference model/pesr.py:53 +
+    model/basic.py:26-30; SURVEY K10's statistics half): conv output, statistics, normalised output and running statistics against
+    torch on the CPU in double, and against the two-call path (conv, then bn_lrelu_fwd with its own statistics pass) - the partial
+    sums are fp32 per thread and double from there on, so the two agree far inside the tolerance; run to run the bits repeat."""
+    from pesr_amd import ops
+    x = _rand(N, 3, H, W, seed=11, lo=0, hi=255); w = _rand(C, 3, 3, 3, seed=12, lo=-0.2, hi=0.2)
+    gamma = _rand(C, seed=13, lo=0.5, hi=1.5); beta = _rand(C, seed=14, lo=-0.3, hi=0.3)
+    zr = F.conv2d(x.double(), w.double(), None, 1, 1)
+    rm = torch.zeros(C, dtype=torch.double); rv = torch.ones(C, dtype=torch.double)
+    ref = F.leaky_relu(F.batch_norm(zr, rm, rv, gamma.double(), beta.double(), True, 0.1, 1e-5), 0.2)
+    rmg = torch.zeros(C).cuda(); rvg = torch.ones(C).cuda(); nb = torch.zeros((), dtype=torch.long).cuda()
+    z, y, stats = ops.conv_rgb_bn_lrelu_fwd(_nhwc(x), w.cuda(), gamma.cuda(), beta.cuda(), rmg, rvg, nb, y_nchw=nchw)
+    _close(_nchw(z).double(), zr, 1e-5, "conv")
+    _close((y.cpu() if nchw else _nchw(y)).double(), ref, 2e-5, "bn(conv)")
+    _close(rmg.cpu().double(), rm, 1e-5, "running_mean"); _close(rvg.cpu().double(), rv, 1e-4, "running_var"); assert int(nb) == 1
+    mean = zr.mean((0, 2, 3)); var = zr.var((0, 2, 3), unbiased=False)
+    _close(stats[0].cpu().double(), mean, 1e-6, "mean"); _close(stats[1].cpu().double(), 1.0 / torch.sqrt(var + 1e-5), 1e-5, "invstd")
+    # the two-call path on the same z
+    rm2 = torch.zeros(C).cuda(); rv2 = torch.ones(C).cuda(); nb2 = torch.zeros((), dtype=torch.long).cuda()
+    y2, stats2 = ops.bn_lrelu_fwd(z, gamma.cuda(), beta.cuda(), rm2, rv2, nb2, y_nchw=nchw)
+    _close(stats.cpu(), stats2.cpu(), 1e-6, "statistics vs the stand-alone pass"); _close(y.cpu(), y2.cpu(), 1e-6, "y vs the two-call path")
+    z3, y3, stats3 = ops.conv_rgb_bn_lrelu_fwd(_nhwc(x), w.cuda(), gamma.cuda(), beta.cuda(), torch.zeros(C).cuda(), torch.ones(C).cuda(),
+                                               torch.zeros((), dtype=torch.long).cuda(), y_nchw=nchw)
+    assert torch.equal(y, y3) and torch.equal(stats, stats3) and torch.equal(z, z3)
+
+
 @pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (3, 70, 1000), (16, 1024, 73728), (70, 96, 2048)])
 def test_linear(M, N, K):
     """(70 rows: more than one 32-row kernel call - a per-GPU batch of 64 must not abort in D's classifier.)"""
