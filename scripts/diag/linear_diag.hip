@@ -1,0 +1,370 @@
+// DIAGNOSTIC copy of pesr_amd/csrc/linear.hip with the LDS-DMA staged forward (linear_fwd_dma_kernel) that round 4 built and measured SLOWER
+// (106 us against 88 - 97 us for the register form at 16 x 73728 -> 1024: one 80 KiB stage in flight per CU does not cover the latency of a
+// whole-chip burst; profiles/r04_ab_notes.txt).  scripts/build_variant.sh <name> linear_diag.hip links it in place of the product object.
+// Skinny-batch Linear for the Discriminator's classifier (reference model/pesr.py:69-74: Linear(73728, 1024)
+// -> LeakyReLU(0.2) -> Linear(1024, 1); ATen addmm / mm in forward and backward).  M (batch) <= 32.
+// All three passes are HBM-bound on the 302 MB weight matrix, which each streams exactly once:
+//   fwd  : y[m][n]  = act(sum_k x[m][k] W[n][k] + b[n])     split-K partials (MFMA for M <= 16) + fixed-order finalize
+//   dgrad: dx[m][k] = sum_n dy[m][n] W[n][k]                 split-N partials + fixed-order finalize
+//   wgrad: dW[n][k] = sum_m dy[m][n] x[m][k],  db[n] = sum_m dy[m][n]
+#include <mutex>
+#include "common.h"
+#include "launchers.h"
+
+#define LIN_MAXM 32
+
+// ---- forward -----------------------------------------------------------------------------------
+// one wave: NR consecutive output features, one K slice; lanes stride over K with float4 loads.
+template <int MB, int NR>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         float* __restrict__ part, int M, int N, long K, int ksplit, long kchunk) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int ngroups = (N + NR - 1) / NR;
+    const int ng = wave % ngroups, ks = wave / ngroups;
+    if (ks >= ksplit) return;
+    const int n0 = ng * NR;
+    const long k0 = ks * kchunk;
+    long k1 = k0 + kchunk; if (k1 > K) k1 = K;
+    float acc[NR][MB];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+    for (long k = k0 + lane * 4; k < k1; k += 256) {
+        f32x4 w[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) w[r] = (n0 + r < N) ? *(const f32x4*)(W + (size_t)(n0 + r) * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m < M) {
+                const f32x4 xv = *(const f32x4*)(x + (size_t)m * K + k);
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    acc[r][m] = fmaf(w[r].w, xv.w, fmaf(w[r].z, xv.z, fmaf(w[r].y, xv.y, fmaf(w[r].x, xv.x, acc[r][m]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float s = wave_sum(acc[r][m]);
+            if (lane == 0 && m < M && n0 + r < N) part[((size_t)ks * M + m) * N + n0 + r] = s;
+        }
+}
+// M <= 16: the batch IS an MFMA dimension.  One wave owns NB x 16 output features and one K slice; per 16-k step every
+// lane loads ONE 16-byte piece of x (row lane%16, k-slot lane/16) and NB pieces of W, and element e of the pieces feeds
+// MFMA k-step e (k-slot g of step e stands for k = k0 + 4g + e).  The x slice is thus read once per NB*16 features
+// (75 MB of L2 traffic for the 73728 -> 1024 layer instead of 600 MB with one feature row per lane group), and the
+// 302 MB weight matrix streams exactly once.  D tile: row m = 4*(lane/16) + reg, col n = lane%16.
+template <int NB>
+__global__ __launch_bounds__(256) void linear_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                              float* __restrict__ part, int M, int N, long K, int ksplit, long kchunk) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const int ngroups = (N + 16 * NB - 1) / (16 * NB);
+    const int ng = wave % ngroups, ks = wave / ngroups;
+    if (ks >= ksplit) return;
+    const int n0 = ng * 16 * NB;
+    const long k0 = ks * kchunk;
+    long k1 = k0 + kchunk; if (k1 > K) k1 = K;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float* xr = x + (size_t)(i < M ? i : 0) * K;
+    const float* wr[NB];
+    bool wok[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { const int n = n0 + b * 16 + i; wok[b] = n < N; wr[b] = W + (size_t)(wok[b] ? n : 0) * K; }
+    const bool xok = i < M;
+    // LU 16-k steps per trip, all their loads issued before the first MFMA (the two 64-byte halves of every 128-byte line of W
+    // are then in flight together): LU * (NB + 1) KiB per wave
+    constexpr int LU = 2;
+    for (long k = k0 + 4 * g; k < k1 + 4 * g; k += 16 * LU) {   // uniform trip count; a lane's piece may lie past k1
+        f32x4 a[LU], w[LU][NB];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const long ku = k + 16 * u;
+            const bool in = ku < k1;
+            a[u] = (xok && in) ? *(const f32x4*)(xr + ku) : zero;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) w[u][b] = (wok[b] && in) ? __builtin_nontemporal_load((const f32x4*)(wr[b] + ku)) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], w[u][b][e], acc[b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = 4 * g + jj, n = n0 + b * 16 + i;
+            if (m < M && n < N) part[((size_t)ks * M + m) * N + n] = acc[b][jj];
+        }
+}
+// Round 4: the same forward with the weights staged global -> LDS by LDS-DMA (M <= 16, N % 64 == 0, K % 256 == 0: the
+// Discriminator's 73728 -> 1024).  The register form above keeps 16 rows x 64 bytes per load instruction in flight and stays at
+// 3.0 - 3.4 TB/s; here a stage is a 64-row x 256-k tile of W (64 KiB) plus the 16 x 256 slice of x, every DMA instruction moves ONE
+// KiB of ONE row (fully coalesced, no VGPRs), and the next stage's 80 KiB are in flight while the current one feeds the MFMAs.
+// LDS rows are 1 KiB with no padding: the 16-byte piece p of row r lives in slot p ^ (r & 15) - the DMA lane that owns slot l
+// fetches piece l ^ (r & 15) -, so the 16 lanes of a fragment read (16 rows, the same piece) touch 16 different bank groups.
+// One workgroup = 4 waves = the tile's four 16-row blocks; grid = (N / 64) x ksplit with 256 workgroups in all.
+constexpr int LF_KT = 256;                         // k per stage
+constexpr int LF_W_BYTES = 64 * LF_KT * 4, LF_X_BYTES = 16 * LF_KT * 4, LF_STAGE_BYTES = LF_W_BYTES + LF_X_BYTES;
+__device__ __forceinline__ void lf_dma16(const float* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__global__ __launch_bounds__(256) void linear_fwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                             float* __restrict__ part, int M, int N, long K, int stages_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char lf_lds[];      // [2][W tile 64 KiB | x tile 16 KiB]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int n_tiles = N / 64;
+    const int nt = blockIdx.x % n_tiles, ks = blockIdx.x / n_tiles;
+    const int n0 = nt * 64;
+    const int total = (int)(K / LF_KT);
+    const int s0 = ks * stages_per_split;
+    int s1 = s0 + stages_per_split; if (s1 > total) s1 = total;
+    if (s0 >= s1) return;
+    // DMA roles: wave w moves rows 16w .. 16w+15 of the W tile (16 instructions) and rows 4w .. 4w+3 of the x tile (4)
+    auto dma = [&](int stage, int buf) {
+        char* const wb = lf_lds + buf * LF_STAGE_BYTES;
+        const long k0 = (long)stage * LF_KT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 16 + r;
+            lf_dma16(W + (size_t)(n0 + row) * K + k0 + 4 * (lane ^ (row & 15)), wb + row * (LF_KT * 4));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 4 + r;
+            const int src = row < M ? row : 0;               // (rows past the batch: any valid row, zeroed at the fragment)
+            lf_dma16(x + (size_t)src * K + k0 + 4 * (lane ^ (row & 15)), wb + LF_W_BYTES + row * (LF_KT * 4));
+        }
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool xok = i < M;
+    dma(s0, 0);
+#pragma unroll 1
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        if (s + 1 < s1) {
+            dma(s + 1, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // this stage's 20 DMA instructions of this wave have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                          // ... and every other wave's
+        const char* const wt = lf_lds + buf * LF_STAGE_BYTES + (wave * 16 + i) * (LF_KT * 4);
+        const char* const xt = lf_lds + buf * LF_STAGE_BYTES + LF_W_BYTES + i * (LF_KT * 4);
+#pragma unroll
+        for (int st = 0; st < LF_KT / 16; ++st) {
+            const int slot = ((4 * st + g) ^ i) * 16;
+            const f32x4 wv = *(const f32x4*)(wt + slot);
+            f32x4 xv = *(const f32x4*)(xt + slot);
+            if (!xok) xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[e], wv[e], acc, 0, 0, 0);
+        }
+        __syncthreads();                                          // the buffer is free for the stage after next
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int m = 4 * g + jj, n = n0 + wave * 16 + i;
+        if (m < M) part[((size_t)ks * M + m) * N + n] = acc[jj];
+    }
+}
+__global__ void linear_fwd_final_kernel(const float* __restrict__ part, const float* __restrict__ b, float* __restrict__ y, int M,
+                                        int N, int ksplit, int act, float slope) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * N) return;
+    // the partials are added in slice order (fixed), but loaded sixteen at a time: as a rolled loop its 128 dependent
+    // load -> add steps took 32 us for 16 K outputs
+    float s = 0.f;
+    int k = 0;
+    for (; k + 16 <= ksplit; k += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(k + u) * M * N + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; k < ksplit; ++k) s += part[(size_t)k * M * N + e];
+    if (b) s += b[e % N];
+    if (act == PESR_ACT_LRELU) s = s > 0.f ? s : s * slope;
+    else if (act == PESR_ACT_RELU) s = s > 0.f ? s : 0.f;
+    y[e] = s;
+}
+
+// ---- dgrad -------------------------------------------------------------------------------------
+// thread: 4 consecutive k, all M rows; loops over an N slice; dy values are wave-uniform (scalar loads).
+constexpr int LD_BT = 256;        // threads per block of the input-gradient kernel
+constexpr int LD_U = 4;           // weight rows in flight per step (8: 134 / 124 us, 16: 146 / 149 against 111 / 101; profiles/r03_linear_sweep.txt)
+template <int MB>
+__global__ __launch_bounds__(LD_BT) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                             float* __restrict__ part, int M, int N, long K, int nchunk) {
+    const long k = ((long)blockIdx.x * LD_BT + threadIdx.x) * 4;
+    const int ns = blockIdx.y;
+    const int n0 = ns * nchunk;
+    int n1 = n0 + nchunk; if (n1 > N) n1 = N;
+    if (k >= K) return;
+    f32x4 acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // LD_U weight rows per step, all their 16-byte loads issued before the first FMA.  Round-3 sweep on one box (back-to-back /
+    // after a 512 MB flush): LD_U 4: 111 / 101 us, 8: 134 / 124, 16: 146 / 149 (round 2 had measured 8 as 106 on its box); 64- /
+    // 512- / 1024-thread blocks slower.  A one-launch form (a workgroup owns 256 k for ALL rows, its waves split N and meet in
+    // LDS: no partial slabs, no finalize launch, 302 instead of 457 MB moved) measured 131 - 234 us in four variants: with 4.5 - 9
+    // waves per CU it keeps too few loads in flight; this split-N form runs 16 waves per CU.
+    constexpr int U = LD_U;
+    int n = n0;
+    for (; n + U <= n1; n += U) {
+        f32x4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load((const f32x4*)(W + (size_t)(n + u) * K + k));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                if (m < M) acc[m] += w[u] * dy[(size_t)m * N + n + u];
+    }
+    for (; n < n1; ++n) {
+        const f32x4 w = *(const f32x4*)(W + (size_t)n * K + k);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m < M) acc[m] += w * dy[(size_t)m * N + n];
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+        if (m < M) *(f32x4*)(part + ((size_t)ns * M + m) * K + k) = acc[m];
+}
+// finalize: dx = sum over N-slices; the LeakyReLU derivative of the layer below is applied by its own backward
+__global__ void linear_dgrad_final_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dx, long MK4, int nsplit) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < MK4; e += (long)gridDim.x * blockDim.x) {
+        f32x4 s = part[e];
+        for (int k = 1; k < nsplit; ++k) s += part[(size_t)k * MK4 + e];
+        dx[e] = s;
+    }
+}
+
+// ---- wgrad -------------------------------------------------------------------------------------
+// thread: 4 consecutive k with x[0..M)[k4] held in registers; loops over an N slice writing dW rows.
+template <int MB>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dW, int M, int N, long K, int nchunk, int accumulate) {
+    const long k = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int n0 = blockIdx.y * nchunk;
+    int n1 = n0 + nchunk; if (n1 > N) n1 = N;
+    if (k >= K) return;
+    f32x4 xv[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) xv[m] = m < M ? *(const f32x4*)(x + (size_t)m * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = n0; n < n1; ++n) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m < M) s += xv[m] * dy[(size_t)m * N + n];
+        // (non-temporal: the 302 MB stream is written once and not re-read by this kernel - 88 -> 78 us)
+        if (accumulate) s += __builtin_nontemporal_load((const f32x4*)(dW + (size_t)n * K + k));   // dW += ... : a second use of the layer in one backward
+        __builtin_nontemporal_store(s, (f32x4*)(dW + (size_t)n * K + k));
+    }
+}
+__global__ void linear_bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
+    db[n] = accumulate ? db[n] + s : s;
+}
+
+namespace {
+struct LinPlan { int ksplit; long kchunk; int nsplit, nchunk; };
+static void lin_plan(int M, int N, long K, LinPlan* p) {
+    // forward: M <= 16: waves = ceil(N/64) * ksplit ~ 2048 (more waves or deeper unrolling measured slower), K slices in multiples of 16 (MFMA kernel);
+    //          M  > 16: waves = ceil(N/2) * ksplit ~ 4096, K slices in multiples of 256 (lane-strided kernel)
+    if (M <= 16) {
+        const int ngroups = (N + 63) / 64;
+        int ks = 2048 / ngroups; if (ks < 1) ks = 1;
+        long kc = ((K + ks - 1) / ks + 15) / 16 * 16;
+        if (kc < 64) kc = 64;
+        p->kchunk = kc; p->ksplit = (int)((K + kc - 1) / kc);
+    } else {
+        const int ngroups = (N + 1) / 2;
+        int ks = 4096 / ngroups; if (ks < 1) ks = 1;
+        long kc = ((K + ks - 1) / ks + 255) / 256 * 256;
+        if (kc < 256) kc = 256;
+        p->kchunk = kc; p->ksplit = (int)((K + kc - 1) / kc);
+    }
+    // dgrad: one-wave blocks, ceil(K/256) * nsplit ~ 1024 of them (every N slice writes an M x K partial: keep them few)
+    const long kb = (K + 4 * LD_BT - 1) / (4 * LD_BT);
+    constexpr int LD_NS_TARGET = 1024, LD_NS_MAX = 16;    // (the 16 x 4 point of the sweep in profiles/r03_linear_sweep.txt)
+    int ns = (int)((LD_NS_TARGET * 256 / LD_BT + kb - 1) / kb); if (ns < 1) ns = 1; if (ns > N) ns = N; if (ns > LD_NS_MAX) ns = LD_NS_MAX;
+    p->nchunk = (N + ns - 1) / ns; p->nsplit = (N + p->nchunk - 1) / p->nchunk;
+    (void)M;
+}
+}  // namespace
+
+size_t pesr_linear_ws_bytes(int M, int N, long K) {
+    LinPlan p; lin_plan(M, N, K, &p);
+    const size_t a = (size_t)p.ksplit * M * N * sizeof(float);
+    const size_t b = (size_t)p.nsplit * M * K * sizeof(float);
+    return a > b ? a : b;
+}
+
+int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float* y, int M, int N, long K, int act, float slope,
+                           void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
+    LinPlan p; lin_plan(M, N, K, &p);
+    if (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float)) return PESR_EWORKSPACE;
+    if (M <= 16 && N % 64 == 0 && K % LF_KT == 0 && (N / 64) * 8 <= 256 && K / LF_KT >= 64) {
+        // LDS-DMA form: (N / 64) x ksplit = 256 workgroups, whole stages per slice (its ksplit never exceeds the plan's: the
+        // workspace covers it)
+        const int n_tiles = N / 64, total = (int)(K / LF_KT);
+        int ks = 256 / n_tiles; if (ks > total) ks = total;
+        const int sps = (total + ks - 1) / ks;
+        ks = (total + sps - 1) / sps;
+        if (ks > p.ksplit) return PESR_EWORKSPACE;
+        static PesrDeviceOnce attr_once;
+        attr_once([&] { (void)hipFuncSetAttribute((const void*)linear_fwd_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_STAGE_BYTES); });
+        hipLaunchKernelGGL(linear_fwd_dma_kernel, dim3(n_tiles * ks), dim3(256), 2 * LF_STAGE_BYTES, stream, x, W, (float*)ws, M, N, K, sps);
+        hipLaunchKernelGGL(linear_fwd_final_kernel, dim3((M * N + 63) / 64), dim3(64), 0, stream, (const float*)ws, b, y, M, N, ks, act, slope);
+        return pesr_launch_status();
+    }
+    if (M <= 16) {
+        const long waves = (long)((N + 63) / 64) * p.ksplit;
+        hipLaunchKernelGGL(linear_fwd_mfma_kernel<4>, dim3((int)((waves + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+    } else
+        hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), dim3((int)(((long)((N + 1) / 2) * p.ksplit + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+    hipLaunchKernelGGL(linear_fwd_final_kernel, dim3((M * N + 63) / 64), dim3(64), 0, stream, (const float*)ws, b, y, M, N, p.ksplit, act, slope);
+    return pesr_launch_status();
+}
+
+int pesr_linear_dgrad_launch(const float* dy, const float* W, float* dx, int M, int N, long K, void* ws, size_t ws_bytes,
+                             hipStream_t stream) {
+    if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
+    LinPlan p; lin_plan(M, N, K, &p);
+    if (!ws || ws_bytes < (size_t)p.nsplit * M * K * sizeof(float)) return PESR_EWORKSPACE;
+    const dim3 grid((unsigned)((K / 4 + LD_BT - 1) / LD_BT), (unsigned)p.nsplit);
+    if (M <= 16) hipLaunchKernelGGL(linear_dgrad_kernel<16>, grid, dim3(LD_BT), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
+    else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(LD_BT), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
+    const long MK4 = (long)M * K / 4;
+    hipLaunchKernelGGL(linear_dgrad_final_kernel, dim3((unsigned)((MK4 + 255) / 256 < 4096 ? (MK4 + 255) / 256 : 4096)), dim3(256), 0, stream,
+                       (const f32x4*)ws, (f32x4*)dx, MK4, p.nsplit);
+    return pesr_launch_status();
+}
+
+int pesr_linear_wgrad_launch(const float* dy, const float* x, float* dW, float* db, int M, int N, long K, int accumulate,
+                             hipStream_t stream) {
+    if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
+    int nchunk = 64; if (nchunk > N) nchunk = N;
+    const dim3 grid((unsigned)((K / 4 + 255) / 256), (unsigned)((N + nchunk - 1) / nchunk));
+    if (M <= 16) hipLaunchKernelGGL(linear_wgrad_kernel<16>, grid, dim3(256), 0, stream, dy, x, dW, M, N, K, nchunk, accumulate);
+    else hipLaunchKernelGGL(linear_wgrad_kernel<32>, grid, dim3(256), 0, stream, dy, x, dW, M, N, K, nchunk, accumulate);
+    if (db) hipLaunchKernelGGL(linear_bgrad_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dy, db, M, N, accumulate);
+    return pesr_launch_status();
+}
