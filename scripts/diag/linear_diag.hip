@@ -1,5 +1,5 @@
 // DIAGNOSTIC copy of pesr_amd/csrc/linear.hip with the LDS-DMA staged forward (linear_fwd_dma_kernel) that round 4 built and measured SLOWER
-// (106 us against 88 - 97 us for the register form at 16 x 73728 -> 1024: one 80 KiB stage in flight per CU does not cover the latency of a
+// (106 us against 96 - 101 us for the register form at 16 x 73728 -> 1024: one 80 KiB stage in flight per CU does not cover the latency of a
 // whole-chip burst; profiles/r04_ab_notes.txt).  scripts/build_variant.sh <name> linear_diag.hip links it in place of the product object.
 // Skinny-batch Linear for the Discriminator's classifier (reference model/pesr.py:69-74: Linear(73728, 1024)
 // -> LeakyReLU(0.2) -> Linear(1024, 1); ATen addmm / mm in forward and backward).  M (batch) <= 32.
