@@ -298,6 +298,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     { char* const vcur = smem; W4_READ_A(fa[0], vcur, 0, 0, 0) W4_READ_A(fa[1], vcur, 0, 0, 1) }
 #endif
 
+#ifdef W4D_CLOCK
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll 1
     for (int c = 0; c < C16; ++c) {
         char* const vcur = smem + (c & 1) * v_bytes;      // (TXTC: the fragment offsets carry the buffer, moved below)
@@ -377,6 +380,12 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     }
 #undef W4_READ_A
 #undef W4_MFMA
+#ifdef W4D_CLOCK   /* shader-clock and 100 MHz real-time ticks of the main loop, per workgroup (wave 0), into the otherwise unused split-K slab */
+    if (tid == 0 && a.slab && a.ksplit == 1) {
+        ((unsigned long long*)a.slab)[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - clk_t0;
+        ((unsigned long long*)a.slab)[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
 #ifdef W4D_MFMA32
 #pragma unroll
     for (int j = 0; j < 6; ++j)

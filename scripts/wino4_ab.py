@@ -9,7 +9,7 @@ sys.path.insert(0, R)
 from pesr_amd import _lib
 what = "fwd"
 args = sys.argv[1:]
-if args and args[0] in ("fwd", "skip", "mask", "both", "wgrad", "wgrad1d", "wgrad16"):
+if args and args[0] in ("fwd", "skip", "mask", "both", "wgrad", "wgrad1d", "wgrad16", "clock"):
     what = args.pop(0)
 libs = args
 N, H, W, C = 16, 48, 48, 256
@@ -46,6 +46,22 @@ def run(l, iters=20):
         assert rc == 0, rc
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
+if what == "clock":   # diagnostic builds with -DW4D_CLOCK: in-kernel shader clock of the forward kernel's main loop (bias + ReLU)
+    import numpy as np
+    clk = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+    for p, l in zip(libs, handles):
+        for it in range(60):
+            rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1.0, 1, 0.0, 0, 0,
+                                      clk.data_ptr(), clk.numel() * 8, s)
+            assert rc == 0
+        torch.cuda.synchronize()
+        c = clk[:512].cpu().numpy().reshape(256, 2).astype(np.float64)
+        ok = c[:, 1] > 0
+        ghz = c[ok, 0] / c[ok, 1] * 0.1
+        us = c[ok, 1] / 100.0
+        print(f"{p:34s} main loop: {np.median(us):7.1f} us (real-time counter), shader clock median {np.median(ghz):.3f} GHz (min {ghz.min():.3f} max {ghz.max():.3f}) over {int(ok.sum())} workgroups")
+        clk.zero_()
+    sys.exit(0)
 for l in handles: run(l, 5)
 res = {p: [] for p in libs}
 for rnd in range(6):
