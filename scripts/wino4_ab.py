@@ -49,8 +49,9 @@ def run(l, iters=20):
 if what == "clock":   # diagnostic builds with -DW4D_CLOCK: in-kernel shader clock of the forward kernel's main loop (bias + ReLU)
     import numpy as np
     clk = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+    n_launch = int(os.environ.get("W4_CLOCK_LAUNCHES", "60"))     # 60: a 10 ms burst; 3000: half a second of sustained load (the stamps of the LAST launch are read)
     for p, l in zip(libs, handles):
-        for it in range(60):
+        for it in range(n_launch):
             rc = l.pesr_conv3x3_wino4(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 1.0, 1, 0.0, 0, 0,
                                       clk.data_ptr(), clk.numel() * 8, s)
             assert rc == 0
