@@ -31,6 +31,18 @@ def vgg_sd(seed=2):
     return OM.set_meanshift(sd, "V")
 
 
+def x8_toy_model(weight_seed, bias_seed, device=None):
+    """The toy "model" of golden GV10 (tests/golden/make_golden_plumbing.py): an asymmetric 3x3 conv 3 -> 12 + PixelShuffle(2),
+    NOT equivariant under flips / transposes.  Weights are multiples of 1/8 in [-1, 1] and inputs are integers 0..255, so every
+    sum is exact in fp32 and the result is the same bits on any device and in any summation order."""
+    import torch.nn.functional as F
+    w = torch.round(detrand.uniform((12, 3, 3, 3), int(weight_seed), -1.0, 1.0) * 8) / 8
+    b = torch.round(detrand.uniform((12,), int(bias_seed), -1.0, 1.0) * 8) / 8
+    if device is not None:
+        w, b = w.to(device), b.to(device)
+    return lambda x: F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2)
+
+
 def close(a, b, rtol=1e-6, atol=0.0, what=""):
     a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
     b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, dtype=np.float64)

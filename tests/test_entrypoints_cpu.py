@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden
+from helpers import load_golden, x8_toy_model
 from oracle import detrand
 from oracle import image as OI
 
@@ -52,6 +52,53 @@ def test_x8_self_ensemble_matches_reference_semantics_gv10():
     # an equivariant model is a fixed point of the ensemble
     ident = lambda x: x * 2.0                              # noqa: E731
     assert torch.allclose(T.x8_forward(img, ident), img * 2.0)
+
+
+def test_oracle_and_product_x8_pinned_by_the_reference_gv10():
+    """GV10 = outputs of the reference's OWN x8_forward (reference test.py:45-74, imported by tests/golden/make_golden_plumbing.py)
+    on a non-equivariant toy model with exact fp32 arithmetic: the oracle's restatement and the product's test.py reproduce them
+    bit for bit."""
+    T = _load("test")
+    g = load_golden("gv10_x8")
+    model = x8_toy_model(g["weight_seed"], g["bias_seed"])
+    with torch.no_grad():
+        for i, (shape, seed) in enumerate(zip(g["shapes"], g["seeds"])):
+            img = detrand.image_batch(tuple(int(v) for v in shape), int(seed))
+            want = torch.from_numpy(g[f"out{i}"])
+            assert (want - model(img)).abs().max() > 1.0          # the ensemble differs from a plain forward: a wrong inverse shows
+            assert torch.equal(OI.x8_forward(img, model), want), f"oracle x8, case {i}"
+            assert torch.equal(T.x8_forward(img, model), want), f"product x8, case {i}"
+
+
+def _gv12_cases():
+    g = load_golden("gv12_crop_aug")
+    images = {}
+    for n, (ih, iw, ps, s_lr, s_hr, seed, is_random, y, x, aug) in enumerate(g["cases"].tolist()):
+        if (s_lr, s_hr) not in images:
+            mk = lambda h, w, s: detrand.image_batch((1, 3, h, w), s)[0].permute(1, 2, 0).contiguous().numpy().astype(np.uint8)  # noqa: E731
+            images[(s_lr, s_hr)] = (mk(ih, iw, s_lr), mk(4 * ih, 4 * iw, s_hr))
+        inp, lbl = images[(s_lr, s_hr)]
+        yield n, inp, lbl, ps, seed, is_random, y, x, aug, torch.from_numpy(g[f"inp{n}"]).float(), torch.from_numpy(g[f"lbl{n}"]).float()
+
+
+def test_oracle_and_product_crop_augment_pinned_by_the_reference_gv12():
+    """GV12 = outputs of the reference's OWN SRDataset._crop / _aug_data / _to_tensor (reference data.py:79-126) under
+    random.seed(s): all 8 aug_idx values, crops on every image edge, both crop types, image sizes that are multiples of nothing.
+    The oracle's explicit-draw restatement and the product's data.py helpers reproduce them bit for bit."""
+    import random
+    D = _load("data")
+    augs, n_cases = set(), 0
+    for n, inp, lbl, ps, seed, is_random, y, x, aug, want_lr, want_hr in _gv12_cases():
+        random.seed(seed)                                   # the stored draws ARE what this seed draws (the reference's call order)
+        if is_random:
+            assert (random.randint(0, inp.shape[0] - ps), random.randint(0, inp.shape[1] - ps)) == (y, x)
+        assert random.randint(0, 7) == aug
+        got_lr, got_hr = OI.crop_augment(inp, lbl, ps, y, x, aug)
+        assert got_lr.dtype == torch.float32 and torch.equal(got_lr, want_lr) and torch.equal(got_hr, want_hr), f"oracle, case {n}"
+        pl, ph = D.augment(inp[y:y + ps, x:x + ps], lbl[4 * y:4 * (y + ps), 4 * x:4 * (x + ps)], aug)
+        assert torch.equal(D.to_tensor(pl), want_lr) and torch.equal(D.to_tensor(ph), want_hr), f"product data.py, case {n}"
+        augs.add(aug); n_cases += 1
+    assert augs == set(range(8)) and n_cases >= 40
 
 
 def test_data_augment_and_shapes():

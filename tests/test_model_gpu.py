@@ -224,6 +224,56 @@ def test_generator_ragged_image_and_x8_ensemble():
         close(ens, ens_ref, 1e-5, 2e-3, "x8 ensemble")
 
 
+def test_x8_ensemble_on_device_vs_the_reference_fixture_gv10():
+    """test.py's device-side x8 self-ensemble against golden GV10: outputs of the reference's OWN x8_forward (reference
+    test.py:45-74) on a non-equivariant toy model whose arithmetic is exact in fp32 - bit for bit."""
+    import importlib.util, os
+    from helpers import x8_toy_model
+    spec = importlib.util.spec_from_file_location("entry_test", os.path.join(os.path.dirname(os.path.dirname(__file__)), "test.py"))
+    T = importlib.util.module_from_spec(spec); spec.loader.exec_module(T)
+    g = load_golden("gv10_x8")
+    model = x8_toy_model(g["weight_seed"], g["bias_seed"], "cuda")
+    with torch.no_grad():
+        for i, (shape, seed) in enumerate(zip(g["shapes"], g["seeds"])):
+            img = detrand.image_batch(tuple(int(v) for v in shape), int(seed)).cuda()
+            out = T.x8_forward(img, model)
+            assert out.is_cuda and torch.equal(out.cpu(), torch.from_numpy(g[f"out{i}"])), i
+
+
+def test_gv2c_generator_full_batch1():
+    """Reference Generator 256 ch x 32 blocks (model/pesr.py:28-38) at [1,3,48,48] -> [1,3,192,192] - the shape of reference
+    test.py:100-106 / BASELINE config 1.  At batch 1 the body layers have 16 pixel tiles: they run on the
+    small-layer dispatch (split-K / direct kernels), which no batch-2 or batch-16 golden reaches."""
+    from pesr_amd import functional as PF
+    from pesr_amd.model.basic import nhwc
+    g = load_golden("gv2c_generator_full_b1")
+    G = _G(256, 32, gen_sd(256, 32))
+    lr = detrand.image_batch((1, 3, 48, 48), 1234).cuda()
+    hr = detrand.image_batch((1, 3, 192, 192), 1235).cuda()
+    with torch.no_grad():
+        sr0 = G(lr)                                           # the inference call of test.py
+    sr = G(lr)
+    assert torch.equal(sr0, sr.detach())
+    flat = sr.contiguous().reshape(-1)
+    idx = torch.from_numpy(g["sr_idx"]).cuda()
+    close(flat[idx], g["sr_val"], 1e-5, 2e-3, "sr samples")
+    close(flat[idx], g["sr_val64"], 1e-5, 2e-3, "sr samples vs fp64")
+    close(sr.sum(), g["sr_sum"], 1e-5, what="sr sum")
+    close(sr.abs().sum(), g["sr_abs_sum"], 1e-5, what="sr abs sum")
+    loss = PF.l1_loss(nhwc(sr), nhwc(hr.contiguous(memory_format=torch.channels_last)))
+    close(loss, g["loss"], 1e-5, what="l1")
+    loss.backward()
+    params = dict(G.named_parameters())
+    errs = {}
+    for key in [k[5:] for k in g.files if k.startswith("gidx.")]:
+        gr = params[key].grad.reshape(-1)[torch.from_numpy(g["gidx." + key]).cuda()]
+        close(gr, g["gval." + key], 0.0, 1e-4 * float(g["gmax." + key]), "grad " + key)          # SURVEY 8c's bar
+        errs[key] = float((gr.double().cpu() - torch.from_numpy(g["g64." + key])).abs().max()) / float(g["gmax64." + key])
+    worst = max(errs, key=errs.get)
+    print(f"GV2c: worst gradient error vs fp64 {errs[worst]:.2e} ({worst}); the reference's own fp32: {float(g['floor_worst']):.2e}")
+    assert errs[worst] <= 1e-4
+
+
 def test_train_entrypoint_runs(tmp_path):
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("entry_train", os.path.join(os.path.dirname(os.path.dirname(__file__)), "train.py"))

@@ -256,6 +256,30 @@ def test_gpu_input_pipeline_bit_exact():
             assert torch.equal(lr[b].cpu(), rl) and torch.equal(hr[b].cpu(), rh), (b, i, y, x, aug)
 
 
+def test_gpu_input_pipeline_vs_the_reference_fixture_gv12():
+    """The same kernel against golden GV12: outputs of the reference's OWN SRDataset._crop / _aug_data / _to_tensor
+    (reference data.py:79-126; tests/golden/make_golden_plumbing.py) - every aug_idx, crops on every image edge, both crop types."""
+    from helpers import load_golden
+    from oracle import detrand
+    from pesr_amd.input_pipeline import GpuPatchSampler
+    g = load_golden("gv12_crop_aug")
+    cases = g["cases"].tolist()
+    mk = lambda h, w, s: detrand.image_batch((1, 3, h, w), s)[0].permute(1, 2, 0).contiguous().numpy().astype("uint8")  # noqa: E731
+    keys = sorted({(c[0], c[1], c[2], c[3], c[4]) for c in cases})
+    samp = GpuPatchSampler([mk(ih, iw, s) for ih, iw, _, s, _ in keys], [mk(4 * ih, 4 * iw, s) for ih, iw, _, _, s in keys], torch.device("cuda"))
+    augs = set()
+    for img, key in enumerate(keys):
+        mine = [(n, c) for n, c in enumerate(cases) if tuple(c[:5]) == key]
+        picks = [(img, c[7], c[8], c[9]) for _, c in mine]
+        for nhwc in (False, True):
+            lr, hr = samp.assemble(picks, key[2], nhwc=nhwc)
+            for b, (n, c) in enumerate(mine):
+                assert torch.equal(lr[b].cpu(), torch.from_numpy(g[f"inp{n}"]).float()), (n, c)
+                assert torch.equal(hr[b].cpu(), torch.from_numpy(g[f"lbl{n}"]).float()), (n, c)
+                augs.add(c[9])
+    assert augs == set(range(8))
+
+
 def test_psnr_on_device_bit_identical():
     """utils.compute_PSNR on GPU tensors (device kernel) == the oracle's numpy restatement of reference utils.py:32-41."""
     import importlib.util, os

@@ -38,6 +38,24 @@ def test_gv1_generator_small():
         close(v.grad, g["grad." + k], 2e-5)
 
 
+def test_gv2c_generator_full_batch1():
+    """The oracle at the reference's inference shape (reference test.py:100-106, BASELINE config 1): 256 ch x 32 blocks,
+    [1,3,48,48] -> [1,3,192,192], sampled output and gradients under L1 against the reference's own (fp32) values."""
+    g = load("gv2c_generator_full_b1")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in gen_sd(256, 32).items()}
+    lr = detrand.image_batch((1, 3, 48, 48), 1234)
+    hr = detrand.image_batch((1, 3, 192, 192), 1235)
+    sr = OM.generator_forward(leaves, lr, 32, 0.1)
+    assert sr.shape == (1, 3, 192, 192)
+    close(sr.detach().reshape(-1)[g["sr_idx"]], g["sr_val"], 1e-6)
+    close(sr.sum().item(), g["sr_sum"], 1e-6)
+    loss = F.l1_loss(sr, hr)
+    close(loss.item(), g["loss"], 1e-6)
+    loss.backward()
+    for key in [k[5:] for k in g.files if k.startswith("gidx.")]:
+        close(leaves[key].grad.reshape(-1)[g["gidx." + key]], g["gval." + key], 0.0, 2e-5 * float(g["gmax." + key]))
+
+
 def test_gv3_pixel_shuffle_bit_exact():
     g = load("gv3_pixel_shuffle")
     x = torch.arange(2 * 16 * 3 * 5, dtype=torch.float32).reshape(2, 16, 3, 5)
