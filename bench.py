@@ -512,6 +512,32 @@ def side_measurements(args, trainer, G, batches, device):
     measured / 8 TB/s spec; algorithmic bytes = SURVEY Appendix A.4 "min MB")."""
     from pesr_amd import ops
     side = {}
+    # ---- the reference's own --learning_rate 5e-5 (reference train.py:46, SURVEY 8d), from the INITIAL weights -----------------
+    # The timed region runs at --lr (default 5e-7, `lr_note`).  Same seeds, a second set of networks, Adam at 5e-5: two untimed
+    # and five timed GAN steps - the Discriminator has not yet separated the white-noise crops after seven steps (its loss is in
+    # the record), so its backward pass still runs on live data and the two rates can be compared in one driver-attested line.
+    if args.workload == "gan" and abs(args.lr - 5e-5) > 1e-12:
+        import copy
+        a2 = copy.copy(args)
+        a2.lr = 5e-5
+        tr2, G2, D2, V2 = build(a2, device, 1)
+        for i in range(2):
+            tr2.gan_step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        for i in range(n):
+            log2 = tr2.gan_step(*batches[(2 + i) % len(batches)])
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        side["lr_5e-5"] = {"workload": "the timed workload at the reference's --learning_rate 5e-5 (reference train.py:46), from the initial "
+                                       "weights: 2 untimed + 5 timed eager GAN steps",
+                           "steps": n, "ms_per_step": round(ms, 3), "patches_per_s": round(args.batch / ms * 1e3, 2),
+                           "losses_after": {k: float(v) for k, v in log2.items()},
+                           "note": "compare with the line's own ms_per_step (Adam at %g): the work of a step does not depend on the value "
+                                   "of the learning rate" % args.lr}
+        del tr2, G2, D2, V2, log2
+        torch.cuda.empty_cache()
     # ---- config 2: pretrain step (reference train.py:164-173) -----------------------------------------------------------
     for b in batches[:2]:
         trainer.pretrain_step(*b)

@@ -18,7 +18,9 @@ Two transports behind one small interface (`all_reduce_async` / `wait` / `host_m
   exist on the direct transport only (Trainer._capture refuses the other).
 
 `make_transport()` picks one for a process group; every rank takes the same decision (the choice is agreed with a MIN
-all-reduce on the bootstrap group).
+all-reduce on the bootstrap group).  With more than one rank the direct transport is rehearsed in child processes first
+(`probe_direct`, `pesr_amd/comm_probe.py`): if it hangs or fails there, the children are killed and every rank uses
+torch.distributed - the ctypes path has never run on more than one GPU, and a hang inside `ncclCommInitRank` cannot be undone.
 """
 from __future__ import annotations
 
@@ -193,11 +195,56 @@ class TorchGroup(Transport):
                         "events of the streams that join the capture): use the direct RCCL transport (PESR_DP_TRANSPORT=rccl or auto)")
 
 
+def probe_direct(device: Optional[torch.device], group=None, timeout: Optional[float] = None):
+    """Can the direct RCCL transport come up among THESE ranks?  Answered in child processes (`pesr_amd.comm_probe`, one per rank,
+    rendezvous among themselves over gloo on a port rank 0 picks): communicator, a 32 MB all-reduce with a known answer, a MAX
+    all-reduce, teardown.  A child that has not exited after `timeout` seconds (env PESR_DP_PROBE_TIMEOUT, default 180) is killed.
+    Returns (ok on THIS rank, reason); the caller agrees the answer over the ranks.  Why a child: `ncclCommInitRank` called through
+    ctypes cannot be abandoned once it hangs (a partial failure - some ranks in, some out - leaves the others waiting in C),
+    and no multi-GPU node was available to run that path before the first one the benchmark sees."""
+    import socket
+    import subprocess
+    import sys
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    timeout = float(timeout if timeout is not None else os.environ.get("PESR_DP_PROBE_TIMEOUT", "180"))
+    port = [0]
+    if rank == 0:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("", 0))
+            port[0] = s.getsockname()[1]
+    if world > 1:
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        dist.broadcast_object_list(port, src=src, group=group)
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    index = device.index if device is not None and device.type == "cuda" and device.index is not None else 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "pesr_amd.comm_probe", str(rank), str(world), str(index), addr, str(port[0]), str(max(10.0, timeout - 10.0))]
+    try:
+        p = subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    except OSError as e:
+        return False, f"probe child did not start: {e}"
+    try:
+        _, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        return False, f"probe child still running after {timeout:.0f} s (killed)"
+    if p.returncode != 0:
+        tail = err.decode(errors="replace").strip().splitlines()[-1:] or [""]
+        return False, f"probe child exited {p.returncode}: {tail[0][:300]}"
+    return True, ""
+
+
 def make_transport(device: Optional[torch.device], group=None, prefer: Optional[str] = None) -> Transport:
     """The transport of this process group's gradient exchange.  prefer (or env PESR_DP_TRANSPORT): "rccl" = the direct
     communicator or an error, "torch" = torch.distributed, "auto" (default) = direct RCCL when the ranks own one GPU each and the
-    bootstrap backend is nccl, else torch.distributed; should the direct communicator fail on ANY rank, all ranks fall back
-    together (agreed by a MIN all-reduce) and the reason is kept in `.fallback_reason`."""
+    bootstrap backend is nccl, else torch.distributed.  Under "auto" with more than one rank the direct transport is first
+    brought up in CHILD processes (`probe_direct`; PESR_DP_PROBE=0 skips it) and used only if every rank's child succeeded: a
+    hang or a partial failure of the ctypes path costs a killed child and an eager fallback to torch.distributed on all ranks,
+    not a hung job.  Should the communicator then still fail in this process on ANY rank with an exception, all ranks fall
+    back together (agreed by a MIN all-reduce); the reason is kept in `.fallback_reason`."""
     prefer = prefer or os.environ.get("PESR_DP_TRANSPORT", "auto")
     if prefer not in ("auto", "rccl", "torch"):
         raise ValueError(f"PESR_DP_TRANSPORT must be auto, rccl or torch, got {prefer!r}")
@@ -205,12 +252,21 @@ def make_transport(device: Optional[torch.device], group=None, prefer: Optional[
     want_direct = prefer == "rccl" or (prefer == "auto" and backend == "nccl" and device is not None and device.type == "cuda")
     if not want_direct:
         return TorchGroup(group)
+    agree_dev = device if backend == "nccl" else "cpu"
+    if prefer == "auto" and dist.get_world_size(group) > 1 and os.environ.get("PESR_DP_PROBE", "1") != "0":
+        ok_here, why = probe_direct(device, group)
+        ok = torch.tensor([1.0 if ok_here else 0.0], device=agree_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if float(ok.item()) != 1.0:
+            fb = TorchGroup(group)
+            fb.fallback_reason = "probe: " + (why or "another rank's probe failed")
+            return fb
     tr, reason = None, ""
     try:
         tr = DirectRccl(device, dist.get_rank(group), dist.get_world_size(group), group)
     except (CommError, OSError, RuntimeError) as e:      # (decided together below)
         reason = f"{type(e).__name__}: {e}"
-    ok = torch.tensor([1.0 if tr is not None else 0.0], device=device if backend == "nccl" else "cpu")
+    ok = torch.tensor([1.0 if tr is not None else 0.0], device=agree_dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if float(ok.item()) == 1.0:
         return tr

@@ -1,0 +1,46 @@
+"""Child process of `comm.probe_direct`: brings the direct RCCL communicator up among the probe children of all ranks, runs one
+gradient-sized all-reduce with a known answer, and exits 0.  If RCCL's C API through ctypes were to hang or fail on a node with
+several GPUs - a path no single-GPU box can execute - it hangs or fails HERE, in a process its parent can kill, and the training
+processes fall back to torch.distributed together instead of hanging in `ncclCommInitRank` (replaces nothing of the reference:
+the guard of the replacement of nn.DataParallel, reference train.py:114-118).
+
+    python -m pesr_amd.comm_probe <rank> <world> <cuda device index> <addr> <port> <rendezvous timeout s>
+"""
+import datetime
+import sys
+
+
+def main(argv) -> int:
+    rank, world, dev, addr, port, timeout = int(argv[0]), int(argv[1]), int(argv[2]), argv[3], int(argv[4]), float(argv[5])
+    import torch
+    import torch.distributed as dist
+    from pesr_amd import comm
+    if not torch.cuda.is_available():
+        print("comm_probe: no GPU visible", file=sys.stderr)
+        return 3
+    device = torch.device("cuda", dev)
+    torch.cuda.set_device(device)
+    # bootstrap over gloo: nothing of ProcessGroupNCCL in this process, the unique id travels as a CPU tensor
+    dist.init_process_group("gloo", init_method=f"tcp://{addr}:{port}", rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=timeout))
+    tr = comm.DirectRccl(device, rank, world, None)               # includes a 4-element self-test
+    n = 8 << 20                                                   # one 32 MB bucket
+    t = torch.full((n,), float(rank + 1), dtype=torch.float32, device=device)
+    tr.wait([tr.all_reduce_async(t)])
+    torch.cuda.synchronize(device)
+    want = world * (world + 1) / 2.0
+    got = (float(t[0]), float(t[n // 2]), float(t[-1]))
+    if got != (want, want, want):
+        print(f"comm_probe: all-reduce gave {got}, expected {want}", file=sys.stderr)
+        return 4
+    m = tr.host_max([float(rank)])
+    if m != [float(world - 1)]:
+        print(f"comm_probe: MAX all-reduce gave {m}", file=sys.stderr)
+        return 5
+    tr.close()
+    dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -262,12 +262,14 @@ class Trainer:
             self.optim_D.buckets.set_mode(d_mode)
         self.dp_policy = name
 
-    def calibrate_dp_policy(self, kind, next_batch, steps=3, graph=True, candidates=None):
+    def calibrate_dp_policy(self, kind, next_batch, steps=3, graph=True, candidates=None, margin=0.015):
         """Pick the data-parallel schedule by timing it (call it inside the warm-up, on every rank, after at least two eager
         steps).  Each eager candidate of DP_POLICIES runs one untimed step (the policy switch) and `steps` timed ones; then,
         if the transport is capturable, the step is captured as a hipGraph with the best eager bucket policy and its replays
         are timed the same way.  Every rank uses the SLOWEST rank's time per candidate (Transport.host_max), so all ranks
-        choose alike; ties go to the earlier candidate.  Returns {"chosen", "ms_per_step": {candidate: ms}, "graph_error",
+        choose alike.  The first candidate ("overlap") stays unless another one is faster by more than `margin` (1.5 %): the
+        bucket schedule decides RCCL's reduction order, i.e. the last bits of a run, and that must not hang on a 0.1 % timing
+        race between equally good schedules (a graph replay keeps its eager policy's order: plain "faster" decides).  Returns {"chosen", "ms_per_step": {candidate: ms}, "graph_error",
         "transport"}; afterwards `self.dp_step` is the step function to call (eager method or graph replay).
         These are real optimizer steps on real batches - nothing is thrown away."""
         import time
@@ -297,7 +299,8 @@ class Trainer:
             mine.append(timed(eager))
         agreed = tr.host_max(mine)
         ms = dict(zip(cands, agreed))
-        best = min(cands, key=lambda c: (ms[c], cands.index(c)))
+        faster = [c for c in cands[1:] if ms[c] < ms[cands[0]] * (1.0 - margin)]
+        best = min(faster, key=lambda c: (ms[c], cands.index(c))) if faster else cands[0]
         self.set_dp_policy(best)
         self.dp_step, chosen, graph_error = eager, best, None
         if graph and tr.capturable:
@@ -322,7 +325,7 @@ class Trainer:
                 else:
                     self._graph.pop(kind, None)         # frees the graph's private memory pool
         return {"chosen": chosen, "ms_per_step": {k: round(v, 3) for k, v in ms.items()}, "graph_error": graph_error,
-                "transport": tr.name, "steps_per_candidate": steps}
+                "transport": tr.name, "steps_per_candidate": steps, "margin": margin}
 
     def _replay(self, kind, lr, hr, gp_u=None):
         assert self._graph and kind in self._graph, f"capture_{kind}_step first"

@@ -254,3 +254,51 @@ def test_two_rank_dp_policy_selection_agrees():
         got = None
     assert got is not None, "the 2-rank gloo job failed three times"
     assert {g[1] for g in got} == {"defer_g"} and got[0][2] == got[1][2], got      # same choice from the same agreed numbers
+
+
+def _probe_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pesr_amd import comm
+        # the probe itself between two ranks: rank 0's port reaches both, each rank's child starts, finds no GPU here, is reported
+        ok, why = comm.probe_direct(torch.device("cpu"))
+        assert not ok and "no GPU visible" in why, why
+        # make_transport's "auto" with a probe that fails on ONE rank only: both ranks must take torch.distributed (MIN all-reduce)
+        # before any of them would have entered ncclCommInitRank (DirectRccl is made to raise if anybody gets there)
+        orig_backend = dist.get_backend
+        comm.dist.get_backend = lambda group=None: "nccl"
+        comm.probe_direct = lambda device, group=None, timeout=None: ((False, "rank 1's child hung") if rank == 1 else (True, ""))
+
+        class _Never:
+            def __init__(self, *a, **k):
+                raise AssertionError("the communicator was created although a rank's probe failed")
+        comm.DirectRccl = _Never
+        fake_cuda = type("D", (), {"type": "cuda", "index": 0})()
+        real_tensor = torch.tensor
+        torch.tensor = lambda *a, **k: real_tensor(*a, **{**k, "device": "cpu"}) if "device" in k else real_tensor(*a, **k)
+        try:
+            tr = comm.make_transport(fake_cuda, prefer="auto")
+        finally:
+            torch.tensor = real_tensor
+            comm.dist.get_backend = orig_backend
+        assert isinstance(tr, comm.TorchGroup) and tr.fallback_reason.startswith("probe: ")
+        q.put((rank, tr.fallback_reason))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_direct_transport_probe_falls_back_together():
+    """Guard of the never-executed world > 1 branch of the direct RCCL transport (pesr_amd/comm.py `probe_direct`)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    port, q = _free_port(), ctx.Queue()
+    procs = [ctx.Process(target=_probe_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=200) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][1] == "probe: another rank's probe failed" and got[1][1] == "probe: rank 1's child hung"

@@ -64,6 +64,27 @@ def _close_group():
     dist.destroy_process_group()
 
 
+def test_direct_rccl_probe_child_on_hardware(monkeypatch):
+    """`comm.probe_direct`: the child process brings the direct communicator up (one rank here), all-reduces 32 MB with a known
+    answer and exits 0; a child that cannot finish in time is killed and reported, and `make_transport` then takes
+    torch.distributed on every rank instead of entering `ncclCommInitRank` itself."""
+    from pesr_amd import comm
+    _one_rank_group()
+    try:
+        ok, why = comm.probe_direct(torch.device("cuda", 0))
+        assert ok and why == "", why
+        ok, why = comm.probe_direct(torch.device("cuda", 0), timeout=0.05)          # (the interpreter alone needs longer)
+        assert not ok and "killed" in why
+        # the fallback branch of make_transport with a failing probe (world size faked: a one-rank group skips the probe)
+        monkeypatch.setattr(comm, "probe_direct", lambda device, group=None, timeout=None: (False, "rehearsed failure"))
+        monkeypatch.setattr(comm.dist, "get_world_size", lambda group=None: 2)
+        tr = comm.make_transport(torch.device("cuda", 0), prefer="auto")
+        assert isinstance(tr, comm.TorchGroup) and "rehearsed failure" in tr.fallback_reason
+    finally:
+        monkeypatch.undo()
+        _close_group()
+
+
 @pytest.mark.parametrize("transport", ["rccl", "torch"])
 def test_single_rank_nccl_forced_dp_is_bit_identical(monkeypatch, transport):
     """transport "rccl": the direct communicator (ctypes over librccl, pesr_amd/comm.py); "torch": ProcessGroupNCCL."""

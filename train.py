@@ -8,6 +8,7 @@ optimizers replaces nn.DataParallel; --batch_size stays the GLOBAL batch as in t
 tensorboardX is optional.  Checkpoints keep the reference's format: torch.save(G.state_dict()).
 """
 import argparse
+import json
 import os
 
 import numpy as np
@@ -312,6 +313,10 @@ def main(argv=None):
                     dp_calibrate = False
                     if rank == 0:
                         print("data-parallel schedule:", info)
+                        # a run is reproduced bit for bit with an explicit --dp_policy (the bucket schedule decides RCCL's
+                        # reduction order): the choice is kept next to the checkpoints
+                        with open(os.path.join(check_point, "dp_policy.json"), "w") as fh:
+                            json.dump({"dp_policy": trainer.dp_policy, **info}, fh, indent=1)
                     if info["chosen"].startswith("graph"):
                         graphed, graph_shapes = trainer.dp_step, (lr_img.shape, hr_img.shape)
                     # (--hip_graph true / false: the flag decides and only the bucket schedule was measured; the capture below
@@ -326,6 +331,13 @@ def main(argv=None):
                         graphed = (trainer.capture_gan_step if gan else trainer.capture_pretrain_step)(lr_img, hr_img)
             running += torch.stack([logs[k].float() for k in keys])
             iters += 1
+        if dp_calibrate:
+            # No epoch will get longer: with too few iterations left behind the second step for the measurement (short epochs
+            # or a small --max_iters) the schedule stays the default one - said once, and --hip_graph true can capture now.
+            dp_calibrate = False
+            if rank == 0:
+                print("data-parallel schedule: an epoch has %d iterations, the measurement needs %d behind the second one - keeping "
+                      "'%s' (choose with --dp_policy)" % (n_iters, calib_need, trainer.dp_policy))
         if world > 1:
             dist.all_reduce(running)
             running /= world
