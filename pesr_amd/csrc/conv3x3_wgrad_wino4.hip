@@ -356,6 +356,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int X4_NT = 768;
 constexpr int X4_VPLANE = G4_TXT * 32, X4_VROW = 6 * X4_VPLANE;       // floats: V row slot [6 xi][12 x-tiles][32 ci]
 constexpr int X4_DPLANE = G4_TXT * 64, X4_DROW = 6 * X4_DPLANE;       // floats: dM row     [6 xi][12 x-tiles][64 co]
+constexpr int X4_RING = 8;                                            // V row slots: four in use, four for the segment behind (a strip start needs all four)
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Round 4, NEST = true (the default): the transform NESTED in y - F(2,3) along y on top of F(4,3) along x - at no cost in staging.
@@ -373,9 +374,8 @@ constexpr int X4_DPLANE = G4_TXT * 64, X4_DROW = 6 * X4_DPLANE;       // floats:
 template <bool NEST>
 __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const vring = lds;                             // [6 slots] V rows
-    float* const dmbuf = lds + G4_RING * X4_VROW;         // [2 buffers][2 rows] dM rows
-
+    float* const vring = lds;                             // [8 slots] V rows
+    float* const dmbuf = lds + X4_RING * X4_VROW;         // [2 buffers][2 rows] dM rows
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c32 = lane & 31, ks = lane >> 5;            // fragment lane: channel, k-slot (x-tile 2q + ks of k-step q)
     const int cot2 = wave / 6, xi = wave - cot2 * 6;
@@ -400,50 +400,74 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     float bsum = 0.f;
 
     // ---- staging roles: threads 0..191 (waves 0..2) the 192 V items (2 rows x 12 x-tiles x 8 ci groups, six input columns each),
-    //      threads 192..575 (waves 3..8) the 384 dM items (2 rows x 12 x-tiles x 16 co groups, four columns each); one register set
-    //      waves 9..11 idle in the loop; at a strip start they take the V role for the strip's SECOND pair of halo rows, so that its
-    //      four halo rows arrive in one load round instead of two dependent ones
-    const bool v_thr = tid < 192 || tid >= 576, d_thr = tid >= 192 && tid < 576;
-    const int vi = tid < 192 ? tid : (tid >= 576 ? tid - 576 : 0);
-    const int v_rr = vi / 96, vt = (vi % 96) >> 3, vc4 = vi & 7;
-    const int di = d_thr ? tid - 192 : 0;
-    const int d_rr = di / 192, dt = (di % 192) >> 4, dc4 = di & 15;
-    const int v_pos = vt * 32 + vc4 * 4;
-    const int d_pos = dt * 64 + dc4 * 4;
+    //      threads 192..575 (waves 3..8) the 384 dM items (2 rows x 12 x-tiles x 16 co groups, four columns each); one register set.
+    //      Waves 9..11 take the V role for the SECOND pair of halo rows whenever a segment does not continue the previous one's
+    //      strip (the workgroup's first segment, a new strip, a new image): its four halo rows then arrive in one load round.
+    //      A thread has ONE role, so the per-thread staging constants live in role-neutral registers (the register budget of three
+    //      waves per SIMD is 168): s_rr = which of the item's two rows, s_pos = float position inside an LDS plane, s_cb = byte offset
+    //      of the item's channel group (and, side > 1, of its image inside the strip's group), s_x = first column (strip-relative
+    //      column + 48 * strip; pushed out of range for an image that does not exist), s_ps = byte pitch of a pixel.
+    // Roles by SIMD (waves w, w + 4, w + 8 share one): every VALU instruction costs the fp32 MFMA pipe of ITS SIMD ~3.7 cycles
+    // (scripts/mfma_valu_probe.hip), and the segment's barrier waits for the SIMD with the most staging work - so V (48 VALU per
+    // item) goes to waves 0, 1, 2, dM (32) to waves 4, 5, 6 and - three to the SIMD that has no V wave - 3, 7, 11; waves 8, 9, 10
+    // (one on each V SIMD) stage nothing in a strip and take the second pair of halo rows at its start.
+    const bool v_hi = wave >= 8 && wave < 11, v_role = wave < 3 || v_hi;
+    const int d_wave = wave == 11 ? 5 : wave - 3;             // dM waves 3, 4, 5, 6, 7, 11 -> item blocks 0 .. 5
+    const int XTW = a.W >> 2;
     const int d_C = a.ps_in ? (a.Cout >> 2) : a.Cout;
-    int d_choff;
+    int s_rr, s_pos;
+    unsigned s_cb, s_ps;
+    int s_x;
     {
-        const int pch = co0 + dc4 * 4;
-        if (a.ps_in) { const int sub = pch / d_C, cc = pch - sub * d_C; d_choff = ((sub >> 1) * (2 * a.W) + (sub & 1)) * d_C + cc; }
-        else d_choff = pch;
+        const int item = v_role ? (tid < 192 ? tid : tid - 512) : d_wave * 64 + lane;
+        if (v_role) {
+            const int vt = (item % 96) >> 3, vc4 = item & 7;
+            const int sub = a.side > 1 ? vt / XTW : 0;
+            s_rr = item / 96;
+            s_pos = vt * 32 + vc4 * 4;
+            s_x = 4 * (vt - sub * XTW) - 1;
+            s_ps = (unsigned)a.Cin * 4;
+            s_cb = (unsigned)(((sub * a.H) * a.W) * a.Cin + ci0 + vc4 * 4) * 4;
+        } else {
+            const int dt = (item % 192) >> 4, dc4 = item & 15;
+            const int sub0 = a.side > 1 ? dt / XTW : 0;
+            s_rr = item / 192;
+            s_pos = dt * 64 + dc4 * 4;
+            s_x = 4 * (dt - sub0 * XTW);
+            const int pch = co0 + dc4 * 4;
+            if (a.ps_in) {
+                const int sub = pch / d_C, cc = pch - sub * d_C;
+                s_cb = (unsigned)(((sub >> 1) * (2 * a.W) + (sub & 1)) * d_C + cc) * 4;
+                s_ps = (unsigned)(2 * d_C) * 4;
+            } else {
+                s_cb = (unsigned)((sub0 * a.H * a.W) * a.Cout + pch) * 4;
+                s_ps = (unsigned)a.Cout * 4;
+            }
+        }
+        s_ps = __builtin_amdgcn_readfirstlane(s_ps);         // (the same for every lane of a wave)
     }
     u32x4 st[6];                  // V thread: six input columns; dM thread: four gradient columns
-    unsigned off[6];
+    unsigned off[6];              // their byte offsets from the start of the item's FIRST row (V: the lane's row pitch folded in); 2^31 = outside
     // side > 1: x-tile t of the strip is tile t % XTW of image (group * side + t / XTW); its columns never leave that image (the
     // neighbour's pixels are NOT its halo: out-of-image columns read zeros as at a real image border)
-    const int XTW = a.W >> 2;
-    auto set_strip = [&](int xs, int grp) {
-        if (v_thr) {
-            const int sub = a.side > 1 ? vt / XTW : 0, lt = a.side > 1 ? vt - sub * XTW : vt;
-            const bool img_ok = a.side == 1 || grp * a.side + sub < a.N;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int ix = xs * 48 + 4 * lt - 1 + j;
-                off[j] = (img_ok && ix >= 0 && ix < a.W) ? (unsigned)((((sub * a.H) * a.W + ix) * a.Cin + ci0 + vc4 * 4) * 4) : 0x80000000u;
-            }
-        } else {
-            const int sub = a.side > 1 ? dt / XTW : 0, lt = a.side > 1 ? dt - sub * XTW : dt;
-            const bool img_ok = a.side == 1 || grp * a.side + sub < a.N;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ox = xs * 48 + 4 * lt + j;
-                off[j] = (d_thr && img_ok && ox < a.W) ? (unsigned)(((a.ps_in ? 2 * ox * d_C : (sub * a.H * a.W + ox) * a.Cout) + d_choff) * 4) : 0x80000000u;
-            }
-            off[4] = off[5] = 0x80000000u;
-        }
-    };
     const unsigned x_row_bytes = (unsigned)a.W * a.Cin * 4;
     const unsigned d_row_bytes = (unsigned)a.W * a.Cout * 4;
+    int s_xs = 0;                                             // the strip s_x currently points into
+    auto set_strip = [&](int xs, int grp) {                   // (once per strip: the only place the offsets cost VALU instructions)
+        s_x += (xs - s_xs) * 48;
+        s_xs = xs;
+        int x0 = s_x;
+        if (a.side > 1) {                                     // (one strip per row there: only the image group changes)
+            const int t = v_role ? ((tid < 192 ? tid : tid - 512) % 96) >> 3 : ((d_wave * 64 + lane) % 192) >> 4;
+            if (grp * a.side + t / XTW >= a.N) x0 += 0x100000;      // an image of the last group that does not exist: its columns leave the row
+        }
+        const unsigned rowterm = v_role ? s_cb + (unsigned)s_rr * x_row_bytes : s_cb;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const unsigned x = (unsigned)(x0 + j);
+            off[j] = (x < (unsigned)a.W && (v_role || j < 4)) ? rowterm + x * s_ps : 0x80000000u;
+        }
+    };
     const unsigned x_side_bytes = (unsigned)(a.side - 1) * a.H * x_row_bytes;     // the descriptors reach over the strip's other images
     const unsigned d_side_bytes = (unsigned)(a.side - 1) * a.H * d_row_bytes;
     auto uniform_ptr = [](const float* p) -> const float* {
@@ -451,65 +475,118 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return (const float*)(((unsigned long long)hi << 32) | lo);
     };
-    // (descriptors wave-uniform, as above: the V descriptor spans the two rows that mix inside wave 1, lanes add their row's
-    // pitch; the dM rows change at thread 384 = a wave boundary)
-    auto load_stage = [&](int img, int v_iy0, int d_oy0, const bool hi = false) {   // V rows v_iy0, v_iy0 + 1; dM rows d_oy0, d_oy0 + 1
-        if (hi ? wave >= 9 : wave < 3) {                                              // (hi: the V role on waves 9..11, no dM role)
-            const float* const rowp = a.x + ((long)img * a.side * a.H + v_iy0) * ((long)a.W * a.Cin);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0, x_side_bytes + 2 * x_row_bytes, 0x00020000);
-            const int iy = v_iy0 + v_rr;
-            const bool row_ok = iy >= 0 && iy < a.H;
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                st[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? off[j] + (unsigned)v_rr * x_row_bytes : 0x80000000u, 0, 0);
-        } else if (!hi && wave >= 3 && wave < 9) {
-            const int oy = d_oy0 + d_rr;
-            const bool row_ok = oy < a.H;
+    // A segment of the walk: image (or image group), strip, top output row; cont = it continues the previous segment's strip (its
+    // rows row-1, row are already in the ring), valid = it exists in this workgroup's slice.
+    struct Seg { int img, xs, row; bool cont, valid; };
+    auto seg_after = [&](const Seg& c, int index) {           // the segment behind c; index = its number in the walk
+        Seg n;
+        n.valid = index < seg_end;
+        if (c.row + 2 < a.H) { n.img = c.img; n.xs = c.xs; n.row = c.row + 2; n.cont = true; }
+        else { n.cont = false; n.row = 0; n.xs = c.xs + 1; n.img = c.img; if (n.xs == a.segs_x) { n.xs = 0; n.img = c.img + 1; } }
+        return n;
+    };
+    // The staging loads of segment g, unconditional (a segment that does not exist is fetched through zero-size descriptors: nothing
+    // moves): a continuing segment adds input rows row+1, row+2 (waves 0..2), a segment that starts a strip needs row-1 .. row+2
+    // (waves 0..2: row-1, row; waves 8..10: row+1, row+2); the dM waves its two gradient rows.  Loads go through a buffer
+    // descriptor over the item's rows: a column outside the row sits at offset 2^31, a row behind the image's last one is cut off
+    // by the descriptor's size, a segment that does not exist gets size 0 - all return zeros, and store_stage() transforms what
+    // arrived without masking.  Inside a strip (the hot path) this costs NO vector instruction besides the loads: base and size are
+    // scalar, the lane offsets are the strip's constants (every VALU instruction takes ~3.7 cycles from the fp32 MFMA pipe of its
+    // SIMD).  Only a strip's first segment - whose halo row above the image needs a per-lane test - and the side-by-side form
+    // (side > 1: the descriptor spans several images, its size cannot cut off one image's last row) select per lane.
+    // (descriptors wave-uniform: the V descriptor spans the two rows that mix inside a wave, the dM rows change at a wave boundary)
+    // load_prep(g) makes the segment's descriptor (scalar), load_step(j) issues column j: the main loop puts ONE load in front of
+    // each of six consecutive MFMAs - as a burst, the ~42 wave-level loads of a segment queued up behind each other in the CU's
+    // one address unit and the issuing waves (and their MFMAs) stood 400 - 1100 cycles.
+    __amdgpu_buffer_rsrc_t ld_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0, 0x00020000);
+    int ld_on = 0;                                            // 1: this wave loads for the segment (scalar)
+    bool ld_lane_ok = true;                                   // this lane's row is inside the image (false only on the per-lane path below)
+    auto load_prep = [&](const Seg& g) {
+        if (v_role) {
+            const int v_iy0 = (g.cont || v_hi) ? g.row + 1 : g.row - 1;
+            const bool on = g.valid && !(v_hi && g.cont);     // (waves 8..10 inside a strip, segments that do not exist: no loads at all)
+            const float* const rowp = a.x + ((long)g.img * a.side * a.H + v_iy0) * ((long)a.W * a.Cin);
+            const int iy = v_iy0 + s_rr;
+            unsigned bytes;
+            if (g.cont && a.side == 1) {                      // inside a strip: the descriptor's size cuts off what lies behind the image
+                const int rows = a.H - v_iy0 > 2 ? 2 : (a.H - v_iy0 < 0 ? 0 : a.H - v_iy0);
+                bytes = (unsigned)rows * x_row_bytes;
+                ld_lane_ok = true;
+            } else {                                          // a strip's first segment (its halo row ABOVE the image), the side-by-side form
+                bytes = x_side_bytes + 2 * x_row_bytes;
+                ld_lane_ok = iy >= 0 && iy < a.H;
+            }
+            ld_on = __builtin_amdgcn_readfirstlane(on ? 1 : 0);
+            ld_rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+        } else {
+            const int oy = g.row + __builtin_amdgcn_readfirstlane(s_rr);      // (dM rows change at a wave boundary)
+            const bool row_ok = g.valid && oy < a.H;
             const int ry = row_ok ? oy : 0;
-            const float* const rowp = a.ps_in ? a.dy + ((size_t)img * (2 * a.H) + 2 * ry) * (2 * a.W) * d_C
-                                              : a.dy + ((size_t)img * a.side * a.H + ry) * a.W * a.Cout;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0,
-                                                                                __builtin_amdgcn_readfirstlane(row_ok ? d_side_bytes + d_row_bytes : 0u), 0x00020000);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, 0);
+            const float* const rowp = a.ps_in ? a.dy + ((size_t)g.img * (2 * a.H) + 2 * ry) * (2 * a.W) * d_C
+                                              : a.dy + ((size_t)g.img * a.side * a.H + ry) * a.W * a.Cout;
+            ld_lane_ok = true;
+            ld_on = __builtin_amdgcn_readfirstlane(g.valid ? 1 : 0);
+            ld_rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0,
+                                                      __builtin_amdgcn_readfirstlane(row_ok ? d_side_bytes + d_row_bytes : 0u), 0x00020000);
         }
     };
-    auto store_stage = [&](int v_slot0, int d_buf, const bool hi = false) {   // V rows -> ring slots v_slot0 + v_rr (mod 6); dM rows -> buffer d_buf
-        if (hi ? wave >= 9 : wave < 3) {
-            const f32x4 d0 = __builtin_bit_cast(f32x4, st[0]), d1 = __builtin_bit_cast(f32x4, st[1]), d2 = __builtin_bit_cast(f32x4, st[2]),
-                        d3 = __builtin_bit_cast(f32x4, st[3]), d4 = __builtin_bit_cast(f32x4, st[4]), d5 = __builtin_bit_cast(f32x4, st[5]);
-            int sl = v_slot0 + v_rr; if (sl >= G4_RING) sl -= G4_RING;
-            float* p = vring + sl * X4_VROW + v_pos;
-            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1, t3 = d4 - d2, t4 = d3 - d1;
-            *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
-            *(f32x4*)(p + X4_VPLANE) = t1 + t2;
-            *(f32x4*)(p + 2 * X4_VPLANE) = t1 - t2;
-            *(f32x4*)(p + 3 * X4_VPLANE) = t3 + 2.0f * t4;
-            *(f32x4*)(p + 4 * X4_VPLANE) = t3 - 2.0f * t4;
-            *(f32x4*)(p + 5 * X4_VPLANE) = 4.0f * d1 + (d5 - 5.0f * d3);
-        } else if (!hi && wave >= 3 && wave < 9) {
+    auto load_step = [&](const int j) {                       // (ONE load site per column: a second definition of st[] costs copies behind a vmcnt(0))
+        if (ld_on && (v_role || j < 4)) st[j] = __builtin_amdgcn_raw_buffer_load_b128(ld_rs, ld_lane_ok ? off[j] : 0x80000000u, 0, 0);
+    };
+#define X4_LOAD_ALL(G) { load_prep(G); _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) load_step(j_); }      /* all columns at once (the workgroup's first two segments) */
+    // ... and their transform + LDS stores: V rows -> ring slots v_slot0 (+ 2 for waves 8..10) + row (mod 8), dM rows -> buffer d_buf.
+    // In SIX steps, one LDS plane each (step n: the few VALU instructions plane n needs, then its ds_write_b128), so that the main
+    // loop can put one step in front of each of six consecutive MFMAs: as one block per wave (round 4) the nine staging waves ran
+    // ~850 cycles of transform + stores and 400 - 1100 cycles of queued-up buffer loads all at the same point of the segment, and the
+    // matrix pipes of their SIMDs starved meanwhile (in-kernel stamps, profiles/r05_wgrad_notes.txt).
+    f32x4 tA, tB;                                             // transform terms that live from one step to the next
+    float* sp_ = nullptr;                                     // the item's LDS address for the segment being stored
+    auto stage_step = [&](const int n, int v_slot0, int d_buf, bool four) {
+        if (v_role) {
+            if (!v_hi || four) {
+                const f32x4 d0 = __builtin_bit_cast(f32x4, st[0]), d1 = __builtin_bit_cast(f32x4, st[1]), d2 = __builtin_bit_cast(f32x4, st[2]),
+                            d3 = __builtin_bit_cast(f32x4, st[3]), d4 = __builtin_bit_cast(f32x4, st[4]), d5 = __builtin_bit_cast(f32x4, st[5]);
+                if (n == 0) {
+                    sp_ = vring + ((v_slot0 + (v_hi ? 2 : 0) + s_rr) & (X4_RING - 1)) * X4_VROW + s_pos;
+                    *(f32x4*)(sp_) = 4.0f * d0 + (d4 - 5.0f * d2);
+                } else if (n == 1) {
+                    tA = d4 - 4.0f * d2; tB = d3 - 4.0f * d1;
+                    *(f32x4*)(sp_ + X4_VPLANE) = tA + tB;
+                } else if (n == 2) {
+                    *(f32x4*)(sp_ + 2 * X4_VPLANE) = tA - tB;
+                } else if (n == 3) {
+                    tA = d4 - d2; tB = 2.0f * (d3 - d1);
+                    *(f32x4*)(sp_ + 3 * X4_VPLANE) = tA + tB;
+                } else if (n == 4) {
+                    *(f32x4*)(sp_ + 4 * X4_VPLANE) = tA - tB;
+                } else {
+                    *(f32x4*)(sp_ + 5 * X4_VPLANE) = 4.0f * d1 + (d5 - 5.0f * d3);
+                }
+            }
+        } else {
             const f32x4 g0 = __builtin_bit_cast(f32x4, st[0]), g1 = __builtin_bit_cast(f32x4, st[1]), g2 = __builtin_bit_cast(f32x4, st[2]),
                         g3 = __builtin_bit_cast(f32x4, st[3]);
-            float* p = dmbuf + (d_buf * 2 + d_rr) * X4_DROW + d_pos;
-            const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = g1 + 4.0f * g3;
-            *(f32x4*)(p) = g0;
-            *(f32x4*)(p + X4_DPLANE) = e02 + e13;
-            *(f32x4*)(p + 2 * X4_DPLANE) = e02 - e13;
-            *(f32x4*)(p + 3 * X4_DPLANE) = f02 + 2.0f * f13;
-            *(f32x4*)(p + 4 * X4_DPLANE) = f02 - 2.0f * f13;
-            *(f32x4*)(p + 5 * X4_DPLANE) = g3;
+            if (n == 0) {
+                sp_ = dmbuf + (d_buf * 2 + s_rr) * X4_DROW + s_pos;
+                *(f32x4*)(sp_) = g0;
+            } else if (n == 1) {
+                tA = g0 + g2; tB = g1 + g3;
+                *(f32x4*)(sp_ + X4_DPLANE) = tA + tB;
+            } else if (n == 2) {
+                *(f32x4*)(sp_ + 2 * X4_DPLANE) = tA - tB;
+            } else if (n == 3) {
+                tA = g0 + 4.0f * g2; tB = 2.0f * (g1 + 4.0f * g3);
+                *(f32x4*)(sp_ + 3 * X4_DPLANE) = tA + tB;
+            } else if (n == 4) {
+                *(f32x4*)(sp_ + 4 * X4_DPLANE) = tA - tB;
+            } else {
+                *(f32x4*)(sp_ + 5 * X4_DPLANE) = g3;
+            }
         }
     };
-    auto seg_coords = [&](int seg, int& img, int& xs, int& row) {
-        const int strip = seg / a.segs_y;
-        row = 2 * (seg - strip * a.segs_y);
-        img = strip / a.segs_x;
-        xs = strip - img * a.segs_x;
-    };
-    auto stage_strip_start = [&](int img, int row, int buf) {   // halo rows row-1 .. row+2 -> slots 0 .. 3; dM(row, row+1) -> buf
-        load_stage(img, row - 1, row);                            // waves 0..2: V rows row-1, row; waves 3..8: both dM rows
-        load_stage(img, row + 1, 0, true);                        // waves 9..11: V rows row+1, row+2 - the same load round
-        store_stage(0, buf); store_stage(2, buf, true);
+    auto store_stage = [&](int v_slot0, int d_buf, bool four) {      // all six at once (the workgroup's first segment)
+#pragma unroll
+        for (int n = 0; n < 6; ++n) stage_step(n, v_slot0, d_buf, four);
     };
 
     // ---- fragment addresses (floats): lane (c32, ks) reads x-tile 2q + ks, channel c32 of its tile ---------------------------
@@ -517,106 +594,130 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     const int a_lane = xi * X4_DPLANE + ks * 64 + cot2 * 32 + c32;
 
     if (seg_begin >= seg_end) return;
-    int img, xs, row;
-    seg_coords(seg_begin, img, xs, row);
-    set_strip(xs, img);
-    stage_strip_start(img, row, 0);
-    if (seg_begin + 1 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
+    Seg cur;
+    {
+        const int strip = seg_begin / a.segs_y;
+        cur.row = 2 * (seg_begin - strip * a.segs_y);
+        cur.img = strip / a.segs_x;
+        cur.xs = strip - cur.img * a.segs_x;
+        cur.cont = false; cur.valid = true;
+    }
+    Seg n2 = seg_after(cur, seg_begin + 1);
+    bool n1_valid = n2.valid, n1_cont = n2.cont;              // the segment behind the one being computed (n2: the one after that)
+    // The walk is ONE software pipeline over all segments of the slice, strip changes included (round 5): at its store point a
+    // segment stores what the segment behind it needs (two new rows, or the four halo rows of a new strip: the ring has EIGHT
+    // slots, four in use, four free) and loads for the one after that.  Until round 4 a strip change was staged synchronously
+    // between two barriers (3.8 us per change at the G-body shape).
+    set_strip(cur.xs, cur.img);
+    X4_LOAD_ALL(cur)
+    store_stage(0, 0, true);
+    if (n2.valid && !n2.cont) set_strip(n2.xs, n2.img);
+    X4_LOAD_ALL(n2)
+    n2 = seg_after(n2, seg_begin + 2);
     __syncthreads();
-    int base = 0;                                           // ring slot of the segment's top halo row (row - 1)
+    int base = 0, par = 0;                                  // ring slot of the segment's top halo row (row - 1); its dM buffer
     constexpr int KQ = G4_TXT / 2;                          // k-steps per row
     // Static priority for the second-dispatched half (waves 6..11), set once: the two halves run the same program in lockstep
     // behind one barrier per segment, and the younger half loses every arbitration; raised, it pulls ahead and the halves'
     // LDS read bursts and MFMA blocks de-phase (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): 209.6 -> 206.2 us; three
     // levels (w, w + 4, w + 8 share a SIMD) 206.9, the first half raised instead 208.8 (profiles/r03_wgrad_variants.txt).
-    if (cot2) __builtin_amdgcn_s_setprio(1);
-    constexpr int X4_STORE_STEP = 3;    // the staging stores sit behind this k-step (2 / 3 / 4 measured: 207 - 209 us, profiles/r03_wgrad_variants.txt)
 
-    // Two nested loops - strips outside, a strip's segments inside - instead of one loop over segments with a cold "next strip"
-    // branch: the staging registers' value for the next iteration then has ONE definition inside the hot loop (the load_stage
-    // below, issued unconditionally), where it had two merging at the loop header - hipcc resolved that merge with s_waitcnt
-    // vmcnt(0) + 30 register copies at the end of every segment, i.e. the loads had half a segment to arrive, not a whole one.
-    int seg = seg_begin;
-#pragma unroll 1
-    for (;;) {
-#pragma unroll 1
-      for (;;) {
-        const int par = (seg - seg_begin) & 1;
-        const bool more = seg + 1 < seg_end;
-        const bool cont = more && row + 2 < a.H;
-        const bool cont2 = cont && seg + 2 < seg_end && row + 4 < a.H;
-        const float* const db = dmbuf + (par * 2) * X4_DROW + a_lane;
-        const float* vb[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int sl = base + q; if (sl >= G4_RING) sl -= G4_RING;
-            vb[q] = vring + sl * X4_VROW + b_lane;
-        }
-        float fa0[2], fb0[4], fa1[2], fb1[4];
+    float fa0[2], fb0[4], fa1[2], fb1[4];
 #define X4_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define X4_READ(FA, FB, Q)                                                                       \
+#define X4_READ(FA, FB, DB, VB, Q)      /* three ds_read2st64_b32: the dM rows, V rows 0 / 1, V rows 2 / 3 */ \
         {                                                                                        \
-            FA[0] = db[(Q) * 128]; FA[1] = db[X4_DROW + (Q) * 128];                              \
-            _Pragma("unroll") for (int rw = 0; rw < 4; ++rw) FB[rw] = vb[rw][(Q) * 64];          \
+            FA[0] = DB[(Q) * 128]; FA[1] = DB[X4_DROW + (Q) * 128];                              \
+            FB[0] = VB[0][(Q) * 64]; FB[1] = VB[0][X4_VROW + (Q) * 64];                          \
+            FB[2] = VB[1][(Q) * 64]; FB[3] = VB[1][X4_VROW + (Q) * 64];                          \
         }
-#define X4_MFMA(FA, FB)                                                                          \
+    // One k-step: the y-nesting's VALU work first, then its MFMAs with one hook in front of each (HB < 0: none).  hook(n), n = 0 .. 11
+    // over three consecutive k-steps: staging steps 0 .. 5 (one LDS plane each), then the six loads of the segment after next.
+#define X4_KSTEP(FA, FB, HB)                                                                     \
         if (NEST) {                                                                              \
             const float ds_ = FA[0] + FA[1], dd_ = FA[0] - FA[1];                                \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[0] - FB[2], acc[0], 0, 0, 0); \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds_, FB[1] + FB[2], acc[1], 0, 0, 0);  \
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dd_, FB[2] - FB[1], acc[2], 0, 0, 0);  \
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[3] - FB[1], acc[3], 0, 0, 0); \
-            if (xi == 1) bsum += ds_;                       /* dM_1 = dy0+dy1+dy2+dy3, both rows */ \
+            const float x0_ = FB[0] - FB[2], x1_ = FB[1] + FB[2], x2_ = FB[2] - FB[1], x3_ = FB[3] - FB[1]; \
+            if (xi == 1) { asm volatile("" : "+v"(bsum)); bsum += ds_; }   /* dM_1 = dy0+dy1+dy2+dy3, both rows; the empty asm keeps this a scalar BRANCH: if-converted (v_add + v_cndmask on all twelve waves) it cost every wave two VALU instructions per k-step */ \
+            X4_FENCE(); if ((HB) >= 0) hook((HB) + 0); X4_FENCE();                               \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], x0_, acc[0], 0, 0, 0);          \
+            X4_FENCE(); if ((HB) >= 0) hook((HB) + 1); X4_FENCE();                               \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds_, x1_, acc[1], 0, 0, 0);            \
+            X4_FENCE(); if ((HB) >= 0) hook((HB) + 2); X4_FENCE();                               \
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dd_, x2_, acc[2], 0, 0, 0);            \
+            X4_FENCE(); if ((HB) >= 0) hook((HB) + 3); X4_FENCE();                               \
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], x3_, acc[3], 0, 0, 0);          \
         } else {                                                                                 \
+            if ((HB) >= 0) { hook((HB) + 0); hook((HB) + 1); hook((HB) + 2); hook((HB) + 3); }   \
             _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                   \
                 acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0); \
                 acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
             }                                                                                    \
-            if (xi == 1) bsum += FA[0] + FA[1];             /* dM_1 = dy0+dy1+dy2+dy3 */          \
+            if (xi == 1) { asm volatile("" : "+v"(bsum)); bsum += FA[0] + FA[1]; }   /* dM_1 = dy0+dy1+dy2+dy3 */ \
         }
-        X4_READ(fa0, fb0, 0)
+    const float* db = dmbuf + a_lane;
+    const float* vb[2] = {vring + b_lane, vring + 2 * X4_VROW + b_lane};     // rows (base, base + 1) and (base + 2, base + 3): the base is even, a pair never wraps
+    X4_READ(fa0, fb0, db, vb, 0)
+    int seg = seg_begin;
+#pragma unroll 1
+    for (;;) {
+        // the segment behind this one: ring base (two slots on inside a strip, four at a strip start) and dM buffer
+        const int nbase = (base + (n1_cont ? 2 : 4)) & (X4_RING - 1);
+        // The staging of the segment BEHIND this one (stores; they go to LDS that nobody reads in this segment: the free ring
+        // slots, the other dM buffer) and the loads of the one after that, one step per MFMA of k-steps 2, 3 and 4.
+        auto hook = [&](const int n) {
+            if (n < 6) { if (n1_valid) stage_step(n, base + 4, par ^ 1, !n1_cont); }
+            if (n == 5) {
+                // ... and right behind the last store all loads of the segment after next: woven one per MFMA they were issued up to
+                // 1.5 k-steps later, and that much less lead over their own store point cost 3 us per launch.
+                if (n2.valid && !n2.cont) set_strip(n2.xs, n2.img);
+                // (every staging register has been stored by now, or belongs to a segment that does not exist: told to the compiler
+                // once, or it waits vmcnt(0) in front of EACH of the six loads - for the load before it)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                load_prep(n2);
 #pragma unroll
-        for (int q = 0; q < KQ; q += 2) {
-            X4_READ(fa1, fb1, q + 1)
-            X4_FENCE();
-            X4_MFMA(fa0, fb0)
-            X4_FENCE();
-            if (q + 2 < KQ) X4_READ(fa0, fb0, q + 2)
-            if (q + 1 == X4_STORE_STEP || q == X4_STORE_STEP) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (cont) {
-                    store_stage(base + 4, par ^ 1);
-                    (void)cont2;
-                    load_stage(img, row + 5, row + 4);      // (rows past the image or the slice read zeros through a zero-size descriptor)
-                }
+                for (int t = 0; t < 6; ++t) load_step(t);
             }
-            X4_FENCE();
-            X4_MFMA(fa1, fb1)
-            X4_FENCE();
-        }
-#undef X4_READ
-#undef X4_MFMA
-#undef X4_FENCE
-        if (!cont) break;
+        };
+        X4_READ(fa1, fb1, db, vb, 1)
+        X4_FENCE();
+        X4_KSTEP(fa0, fb0, -1)
+        X4_FENCE();
+        X4_READ(fa0, fb0, db, vb, 2)
+        X4_FENCE();
+        X4_KSTEP(fa1, fb1, -1)
+        X4_FENCE();
+        X4_READ(fa1, fb1, db, vb, 3)
+        X4_FENCE();
+        X4_KSTEP(fa0, fb0, 0)
+        X4_FENCE();
+        X4_READ(fa0, fb0, db, vb, 4)
+        X4_FENCE();
+        X4_KSTEP(fa1, fb1, 4)
+        X4_FENCE();
+        X4_READ(fa1, fb1, db, vb, 5)
+        X4_FENCE();
+        X4_KSTEP(fa0, fb0, -1)
+        X4_FENCE();
+        // The ONE barrier of a segment sits in front of its last k-step: every wave has its last fragments of this segment in
+        // registers (so the NEXT segment's stores may overwrite this segment's rows), every staging store of this segment is
+        // done (so the next segment's first fragments can be read here, under that k-step's MFMAs - until round 4 they were read
+        // behind a barrier at the segment's end, with the matrix pipe idle for their latency).
+        // (behind the slice's last segment the barrier and the read run once more, on rows nobody needs: no branch here)
         __syncthreads();
-        base += 2; if (base >= G4_RING) base -= G4_RING;
-        row += 2;
-        ++seg;
-      }
-      if (seg + 1 >= seg_end) break;
-      // the slice continues in the next strip: its first segment is staged synchronously
-      {
-        const int par = (seg - seg_begin) & 1;
-        __syncthreads();
-        seg_coords(seg + 1, img, xs, row);
-        set_strip(xs, img);
-        stage_strip_start(img, row, par ^ 1);
-        if (seg + 2 < seg_end && row + 2 < a.H) load_stage(img, row + 3, row + 2);
-        __syncthreads();
-        base = 0;
-        ++seg;
-      }
+        db = dmbuf + ((par ^ 1) * 2) * X4_DROW + a_lane;       // (this segment's last fragments are in registers: the pointers move on)
+        vb[0] = vring + nbase * X4_VROW + b_lane;
+        vb[1] = vring + ((nbase + 2) & (X4_RING - 1)) * X4_VROW + b_lane;
+        X4_READ(fa0, fb0, db, vb, 0)
+        X4_FENCE();
+        X4_KSTEP(fa1, fb1, -1)
+        X4_FENCE();
+        base = nbase; par ^= 1;
+        if (!n1_valid) break;
+        n1_valid = n2.valid; n1_cont = n2.cont; ++seg;
+        n2 = seg_after(n2, seg + 2);
     }
+#undef X4_READ
+#undef X4_KSTEP
+#undef X4_FENCE
     __syncthreads();
 
     if (a.bias_part && cit == 0) {     // the xi = 1 waves hold column sums of dy: lane pairs (c, c + 32) meet in LDS, fixed order
@@ -731,8 +832,8 @@ int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, 
     attr_once([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    constexpr size_t ldsx = (size_t)2 * 6 * 3 * 1024 * sizeof(float);      // the variant's G^T staging (147 KB) exceeds its ring (129 KB)
-    static_assert(ldsx >= (size_t)(G4_RING * X4_VROW + 4 * X4_DROW) * sizeof(float) && ldsx <= 160 * 1024, "wgrad-wino4x LDS budget");
+    constexpr size_t ldsx = (size_t)2 * 6 * 3 * 1024 * sizeof(float);      // the variant's G^T staging (144 KiB) = its eight-slot ring + dM buffers
+    static_assert(ldsx >= (size_t)(X4_RING * X4_VROW + 4 * X4_DROW) * sizeof(float) && ldsx <= 160 * 1024, "wgrad-wino4x LDS budget");
     static PesrDeviceOnce attr_once_x;
     attr_once_x([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -38,9 +38,22 @@ def x8_toy_model(weight_seed, bias_seed, device=None):
     import torch.nn.functional as F
     w = torch.round(detrand.uniform((12, 3, 3, 3), int(weight_seed), -1.0, 1.0) * 8) / 8
     b = torch.round(detrand.uniform((12,), int(bias_seed), -1.0, 1.0) * 8) / 8
-    if device is not None:
-        w, b = w.to(device), b.to(device)
-    return lambda x: F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2)
+    if device is None:
+        return lambda x: F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2)
+    # On the GPU the same conv as 27 shifted multiply-adds (elementwise kernels only): torch's own GPU conv2d would bring MIOpen
+    # into the pytest process, and DataLoader workers forked later (test_train_entrypoint_runs) then die with a segmentation fault.
+    wd, bd = w.to(device), b.to(device)
+
+    def model(x):
+        xp = F.pad(x, (1, 1, 1, 1))
+        H, W = x.shape[2], x.shape[3]
+        y = bd.view(1, 12, 1, 1).expand(x.shape[0], 12, H, W).clone()
+        for ci in range(3):
+            for ky in range(3):
+                for kx in range(3):
+                    y = y + wd[:, ci, ky, kx].view(1, 12, 1, 1) * xp[:, ci:ci + 1, ky:ky + H, kx:kx + W]
+        return F.pixel_shuffle(y, 2)
+    return model
 
 
 def close(a, b, rtol=1e-6, atol=0.0, what=""):
