@@ -264,6 +264,9 @@ def main():
                          "step with the best of them - and the timed region runs the fastest (Trainer.calibrate_dp_policy)")
     ap.add_argument("--calib-steps", type=int, default=3, help="timed steps per candidate of --dp-policy auto")
     ap.add_argument("--no-graph-candidate", action="store_true", help="--dp-policy auto: eager candidates only")
+    ap.add_argument("--no-peer-candidate", action="store_true",
+                    help="N > 1: do not time the CU-free gradient exchange over peer memory (comm.PeerCopy: IPC mappings, stream wait / "
+                         "write-value operations, peer copies; rehearsed in child processes first) as a candidate of --dp-policy auto")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side measurements of BASELINE configs 2 and 5 (pretrain step, G forward on 4 x 512x512 LR tiles) that a "
                          "1-GPU run of the default workload appends to its JSON line")
@@ -346,7 +349,8 @@ def main():
     if dp_on and not use_graph:
         # The data-parallel schedule is chosen by measurement, still inside the warm-up (untimed; real optimizer steps)
         if args.dp_policy == "auto":
-            dp_info = trainer.calibrate_dp_policy(args.workload, next_batch, steps=args.calib_steps, graph=not args.no_graph_candidate)
+            dp_info = trainer.calibrate_dp_policy(args.workload, next_batch, steps=args.calib_steps, graph=not args.no_graph_candidate,
+                                                  peer_candidate=not args.no_peer_candidate)
             step = trainer.dp_step
             use_graph = dp_info["chosen"].startswith("graph")
         else:

@@ -307,6 +307,30 @@ int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 int pesr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* state, float beta1, float beta2, float eps,
                        float grad_scale, void* stream);
 
+/* ---- gradient exchange over peer memory (round 5, ABI 15): the replacement of nn.DataParallel's reduce_add (reference
+ * train.py:114-118) as a reduce-scatter + all-gather that keeps no workgroup resident - stream wait / write-value operations and
+ * peer copies on one stream, ONE small kernel over 1/N of the bytes (pesr_amd/csrc/peer_exchange.hip).
+ * pesr_peer_alloc: hipMalloc + zero + the allocation's IPC handle (64 bytes).  pesr_peer_export: IPC handle of the allocation that
+ * CONTAINS ptr, ptr's byte offset in it and the allocation's size.  pesr_peer_open / _close: map / unmap another process's
+ * allocation.  pesr_peer_allreduce: SUM over the ranks, in place, of args->mine (numel % 4 == 0), enqueued on `stream`; all ranks
+ * must call it in the same order with the same numel and the next `epoch` (1, 2, 3, ...). */
+typedef struct PesrPeerArgs {
+    int rank, world;
+    unsigned epoch, pad_;
+    float* mine;
+    float* peer[16];              /* the same tensor in every rank's buffer as mapped in THIS process (peer[rank] == mine) */
+    unsigned* my_flags;           /* [3][16] zero-initialised words of this rank (pesr_peer_alloc), written by the peers */
+    unsigned* peer_flags[16];     /* every rank's flag block as mapped in this process */
+    float* scratch;               /* (world - 1) * ((numel / world rounded up to a multiple of 4)) floats of this rank */
+    size_t numel;
+} PesrPeerArgs;
+int pesr_peer_alloc(size_t bytes, void** ptr, unsigned char* handle64);
+int pesr_peer_free(void* ptr);
+int pesr_peer_export(const void* ptr, unsigned char* handle64, size_t* offset, size_t* alloc_bytes);
+int pesr_peer_open(const unsigned char* handle64, void** base);
+int pesr_peer_close(void* base);
+int pesr_peer_allreduce(const void* args, void* stream);
+
 /* ---- generic k x k conv, odd k != 3 (reference `Conv(in, out, kernel_size, stride, bias)`, model/basic.py:4-7, accepts any
  * kernel size; its networks only use 3): padding k/2, NHWC activations, w OIHW [Cout][Cin][k][k] (not packed).  Plain VALU
  * kernels for completeness - untuned, deterministic.  fwd: y = conv(x, w) + bias (bias may be NULL); dgrad: dx [N][H][W][Cin] from

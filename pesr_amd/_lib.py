@@ -88,6 +88,12 @@ SIGNATURES.update({
     "pesr_psnr_y": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "pesr_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "pesr_adam_step_dev": (c_int, [_P, _P, _P, _P, c_long, _P, c_float, c_float, c_float, c_float, _P]),
+    "pesr_peer_alloc": (c_int, [c_size_t, _P, _P]),
+    "pesr_peer_free": (c_int, [_P]),
+    "pesr_peer_export": (c_int, [_P, _P, _P, _P]),
+    "pesr_peer_open": (c_int, [_P, _P]),
+    "pesr_peer_close": (c_int, [_P]),
+    "pesr_peer_allreduce": (c_int, [_P, _P]),
     "pesr_gan_loss_fwd_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     "pesr_conv_kxk_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pesr_conv_kxk_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

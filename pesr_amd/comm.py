@@ -168,6 +168,175 @@ class DirectRccl(Transport):
             self._comm = ctypes.c_void_p()
 
 
+class _PeerArgs(ctypes.Structure):        # include/pesr_hip.h PesrPeerArgs
+    _fields_ = [("rank", ctypes.c_int), ("world", ctypes.c_int), ("epoch", ctypes.c_uint), ("pad_", ctypes.c_uint),
+                ("mine", ctypes.c_void_p), ("peer", ctypes.c_void_p * 16), ("my_flags", ctypes.c_void_p),
+                ("peer_flags", ctypes.c_void_p * 16), ("scratch", ctypes.c_void_p), ("numel", ctypes.c_size_t)]
+
+
+class PeerCopy(Transport):
+    """Reduce-scatter + all-gather over peer memory (pesr_amd/csrc/peer_exchange.hip): every rank maps the other ranks' flat
+    gradient buffers and flag words through IPC handles; an all-reduce is a sequence of stream wait / write-value operations and
+    peer copies on this transport's stream plus ONE small kernel over 1/N of the bytes - nothing is resident on a compute unit
+    while it waits or copies (RCCL's all-reduce is, and one held CU costs every 256-workgroup conv kernel a second round,
+    profiles/r03_cu_contention.txt).  A slice's sum is formed by one rank in rank order and copied: bit-identical replicas.
+    torch.distributed is used for the one-time exchange of the IPC handles and for host_max (gloo or nccl bootstrap group).
+    Not capturable (stream memory operations under a hipGraph capture are not attempted).  Verified with two processes on ONE
+    GPU (scripts/ipc_probe.py, tests/test_dp_gpu.py `ipc2-one-gpu`); between several GPUs it is rehearsed in child processes
+    before use (`probe_direct(kind="peer")`)."""
+    name = "peer-copy"
+    capturable = False
+    FLAG_BYTES = 4096
+
+    def __init__(self, device: torch.device, rank: int, world: int, group=None):
+        from . import _lib
+        if world > 16:
+            raise CommError("peer-copy transport: at most 16 ranks")
+        self.L = _lib.lib()
+        self.device, self.rank, self.world, self.group = device, rank, world, group
+        self.epoch = 0
+        self.regs = []                   # registered allocations: (base, bytes, [every rank's mapping of its allocation; own = base])
+        self._opened = []
+        self.scratch, self.scratch_bytes = ctypes.c_void_p(), 0
+        with torch.cuda.device(device):
+            self.stream = torch.cuda.Stream(device=device)
+            self.flags = ctypes.c_void_p()
+            h = (ctypes.c_ubyte * 64)()
+            rc = self.L.pesr_peer_alloc(self.FLAG_BYTES, ctypes.byref(self.flags), h)
+            self.peer_flags = self._exchange(bytes(h) if rc == 0 else None, 0, self.flags.value or 0, "the flag block")
+        # self-test: every rank contributes rank + 1 -> world (world + 1) / 2, twice (the epochs count on)
+        t = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
+        keep = torch.zeros(1 << 18, dtype=torch.float32, device=device)       # (keeps `t` a piece of a larger caching-allocator block)
+        for k in (1, 2):
+            self.wait([self.all_reduce_async(t)])
+            torch.cuda.current_stream(device).synchronize()
+            want = float(world * (world + 1) // 2) * world ** (k - 1)
+            if [float(x) for x in t.cpu()] != [want] * 8:
+                raise CommError(f"peer-copy self-test {k}: expected {want}, got {t.cpu().tolist()}")
+        del keep
+
+    def _exchange(self, handle, offset: int, own_ptr: int, what: str):
+        """All ranks' (handle, offset) -> every rank's pointer as mapped here (own: own_ptr).  handle None = this rank could not
+        make one: every rank then raises together (a rank that raised alone would leave the others waiting in the collective)."""
+        mine = (self.rank, handle, int(offset))
+        if self.world == 1:
+            if handle is None:
+                raise CommError(f"peer-copy: {what} failed")
+            return [own_ptr]
+        got = [None] * self.world
+        dist.all_gather_object(got, mine, group=self.group)
+        bad = [r for r, h, _ in got if h is None]
+        out, err = [], None
+        if not bad:
+            for r, h, off in sorted(got):
+                if r == self.rank:
+                    out.append(own_ptr)
+                    continue
+                base = ctypes.c_void_p()
+                hb = (ctypes.c_ubyte * 64).from_buffer_copy(h)
+                with torch.cuda.device(self.device):
+                    rc = self.L.pesr_peer_open(hb, ctypes.byref(base))
+                if rc != 0:
+                    err = f"pesr_peer_open(rank {r}) error {rc}"
+                    break
+                self._opened.append(base)
+                out.append(base.value + off)
+        ok = [None] * self.world
+        dist.all_gather_object(ok, err is None, group=self.group)     # (second round: a mapping that failed on ONE rank stops all)
+        if bad or not all(ok):
+            raise CommError(f"peer-copy: {what} failed on rank(s) {bad or [r for r, v in enumerate(ok) if not v]}" + (f" ({err})" if err else ""))
+        return out
+
+    def _lookup(self, t: torch.Tensor):
+        p = t.data_ptr()
+        for base, nbytes, peers in self.regs:
+            if base <= p and p + t.numel() * 4 <= base + nbytes:
+                return base, peers
+        # first use of this allocation (a flat gradient buffer): all ranks get here in the same order
+        h = (ctypes.c_ubyte * 64)()
+        off, size = ctypes.c_size_t(), ctypes.c_size_t()
+        with torch.cuda.device(self.device):
+            rc = self.L.pesr_peer_export(ctypes.c_void_p(p), h, ctypes.byref(off), ctypes.byref(size))
+        base = p - off.value
+        peers = self._exchange(bytes(h) if rc == 0 else None, 0, base, "the export of a gradient buffer")        # every rank's allocation BASE as mapped here
+        # the same tensor sits at the same offset FROM ITS OWN BASE only if the allocators behaved alike: exchange the offsets too
+        offs = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(offs, (self.rank, off.value), group=self.group)
+        else:
+            offs = [(0, off.value)]
+        self.regs.append((base, size.value, [pb + dict(offs)[r] - off.value for r, pb in enumerate(peers)]))
+        return self.regs[-1][0], self.regs[-1][2]
+
+    def all_reduce_async(self, t: torch.Tensor):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() % 4 == 0, "peer-copy: fp32, numel % 4 == 0"
+        base, peers = self._lookup(t)
+        rel = t.data_ptr() - base
+        slice_elems = ((t.numel() + self.world - 1) // self.world + 3) & ~3
+        need = max(1, self.world - 1) * slice_elems * 4
+        if need > self.scratch_bytes:
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize(self.device)
+                if self.scratch:
+                    self.L.pesr_peer_free(self.scratch)
+                h = (ctypes.c_ubyte * 64)()
+                self.scratch = ctypes.c_void_p()
+                _check_hip(self.L.pesr_peer_alloc(need, ctypes.byref(self.scratch), h), "pesr_peer_alloc(scratch)")
+                self.scratch_bytes = need
+        self.epoch += 1
+        a = _PeerArgs()
+        a.rank, a.world, a.epoch, a.numel = self.rank, self.world, self.epoch, t.numel()
+        a.mine, a.my_flags, a.scratch = t.data_ptr(), self.flags.value, self.scratch.value
+        for r in range(self.world):
+            a.peer[r] = peers[r] + rel        # (peers[r] is rank r's mapping of the address that corresponds to `base`)
+            a.peer_flags[r] = self.peer_flags[r]
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                      # fork: the exchange reads what the current stream has written so far
+        self.stream.wait_event(ready)
+        with torch.cuda.device(self.device):
+            _check_hip(self.L.pesr_peer_allreduce(ctypes.byref(a), ctypes.c_void_p(self.stream.cuda_stream)), "pesr_peer_allreduce")
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return done
+
+    def wait(self, handles) -> None:
+        cur = torch.cuda.current_stream(self.device)
+        for h in handles:
+            cur.wait_event(h)                  # join (the host does not block)
+
+    def host_max(self, values: List[float]) -> List[float]:
+        if self.world == 1:
+            torch.cuda.synchronize(self.device)
+            return list(values)
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor(values, dtype=torch.float64, device=self.device if on_gpu else "cpu")
+        torch.cuda.synchronize(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return [float(x) for x in t.cpu()]
+
+    def begin_capture(self) -> None:
+        raise CommError("the peer-copy transport's stream memory operations are not captured into a hipGraph: use the eager step")
+
+    def close(self) -> None:
+        if self.flags:
+            torch.cuda.synchronize(self.device)
+            if self.world > 1:
+                dist.barrier(group=self.group)          # nobody unmaps a buffer a peer may still be reading
+            for b in self._opened:
+                self.L.pesr_peer_close(b)
+            self._opened = []
+            if self.scratch:
+                self.L.pesr_peer_free(self.scratch)
+            self.L.pesr_peer_free(self.flags)
+            self.flags, self.scratch = ctypes.c_void_p(), ctypes.c_void_p()
+
+
+def _check_hip(rc: int, what: str) -> None:
+    if rc != 0:
+        raise CommError(f"{what}: error {rc}")
+
+
 class TorchGroup(Transport):
     capturable = False
 
@@ -195,8 +364,8 @@ class TorchGroup(Transport):
                         "events of the streams that join the capture): use the direct RCCL transport (PESR_DP_TRANSPORT=rccl or auto)")
 
 
-def probe_direct(device: Optional[torch.device], group=None, timeout: Optional[float] = None):
-    """Can the direct RCCL transport come up among THESE ranks?  Answered in child processes (`pesr_amd.comm_probe`, one per rank,
+def probe_direct(device: Optional[torch.device], group=None, timeout: Optional[float] = None, kind: str = "rccl"):
+    """Can the direct RCCL transport (kind "rccl") / the peer-memory transport (kind "peer") come up among THESE ranks?  Answered in child processes (`pesr_amd.comm_probe`, one per rank,
     rendezvous among themselves over gloo on a port rank 0 picks): communicator, a 32 MB all-reduce with a known answer, a MAX
     all-reduce, teardown.  A child that has not exited after `timeout` seconds (env PESR_DP_PROBE_TIMEOUT, default 180) is killed.
     Returns (ok on THIS rank, reason); the caller agrees the answer over the ranks.  Why a child: `ncclCommInitRank` called through
@@ -218,9 +387,13 @@ def probe_direct(device: Optional[torch.device], group=None, timeout: Optional[f
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     index = device.index if device is not None and device.type == "cuda" and device.index is not None else 0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
+    # The children rendezvous among themselves: nothing of the launcher's environment may reach them - with torchrun's
+    # TORCHELASTIC_USE_AGENT_STORE set, init_process_group would look for the launcher's store on the probe's port and wait for ever
+    drop = {"RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+            "ROLE_NAME", "MASTER_PORT", "PESR_FORCE_DP"}
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC")}
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-    cmd = [sys.executable, "-m", "pesr_amd.comm_probe", str(rank), str(world), str(index), addr, str(port[0]), str(max(10.0, timeout - 10.0))]
+    cmd = [sys.executable, "-m", "pesr_amd.comm_probe", str(rank), str(world), str(index), addr, str(port[0]), str(max(10.0, timeout - 10.0)), kind]
     try:
         p = subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     except OSError as e:
@@ -229,8 +402,9 @@ def probe_direct(device: Optional[torch.device], group=None, timeout: Optional[f
         _, err = p.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
         p.kill()
-        p.communicate()
-        return False, f"probe child still running after {timeout:.0f} s (killed)"
+        _, err = p.communicate()
+        marks = [l for l in err.decode(errors="replace").splitlines() if l.startswith("comm_probe:")]
+        return False, f"probe child still running after {timeout:.0f} s (killed)" + (f"; last step: {marks[-1][12:]}" if marks else "")
     if p.returncode != 0:
         tail = err.decode(errors="replace").strip().splitlines()[-1:] or [""]
         return False, f"probe child exited {p.returncode}: {tail[0][:300]}"
@@ -246,9 +420,11 @@ def make_transport(device: Optional[torch.device], group=None, prefer: Optional[
     not a hung job.  Should the communicator then still fail in this process on ANY rank with an exception, all ranks fall
     back together (agreed by a MIN all-reduce); the reason is kept in `.fallback_reason`."""
     prefer = prefer or os.environ.get("PESR_DP_TRANSPORT", "auto")
-    if prefer not in ("auto", "rccl", "torch"):
-        raise ValueError(f"PESR_DP_TRANSPORT must be auto, rccl or torch, got {prefer!r}")
+    if prefer not in ("auto", "rccl", "torch", "peer"):
+        raise ValueError(f"PESR_DP_TRANSPORT must be auto, rccl, torch or peer, got {prefer!r}")
     backend = dist.get_backend(group)
+    if prefer == "peer":       # explicit only: the CU-free exchange over peer memory (never chosen by "auto"; Trainer.calibrate_dp_policy
+        return PeerCopy(device, dist.get_rank(group), dist.get_world_size(group), group)      # can time it as a candidate)
     want_direct = prefer == "rccl" or (prefer == "auto" and backend == "nccl" and device is not None and device.type == "cuda")
     if not want_direct:
         return TorchGroup(group)

@@ -4,7 +4,9 @@ several GPUs - a path no single-GPU box can execute - it hangs or fails HERE, in
 processes fall back to torch.distributed together instead of hanging in `ncclCommInitRank` (replaces nothing of the reference:
 the guard of the replacement of nn.DataParallel, reference train.py:114-118).
 
-    python -m pesr_amd.comm_probe <rank> <world> <cuda device index> <addr> <port> <rendezvous timeout s>
+    python -m pesr_amd.comm_probe <rank> <world> <cuda device index> <addr> <port> <rendezvous timeout s> [rccl|peer]
+(`peer`: the same rehearsal for the peer-memory transport, comm.PeerCopy - IPC mappings between the GPUs, stream wait / write-value
+operations across them, peer copies.)
 """
 import datetime
 import sys
@@ -12,18 +14,25 @@ import sys
 
 def main(argv) -> int:
     rank, world, dev, addr, port, timeout = int(argv[0]), int(argv[1]), int(argv[2]), argv[3], int(argv[4]), float(argv[5])
+    kind = argv[6] if len(argv) > 6 else "rccl"
     import torch
     import torch.distributed as dist
     from pesr_amd import comm
+
+    def mark(what):                       # (the parent quotes the last mark if it has to kill this process)
+        print(f"comm_probe: {what}", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         print("comm_probe: no GPU visible", file=sys.stderr)
         return 3
     device = torch.device("cuda", dev)
     torch.cuda.set_device(device)
     # bootstrap over gloo: nothing of ProcessGroupNCCL in this process, the unique id travels as a CPU tensor
+    mark("rendezvous")
     dist.init_process_group("gloo", init_method=f"tcp://{addr}:{port}", rank=rank, world_size=world,
                             timeout=datetime.timedelta(seconds=timeout))
-    tr = comm.DirectRccl(device, rank, world, None)               # includes a 4-element self-test
+    mark("communicator")
+    tr = comm.PeerCopy(device, rank, world, None) if kind == "peer" else comm.DirectRccl(device, rank, world, None)   # (each includes a small self-test)
+    mark("32 MB all-reduce")
     n = 8 << 20                                                   # one 32 MB bucket
     t = torch.full((n,), float(rank + 1), dtype=torch.float32, device=device)
     tr.wait([tr.all_reduce_async(t)])
@@ -33,12 +42,15 @@ def main(argv) -> int:
     if got != (want, want, want):
         print(f"comm_probe: all-reduce gave {got}, expected {want}", file=sys.stderr)
         return 4
+    mark("host_max")
     m = tr.host_max([float(rank)])
     if m != [float(world - 1)]:
         print(f"comm_probe: MAX all-reduce gave {m}", file=sys.stderr)
         return 5
+    mark("close")
     tr.close()
     dist.destroy_process_group()
+    mark("done")
     return 0
 
 

@@ -1,0 +1,137 @@
+// Gradient exchange that holds no compute unit while it waits or moves bytes (round 5): the replacement of nn.DataParallel's
+// reduce_add (reference train.py:114-118) as a reduce-scatter + all-gather over PEER MEMORY.  Every rank maps the other ranks'
+// flat gradient buffers and flag words through IPC handles; an all-reduce of a slice is then, enqueued on ONE stream of the rank:
+//     tell every peer "my gradients of this epoch are final"          hipStreamWriteValue32 into the peers' flag words
+//     for every peer: wait for its word, copy MY 1/N of its buffer     hipStreamWaitValue32 (the command processor polls: no wave is
+//                                                                      resident), hipMemcpyAsync out of the mapping (copy engines
+//                                                                      between devices)
+//     sum the N copies of my 1/N in rank order                         peer_reduce_kernel: the one kernel, over 1/N of the bytes
+//     tell every peer "my 1/N is reduced"; for every peer: wait, copy ITS reduced 1/N into my buffer
+//     tell every peer "I have read your buffer"; wait for the same from everybody (their reads of MY buffer are over: it may be
+//     written again)
+// The sum of a slice is formed by exactly one rank, in the fixed order rank 0 .. N-1, and copied: replicas hold bit-identical
+// gradients.  RCCL's all-reduce keeps workgroups resident for the whole transfer, and ONE held compute unit costs every
+// 256-workgroup conv kernel a second round (x 1.82, profiles/r03_cu_contention.txt).  The flag words count epochs upwards (waits are
+// ">="), so nothing is ever reset.  Primitives verified on this runtime with two processes on one GPU: scripts/ipc_probe.py.
+#include <cstring>
+#include "common.h"
+
+namespace {
+constexpr int PEER_MAX = 16;
+
+struct PeerArgs {           // mirrors PesrPeerArgs of include/pesr_hip.h
+    int rank, world;
+    unsigned epoch;
+    unsigned pad_;
+    float* mine;                      // my tensor (a slice of the flat gradient buffer), numel floats
+    float* peer[PEER_MAX];            // the same slice in every rank's buffer as mapped HERE (peer[rank] == mine)
+    unsigned* my_flags;               // [3][PEER_MAX] words the peers write: READY, REDUCED, DONE
+    unsigned* peer_flags[PEER_MAX];   // every rank's flag block as mapped here
+    float* scratch;                   // (world - 1) x slice floats, this rank's own memory
+    size_t numel;
+};
+
+__global__ __launch_bounds__(256) void peer_reduce_kernel(float* __restrict__ mine, const float* __restrict__ scratch, int world, int rank,
+                                                          size_t n4, size_t slice4) {
+    // out = ((x_0 + x_1) + x_2) + ... in rank order; x_rank is my own slice, x_q (q != rank) the copy in scratch slot q - (q > rank)
+    f32x4* const m = (f32x4*)mine;
+    const f32x4* const s = (const f32x4*)scratch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 acc = rank == 0 ? m[i] : s[i];
+        for (int q = 1; q < world; ++q) acc += q == rank ? m[i] : s[(size_t)(q - (q > rank ? 1 : 0)) * slice4 + i];
+        m[i] = acc;
+    }
+}
+}  // namespace
+
+PESR_API int pesr_peer_alloc(size_t bytes, void** ptr, unsigned char* handle64) {
+    if (!ptr || !handle64 || !bytes) return PESR_EINVAL;
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(*ptr, 0, bytes);
+    if (e != hipSuccess) return (int)e;
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, *ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    std::memcpy(handle64, &h, 64);
+    return PESR_OK;
+}
+
+PESR_API int pesr_peer_free(void* ptr) { return (int)hipFree(ptr); }
+
+// IPC handle of the ALLOCATION that contains ptr (the caching allocator hands out pieces of its blocks) and ptr's offset in it.
+PESR_API int pesr_peer_export(const void* ptr, unsigned char* handle64, size_t* offset, size_t* alloc_bytes) {
+    if (!ptr || !handle64 || !offset) return PESR_EINVAL;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, (void*)base);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    std::memcpy(handle64, &h, 64);
+    *offset = (size_t)((const char*)ptr - (const char*)base);
+    if (alloc_bytes) *alloc_bytes = size;
+    return PESR_OK;
+}
+
+PESR_API int pesr_peer_open(const unsigned char* handle64, void** base) {
+    if (!handle64 || !base) return PESR_EINVAL;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle64, 64);
+    const hipError_t e = hipIpcOpenMemHandle(base, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return (int)e;
+}
+
+PESR_API int pesr_peer_close(void* base) { return (int)hipIpcCloseMemHandle(base); }
+
+PESR_API int pesr_peer_allreduce(const void* args, void* stream_) {
+    const PeerArgs& a = *(const PeerArgs*)args;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (a.world < 1 || a.world > PEER_MAX || a.rank < 0 || a.rank >= a.world || (a.numel & 3) || !a.mine || !a.my_flags) return PESR_EINVAL;
+    if (a.world == 1) return PESR_OK;
+    const size_t slice = ((a.numel + a.world - 1) / a.world + 3) & ~(size_t)3;          // floats per rank, a multiple of 4
+    auto lo = [&](int r) { const size_t v = (size_t)r * slice; return v < a.numel ? v : a.numel; };
+    auto len = [&](int r) { return lo(r + 1) - lo(r); };
+    enum { READY = 0, REDUCED = 1, DONE = 2 };
+    hipError_t e = hipSuccess;
+#define PEER_CK(X) do { e = (X); if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; } } while (0)
+    auto tell = [&](int kind) -> hipError_t {
+        for (int d = 1; d < a.world; ++d) {
+            const int p = (a.rank + d) % a.world;
+            const hipError_t r = hipStreamWriteValue32(stream, a.peer_flags[p] + kind * PEER_MAX + a.rank, a.epoch, 0);
+            if (r != hipSuccess) return r;
+        }
+        return hipSuccess;
+    };
+    auto await = [&](int kind, int p) { return hipStreamWaitValue32(stream, a.my_flags + kind * PEER_MAX + p, a.epoch, hipStreamWaitValueGte, 0xffffffffu); };
+    // 1. reduce-scatter: my slice of every peer's buffer -> scratch, then the one kernel
+    PEER_CK(tell(READY));
+    const size_t my_n = len(a.rank);
+    for (int d = 1; d < a.world; ++d) {
+        const int p = (a.rank + d) % a.world;
+        PEER_CK(await(READY, p));
+        if (my_n) PEER_CK(hipMemcpyAsync(a.scratch + (size_t)(p - (p > a.rank ? 1 : 0)) * slice, a.peer[p] + lo(a.rank), my_n * sizeof(float),
+                                         hipMemcpyDefault, stream));
+    }
+    if (my_n) {
+        const size_t n4 = my_n >> 2;
+        const unsigned grid = (unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+        hipLaunchKernelGGL(peer_reduce_kernel, dim3(grid), dim3(256), 0, stream, a.mine + lo(a.rank), a.scratch, a.world, a.rank, n4, slice >> 2);
+        const int rc = pesr_launch_status();
+        if (rc) return rc;
+    }
+    // 2. all-gather: every peer's reduced slice -> my buffer (a peer has read MY copy of its slice before it says REDUCED)
+    PEER_CK(tell(REDUCED));
+    for (int d = 1; d < a.world; ++d) {
+        const int p = (a.rank + d) % a.world;
+        PEER_CK(await(REDUCED, p));
+        if (len(p)) PEER_CK(hipMemcpyAsync(a.mine + lo(p), a.peer[p] + lo(p), len(p) * sizeof(float), hipMemcpyDefault, stream));
+    }
+    // 3. nobody reads my buffer any more once every peer says DONE: only then may the stream's next work write it
+    PEER_CK(tell(DONE));
+    for (int d = 1; d < a.world; ++d) PEER_CK(await(DONE, (a.rank + d) % a.world));
+#undef PEER_CK
+    return PESR_OK;
+}

@@ -262,11 +262,21 @@ class Trainer:
             self.optim_D.buckets.set_mode(d_mode)
         self.dp_policy = name
 
-    def calibrate_dp_policy(self, kind, next_batch, steps=3, graph=True, candidates=None, margin=0.015):
+    def set_dp_transport(self, tr) -> None:
+        """Every optimizer's gradient exchange moves to transport `tr` (between steps)."""
+        for o in (self.optim_D, self.optim_G):
+            if o is not None and o.buckets.enabled:
+                assert not any(o.buckets._launched)
+                o.buckets.transport = tr
+
+    def calibrate_dp_policy(self, kind, next_batch, steps=3, graph=True, candidates=None, margin=0.015, peer_candidate=False):
         """Pick the data-parallel schedule by timing it (call it inside the warm-up, on every rank, after at least two eager
         steps).  Each eager candidate of DP_POLICIES runs one untimed step (the policy switch) and `steps` timed ones; then,
         if the transport is capturable, the step is captured as a hipGraph with the best eager bucket policy and its replays
-        are timed the same way.  Every rank uses the SLOWEST rank's time per candidate (Transport.host_max), so all ranks
+        are timed the same way.  peer_candidate (more than one rank, each with its own GPU): the CU-free exchange over peer memory
+        (comm.PeerCopy) is first rehearsed in child processes (comm.probe_direct kind "peer": a hang there costs killed children,
+        not the job), then timed under the "overlap" schedule as `overlap@peer-copy`; it replaces the transport only if it wins.
+        Every rank uses the SLOWEST rank's time per candidate (Transport.host_max), so all ranks
         choose alike.  The first candidate ("overlap") stays unless another one is faster by more than `margin` (1.5 %): the
         bucket schedule decides RCCL's reduction order, i.e. the last bits of a run, and that must not hang on a 0.1 % timing
         race between equally good schedules (a graph replay keeps its eager policy's order: plain "faster" decides).  Returns {"chosen", "ms_per_step": {candidate: ms}, "graph_error",
@@ -303,6 +313,33 @@ class Trainer:
         best = min(faster, key=lambda c: (ms[c], cands.index(c))) if faster else cands[0]
         self.set_dp_policy(best)
         self.dp_step, chosen, graph_error = eager, best, None
+        peer_note = None
+        if peer_candidate and tr.world > 1 and tr.name != "peer-copy":
+            from . import comm
+            dev = (self.optim_G or self.optim_D).flat.flat_g.device
+            group = (self.optim_G or self.optim_D).buckets.group
+            ok_here, why = comm.probe_direct(dev, group, kind="peer")
+            (bad,) = tr.host_max([0.0 if ok_here else 1.0])
+            if bad:
+                peer_note = "probe: " + (why or "another rank's probe failed")
+            else:
+                ptr_ = None
+                try:
+                    ptr_ = comm.PeerCopy(dev, comm.dist.get_rank(group), tr.world, group)
+                except Exception as e:                   # (PeerCopy's constructor fails on every rank or on none)
+                    peer_note = f"{type(e).__name__}: {e}"
+                if ptr_ is not None:
+                    self.set_dp_transport(ptr_)
+                    self.set_dp_policy("overlap")
+                    (t_peer,) = tr.host_max([timed(eager)])
+                    ms["overlap@peer-copy"] = t_peer
+                    if t_peer < ms[best] * (1.0 - margin):
+                        chosen, tr = "overlap@peer-copy", ptr_
+                        graph = False                    # (not capturable)
+                    else:
+                        self.set_dp_transport(tr)
+                        self.set_dp_policy(best)
+                        ptr_.close()
         if graph and tr.capturable:
             fn, err = None, None
             try:
@@ -325,7 +362,7 @@ class Trainer:
                 else:
                     self._graph.pop(kind, None)         # frees the graph's private memory pool
         return {"chosen": chosen, "ms_per_step": {k: round(v, 3) for k, v in ms.items()}, "graph_error": graph_error,
-                "transport": tr.name, "steps_per_candidate": steps, "margin": margin}
+                "transport": tr.name, "steps_per_candidate": steps, "margin": margin, "peer_candidate": peer_note or ("timed" if "overlap@peer-copy" in ms else "off")}
 
     def _replay(self, kind, lr, hr, gp_u=None):
         assert self._graph and kind in self._graph, f"capture_{kind}_step first"

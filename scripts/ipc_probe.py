@@ -20,12 +20,13 @@ def hip():
 
 def ck(rc, what):
     ok = rc == 0
+    hip().hipGetLastError()                    # (clears the sticky error: torch would otherwise raise it on its next call)
     print(f"  [{os.getpid()}] {what}: {'ok' if ok else 'FAILED rc=%d %s' % (rc, hip().hipGetErrorString(rc).decode())}", flush=True)
     return ok
 
 
 class IpcMemHandle(ctypes.Structure):
-    _fields_ = [("reserved", ctypes.c_char * 64)]
+    _fields_ = [("reserved", ctypes.c_ubyte * 64)]      # (c_char would hand back bytes cut at the first NUL)
 
 
 def child(rank, q01, q10):
@@ -37,8 +38,16 @@ def child(rank, q01, q10):
     attr = ctypes.c_int(0)
     H.hipDeviceGetAttribute(ctypes.byref(attr), 10071 if False else 0, 0)        # (placeholder; the enum value is looked up below)
     # -- plain device memory: a data buffer and a flag word, exported over IPC
-    data = torch.full((1 << 20,), float(rank + 1), device="cuda")
-    flag = torch.zeros(64, dtype=torch.int32, device="cuda")
+    # (own hipMalloc allocations: an IPC handle names a whole allocation, and torch's caching allocator hands out pieces of its blocks)
+    class Raw:
+        def __init__(self, nbytes):
+            self.p = ctypes.c_void_p(); assert H.hipMalloc(ctypes.byref(self.p), ctypes.c_size_t(nbytes)) == 0
+            H.hipMemset(self.p, 0, ctypes.c_size_t(nbytes)); self.n = nbytes
+        def data_ptr(self): return self.p.value
+    data, flag = Raw(4 << 20), Raw(256)
+    fill = torch.full((1 << 20,), float(rank + 1), device="cuda")
+    H.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    H.hipMemcpy(ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(fill.data_ptr()), ctypes.c_size_t(4 << 20), 3)
     torch.cuda.synchronize()
     hd, hf = IpcMemHandle(), IpcMemHandle()
     ok = ck(H.hipIpcGetMemHandle(ctypes.byref(hd), ctypes.c_void_p(data.data_ptr())), "hipIpcGetMemHandle(data)")
@@ -65,7 +74,9 @@ def child(rank, q01, q10):
     w_plain = ck(H.hipStreamWriteValue32(sp, ctypes.c_void_p(flag.data_ptr() + 4), 7, 0), "hipStreamWriteValue32(own plain memory)")
     wt_plain = ck(H.hipStreamWaitValue32(sp, ctypes.c_void_p(flag.data_ptr() + 4), 7, 0, 0xffffffff), "hipStreamWaitValue32(own plain memory, GEQ)")
     s.synchronize()
-    print(f"  [{os.getpid()}] own flag word after stream write: {int(flag[1])}", flush=True)
+    w = torch.zeros(4, dtype=torch.int32, device="cuda")
+    H.hipMemcpy(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(flag.data_ptr()), ctypes.c_size_t(16), 3)
+    print(f"  [{os.getpid()}] own flag word after stream write: {int(w[1])}", flush=True)
     # -- the hand-off: each rank waits (on its copy stream) until the PEER has written 1 into its flag word 0 through the IPC mapping,
     #    then copies the peer's data buffer device-to-device and checks it
     got = torch.zeros(1 << 20, device="cuda")
@@ -89,7 +100,8 @@ def child(rank, q01, q10):
         print(f"  [{os.getpid()}] rank {rank}: wait + copy {'completed' if done else 'DID NOT COMPLETE in 10 s'} after {time.time() - t0:.2f} s; "
               f"copied value {float(got[0]) if done else 'n/a'} (expected {float(2 - rank)})", flush=True)
         if not done:
-            flag[0] = 1          # release the stream so that the process can exit
+            one = torch.ones(1, dtype=torch.int32, device="cuda")          # release the stream so that the process can exit
+            H.hipMemcpy(ctypes.c_void_p(flag.data_ptr()), ctypes.c_void_p(one.data_ptr()), ctypes.c_size_t(4), 3)
             torch.cuda.synchronize()
     qout.put("done"); qin.get(timeout=60)
 

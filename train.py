@@ -64,6 +64,9 @@ def build_parser():
                    help="capture the train step into a hipGraph after two eager iterations and replay it (same results bit for "
                         "bit; the host no longer issues ~1000 launches per step).  auto = on for a single-GPU run; under "
                         "torch.distributed the captured step (RCCL all-reduces included) is one candidate of --dp_policy auto")
+    p.add_argument("--dp_peer_candidate", type=str, default="true",
+                   help="--dp_policy auto also times the CU-free gradient exchange over peer memory (pesr_amd/comm.py PeerCopy), after a "
+                        "rehearsal in child processes; it replaces RCCL only if it is faster")
     p.add_argument("--dp_policy", type=str, default="auto", choices=["auto", "overlap", "defer_g", "defer_all"],
                    help="under torch.distributed: how the gradient all-reduces are scheduled against the backward kernels.  auto = "
                         "measured during the first iterations (Trainer.calibrate_dp_policy: eager overlap, G's exchange deferred behind "
@@ -308,7 +311,7 @@ def main(argv=None):
                 if dp_calibrate and iters >= 1 and n_iters - consumed[0] >= calib_need:
                     # every rank is at the same iteration of equally long loaders: the calibration's collectives line up.  Its
                     # steps are real training steps (their losses are not added to this epoch's averages).
-                    info = trainer.calibrate_dp_policy("gan" if gan else "pretrain", next_batch, steps=CALIB_STEPS,
+                    info = trainer.calibrate_dp_policy("gan" if gan else "pretrain", next_batch, steps=CALIB_STEPS, peer_candidate=str2bool(args.dp_peer_candidate),
                                                        graph=args.hip_graph == "auto")
                     dp_calibrate = False
                     if rank == 0:
