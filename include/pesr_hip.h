@@ -323,7 +323,10 @@ typedef struct PesrPeerArgs {
     unsigned* peer_flags[16];     /* every rank's flag block as mapped in this process */
     float* scratch;               /* (world - 1) * ((numel / world rounded up to a multiple of 4)) floats of this rank */
     size_t numel;
+    void* ctx;                    /* pesr_peer_ctx_create(world): one side stream + event per peer, so that a phase's copies use all links at once */
 } PesrPeerArgs;
+int pesr_peer_ctx_create(int world, void** ctx);
+int pesr_peer_ctx_destroy(void* ctx);
 int pesr_peer_alloc(size_t bytes, void** ptr, unsigned char* handle64);
 int pesr_peer_free(void* ptr);
 int pesr_peer_export(const void* ptr, unsigned char* handle64, size_t* offset, size_t* alloc_bytes);

@@ -171,7 +171,7 @@ class DirectRccl(Transport):
 class _PeerArgs(ctypes.Structure):        # include/pesr_hip.h PesrPeerArgs
     _fields_ = [("rank", ctypes.c_int), ("world", ctypes.c_int), ("epoch", ctypes.c_uint), ("pad_", ctypes.c_uint),
                 ("mine", ctypes.c_void_p), ("peer", ctypes.c_void_p * 16), ("my_flags", ctypes.c_void_p),
-                ("peer_flags", ctypes.c_void_p * 16), ("scratch", ctypes.c_void_p), ("numel", ctypes.c_size_t)]
+                ("peer_flags", ctypes.c_void_p * 16), ("scratch", ctypes.c_void_p), ("numel", ctypes.c_size_t), ("ctx", ctypes.c_void_p)]
 
 
 class PeerCopy(Transport):
@@ -198,8 +198,10 @@ class PeerCopy(Transport):
         self.regs = []                   # registered allocations: (base, bytes, [every rank's mapping of its allocation; own = base])
         self._opened = []
         self.scratch, self.scratch_bytes = ctypes.c_void_p(), 0
+        self.ctx = ctypes.c_void_p()
         with torch.cuda.device(device):
             self.stream = torch.cuda.Stream(device=device)
+            _check_hip(self.L.pesr_peer_ctx_create(world, ctypes.byref(self.ctx)), "pesr_peer_ctx_create")
             self.flags = ctypes.c_void_p()
             h = (ctypes.c_ubyte * 64)()
             rc = self.L.pesr_peer_alloc(self.FLAG_BYTES, ctypes.byref(self.flags), h)
@@ -286,7 +288,7 @@ class PeerCopy(Transport):
         self.epoch += 1
         a = _PeerArgs()
         a.rank, a.world, a.epoch, a.numel = self.rank, self.world, self.epoch, t.numel()
-        a.mine, a.my_flags, a.scratch = t.data_ptr(), self.flags.value, self.scratch.value
+        a.mine, a.my_flags, a.scratch, a.ctx = t.data_ptr(), self.flags.value, self.scratch.value, self.ctx.value
         for r in range(self.world):
             a.peer[r] = peers[r] + rel        # (peers[r] is rank r's mapping of the address that corresponds to `base`)
             a.peer_flags[r] = self.peer_flags[r]
@@ -329,7 +331,8 @@ class PeerCopy(Transport):
             if self.scratch:
                 self.L.pesr_peer_free(self.scratch)
             self.L.pesr_peer_free(self.flags)
-            self.flags, self.scratch = ctypes.c_void_p(), ctypes.c_void_p()
+            self.L.pesr_peer_ctx_destroy(self.ctx)
+            self.flags, self.scratch, self.ctx = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
 
 
 def _check_hip(rc: int, what: str) -> None:
@@ -465,6 +468,12 @@ def get_transport(device: Optional[torch.device], group=None) -> Transport:
     if tr is None:
         tr = _TRANSPORTS[key] = make_transport(device, group)
     return tr
+
+
+def adopt_transport(tr: Transport) -> None:
+    """A transport made outside get_transport() (Trainer.calibrate_dp_policy's peer-memory candidate, once it has won) is closed by
+    close_transports() too - every rank adopts it at the same point, so the shutdown's collectives line up."""
+    _TRANSPORTS[("adopted", len(_TRANSPORTS))] = tr
 
 
 def close_transports() -> None:

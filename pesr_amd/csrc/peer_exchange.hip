@@ -2,8 +2,8 @@
 // reduce_add (reference train.py:114-118) as a reduce-scatter + all-gather over PEER MEMORY.  Every rank maps the other ranks'
 // flat gradient buffers and flag words through IPC handles; an all-reduce of a slice is then, enqueued on ONE stream of the rank:
 //     tell every peer "my gradients of this epoch are final"          hipStreamWriteValue32 into the peers' flag words
-//     for every peer: wait for its word, copy MY 1/N of its buffer     hipStreamWaitValue32 (the command processor polls: no wave is
-//                                                                      resident), hipMemcpyAsync out of the mapping (copy engines
+//     for every peer (one side stream each): wait for its word, copy   hipStreamWaitValue32 (the command processor polls: no wave is
+//       MY 1/N of its buffer                                           resident), hipMemcpyAsync out of the mapping (copy engines
 //                                                                      between devices)
 //     sum the N copies of my 1/N in rank order                         peer_reduce_kernel: the one kernel, over 1/N of the bytes
 //     tell every peer "my 1/N is reduced"; for every peer: wait, copy ITS reduced 1/N into my buffer
@@ -29,6 +29,13 @@ struct PeerArgs {           // mirrors PesrPeerArgs of include/pesr_hip.h
     unsigned* peer_flags[PEER_MAX];   // every rank's flag block as mapped here
     float* scratch;                   // (world - 1) x slice floats, this rank's own memory
     size_t numel;
+    void* ctx;                        // pesr_peer_ctx_create(): one side stream per peer (the copies of a phase run on all links at once)
+};
+
+struct PeerCtx {
+    hipStream_t side[PEER_MAX];
+    hipEvent_t fork, join[PEER_MAX];
+    int n;
 };
 
 __global__ __launch_bounds__(256) void peer_reduce_kernel(float* __restrict__ mine, const float* __restrict__ scratch, int world, int rank,
@@ -86,6 +93,29 @@ PESR_API int pesr_peer_open(const unsigned char* handle64, void** base) {
 
 PESR_API int pesr_peer_close(void* base) { return (int)hipIpcCloseMemHandle(base); }
 
+PESR_API int pesr_peer_ctx_create(int world, void** ctx) {
+    if (!ctx || world < 1 || world > PEER_MAX) return PESR_EINVAL;
+    PeerCtx* c = new PeerCtx();
+    c->n = world - 1;
+    hipError_t e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+    for (int i = 0; i < c->n && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); delete c; return (int)e; }
+    *ctx = c;
+    return PESR_OK;
+}
+
+PESR_API int pesr_peer_ctx_destroy(void* ctx) {
+    PeerCtx* c = (PeerCtx*)ctx;
+    if (!c) return PESR_OK;
+    (void)hipEventDestroy(c->fork);
+    for (int i = 0; i < c->n; ++i) { (void)hipStreamDestroy(c->side[i]); (void)hipEventDestroy(c->join[i]); }
+    delete c;
+    return PESR_OK;
+}
+
 PESR_API int pesr_peer_allreduce(const void* args, void* stream_) {
     const PeerArgs& a = *(const PeerArgs*)args;
     hipStream_t stream = (hipStream_t)stream_;
@@ -106,15 +136,34 @@ PESR_API int pesr_peer_allreduce(const void* args, void* stream_) {
         return hipSuccess;
     };
     auto await = [&](int kind, int p) { return hipStreamWaitValue32(stream, a.my_flags + kind * PEER_MAX + p, a.epoch, hipStreamWaitValueGte, 0xffffffffu); };
+    // A phase's waits and copies run on one side stream per peer - all xGMI links at once -, forked from and joined back into
+    // `stream` by events (a wait for one slow peer does not hold up the copies from the others).
+    PeerCtx* const c = (PeerCtx*)a.ctx;
+    if (!c || c->n != a.world - 1) return PESR_EINVAL;
+    auto phase = [&](int kind, bool gather) -> hipError_t {
+        hipError_t r = hipEventRecord(c->fork, stream);
+        for (int d = 1; d < a.world && r == hipSuccess; ++d) {
+            const int p = (a.rank + d) % a.world;
+            hipStream_t s = c->side[d - 1];
+            r = hipStreamWaitEvent(s, c->fork, 0);
+            if (r == hipSuccess) r = hipStreamWaitValue32(s, a.my_flags + kind * PEER_MAX + p, a.epoch, hipStreamWaitValueGte, 0xffffffffu);
+            if (r == hipSuccess) {
+                if (!gather) {       // my slice of peer p's buffer -> scratch
+                    if (len(a.rank)) r = hipMemcpyAsync(a.scratch + (size_t)(p - (p > a.rank ? 1 : 0)) * slice, a.peer[p] + lo(a.rank),
+                                                        len(a.rank) * sizeof(float), hipMemcpyDefault, s);
+                } else if (len(p)) { // peer p's reduced slice -> my buffer
+                    r = hipMemcpyAsync(a.mine + lo(p), a.peer[p] + lo(p), len(p) * sizeof(float), hipMemcpyDefault, s);
+                }
+            }
+            if (r == hipSuccess) r = hipEventRecord(c->join[d - 1], s);
+            if (r == hipSuccess) r = hipStreamWaitEvent(stream, c->join[d - 1], 0);
+        }
+        return r;
+    };
     // 1. reduce-scatter: my slice of every peer's buffer -> scratch, then the one kernel
     PEER_CK(tell(READY));
+    PEER_CK(phase(READY, false));
     const size_t my_n = len(a.rank);
-    for (int d = 1; d < a.world; ++d) {
-        const int p = (a.rank + d) % a.world;
-        PEER_CK(await(READY, p));
-        if (my_n) PEER_CK(hipMemcpyAsync(a.scratch + (size_t)(p - (p > a.rank ? 1 : 0)) * slice, a.peer[p] + lo(a.rank), my_n * sizeof(float),
-                                         hipMemcpyDefault, stream));
-    }
     if (my_n) {
         const size_t n4 = my_n >> 2;
         const unsigned grid = (unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
@@ -124,11 +173,7 @@ PESR_API int pesr_peer_allreduce(const void* args, void* stream_) {
     }
     // 2. all-gather: every peer's reduced slice -> my buffer (a peer has read MY copy of its slice before it says REDUCED)
     PEER_CK(tell(REDUCED));
-    for (int d = 1; d < a.world; ++d) {
-        const int p = (a.rank + d) % a.world;
-        PEER_CK(await(REDUCED, p));
-        if (len(p)) PEER_CK(hipMemcpyAsync(a.mine + lo(p), a.peer[p] + lo(p), len(p) * sizeof(float), hipMemcpyDefault, stream));
-    }
+    PEER_CK(phase(REDUCED, true));
     // 3. nobody reads my buffer any more once every peer says DONE: only then may the stream's next work write it
     PEER_CK(tell(DONE));
     for (int d = 1; d < a.world; ++d) PEER_CK(await(DONE, (a.rank + d) % a.world));

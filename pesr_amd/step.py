@@ -335,6 +335,7 @@ class Trainer:
                     ms["overlap@peer-copy"] = t_peer
                     if t_peer < ms[best] * (1.0 - margin):
                         chosen, tr = "overlap@peer-copy", ptr_
+                        comm.adopt_transport(ptr_)       # (closed with the others at shutdown)
                         graph = False                    # (not capturable)
                     else:
                         self.set_dp_transport(tr)

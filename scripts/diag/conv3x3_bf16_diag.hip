@@ -1,3 +1,4 @@
+// FORKED FROM pesr_amd/csrc/conv3x3_bf16.hip as of commit e354bfa (2026-10-03); drift since then: python scripts/diag/check_drift.py
 // DIAGNOSTIC copy of pesr_amd/csrc/conv3x3_bf16.hip with its timing-experiment switches (scripts/README.md): -DB16_FAKE_W / -DB16_FAKE_X (weights / halo re-read
 // from one hot KiB: WRONG results), -DB16_ABL_NOREAD / _NOMFMA / _NOW (no LDS fragment reads / MFMAs / weight loads: WRONG results), -DB16_FXD=2|3, -DB16_PRIO=1,
 // -DB16_STAGE_T=n.  Built only by scripts/build_variant.sh <name> conv3x3_bf16_diag.hip ... into exp/; profiles/r03_bf16_kernel_times.txt has what they measured.

@@ -1,3 +1,4 @@
+// FORKED FROM pesr_amd/csrc/conv3x3_wgrad_bf16.hip as of commit e354bfa (2026-10-03); drift since then: python scripts/diag/check_drift.py
 // EXPERIMENT, not the product kernel (scripts/README.md): the bf16 weight gradient with its staging by LDS-DMA of the raw fp32 segment + an
 // in-LDS conversion pass, transposed reads as inline asm with hand-counted lgkmcnt.  Correct (tests/test_bf16_gpu.py passes with it), 207 VGPRs, and
 // 3-6 % SLOWER than the register-staged product kernel (94 vs 91 us G body, 758 vs 715 us upsample.2): the main loop already runs at ~70 % of the

@@ -1,3 +1,4 @@
+// FORKED FROM pesr_amd/csrc/conv3x3_wgrad_wino4.hip as of commit 01c8b44 (2026-10-03); drift since then: python scripts/diag/check_drift.py
 // DIAGNOSTIC copy of pesr_amd/csrc/conv3x3_wgrad_wino4.hip (round 5; forked from the product file as of the commit that introduced
 // the woven staging; scripts/diag/check_drift.py lists what has moved since).  The product file carries none of the switches below.
 //   -DX4_STAMPS        in-kernel stamps (s_memrealtime per phase and per segment, s_memtime around the main loop) + the debug exports

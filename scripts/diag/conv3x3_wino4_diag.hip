@@ -1,3 +1,4 @@
+// FORKED FROM pesr_amd/csrc/conv3x3_wino4.hip as of commit 7dcb5c3 (2026-10-03); drift since then: python scripts/diag/check_drift.py
 // DIAGNOSTIC copy of pesr_amd/csrc/conv3x3_wino4.hip (timing experiments with WRONG results): -DW4D_NO_AREAD drops the loop's LDS fragment
 // reads, -DW4D_NO_BLOAD its weight loads, -DW4D_NO_STAGE its staging loads / transform / LDS stores.  scripts/build_variant.sh.
 // 3x3 stride-1 convolution with a 1-D Winograd F(4,3) transform along x, on the fp32-input MFMA, gfx950.

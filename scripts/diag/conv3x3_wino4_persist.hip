@@ -1,3 +1,4 @@
+// FORKED FROM pesr_amd/csrc/conv3x3_wino4.hip as of commit 13ac97b (2026-10-03); drift since then: python scripts/diag/check_drift.py
 // 3x3 stride-1 convolution with a 1-D Winograd F(4,3) transform along x, on the fp32-input MFMA, gfx950.
 //
 // Same contract as conv3x3_mfma.hip / conv3x3_wino.hip (reference nn.Conv2d(k=3, padding=1), model/basic.py:4-7, forward

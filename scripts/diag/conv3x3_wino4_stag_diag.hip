@@ -1,3 +1,4 @@
+// FORKED FROM pesr_amd/csrc/conv3x3_wino4.hip as of commit da357f6 (2026-10-03); drift since then: python scripts/diag/check_drift.py
 // DIAGNOSTIC copy of pesr_amd/csrc/conv3x3_wino4.hip: the second wave of every SIMD (xi half 1) sleeps -DW4D_SLEEP x 64 cycles behind every chunk barrier, so
 // that the two waves of a SIMD walk their twelve-MFMA blocks out of phase (their fragment reads / staging no longer coincide).  scripts/build_variant.sh.
 // 3x3 stride-1 convolution with a 1-D Winograd F(4,3) transform along x, on the fp32-input MFMA, gfx950.

@@ -1,3 +1,4 @@
+// FORKED FROM pesr_amd/csrc/linear.hip as of commit adbe091 (2026-10-03); drift since then: python scripts/diag/check_drift.py
 // DIAGNOSTIC copy of pesr_amd/csrc/linear.hip with the LDS-DMA staged forward (linear_fwd_dma_kernel) that round 4 built and measured SLOWER
 // (106 us against 96 - 101 us for the register form at 16 x 73728 -> 1024: one 80 KiB stage in flight per CU does not cover the latency of a
 // whole-chip burst; profiles/r04_ab_notes.txt).  scripts/build_variant.sh <name> linear_diag.hip links it in place of the product object.
