@@ -518,26 +518,30 @@ def side_measurements(args, trainer, G, batches, device):
     side = {}
     # ---- the reference's own --learning_rate 5e-5 (reference train.py:46), from the INITIAL weights -----------------
     # The timed region runs at --lr (default 5e-7, `lr_note`).  Same seeds, a second set of networks, Adam at 5e-5: two untimed
-    # and five timed GAN steps - the Discriminator has not yet separated the white-noise crops after seven steps (its loss is in
-    # the record), so its backward pass still runs on live data and the two rates can be compared in one driver-attested line.
+    # and five timed GAN steps, the Discriminator's loss after every one of them in the record (on white-noise crops it separates real
+    # from generated within a handful of steps at this rate - which is why the timed region does not use it), so that the two rates
+    # can be compared in one driver-attested line.
     if args.workload == "gan" and abs(args.lr - 5e-5) > 1e-12:
         import copy
         a2 = copy.copy(args)
         a2.lr = 5e-5
         tr2, G2, D2, V2 = build(a2, device, 1)
+        d_trace = []
         for i in range(2):
-            tr2.gan_step(*batches[i % len(batches)])
+            d_trace.append(tr2.gan_step(*batches[i % len(batches)])["d"])
         torch.cuda.synchronize()
         n = 5
         t0 = time.perf_counter()
         for i in range(n):
             log2 = tr2.gan_step(*batches[(2 + i) % len(batches)])
+            d_trace.append(log2["d"])
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / n
         side["lr_5e-5"] = {"workload": "the timed workload at the reference's --learning_rate 5e-5 (reference train.py:46), from the initial "
                                        "weights: 2 untimed + 5 timed eager GAN steps",
                            "steps": n, "ms_per_step": round(ms, 3), "patches_per_s": round(args.batch / ms * 1e3, 2),
                            "losses_after": {k: float(v) for k, v in log2.items()},
+                           "d_loss_per_step": [float(v) for v in d_trace],      # (the 2 untimed steps, then the 5 timed ones: shows when D separates the noise crops)
                            "note": "compare with the line's own ms_per_step (Adam at %g): the work of a step does not depend on the value "
                                    "of the learning rate" % args.lr}
         del tr2, G2, D2, V2, log2

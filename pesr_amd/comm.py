@@ -426,6 +426,8 @@ def make_transport(device: Optional[torch.device], group=None, prefer: Optional[
     if prefer not in ("auto", "rccl", "torch", "peer"):
         raise ValueError(f"PESR_DP_TRANSPORT must be auto, rccl, torch or peer, got {prefer!r}")
     backend = dist.get_backend(group)
+    if prefer == "peer" and (device is None or device.type != "cuda"):
+        raise CommError("PESR_DP_TRANSPORT=peer needs one GPU per rank (IPC-mapped device memory); there is no host path")
     if prefer == "peer":       # explicit only: the CU-free exchange over peer memory (never chosen by "auto"; Trainer.calibrate_dp_policy
         return PeerCopy(device, dist.get_rank(group), dist.get_world_size(group), group)      # can time it as a candidate)
     want_direct = prefer == "rccl" or (prefer == "auto" and backend == "nccl" and device is not None and device.type == "cuda")

@@ -316,6 +316,10 @@ def test_comm_torch_group_single_rank_gloo():
             tr.begin_capture()
         with pytest.raises(ValueError):
             comm.make_transport(torch.device("cpu"), prefer="smoke-signals")
+        with pytest.raises(comm.CommError, match="one GPU per rank"):      # the peer-memory transport has no host path (and no fallback)
+            comm.make_transport(torch.device("cpu"), prefer="peer")
+        ok, why = comm.probe_direct(torch.device("cpu"), kind="peer")       # its child-process rehearsal reports, it does not raise
+        assert not ok and "no GPU visible" in why
     finally:
         comm.close_transports()
         dist.destroy_process_group()
