@@ -32,16 +32,21 @@ def main(argv) -> int:
                             timeout=datetime.timedelta(seconds=timeout))
     mark("communicator")
     tr = comm.PeerCopy(device, rank, world, None) if kind == "peer" else comm.DirectRccl(device, rank, world, None)   # (each includes a small self-test)
-    mark("32 MB all-reduce")
+    mark("32 MB all-reduces")
     n = 8 << 20                                                   # one 32 MB bucket
-    t = torch.full((n,), float(rank + 1), dtype=torch.float32, device=device)
-    tr.wait([tr.all_reduce_async(t)])
-    torch.cuda.synchronize(device)
-    want = world * (world + 1) / 2.0
-    got = (float(t[0]), float(t[n // 2]), float(t[-1]))
-    if got != (want, want, want):
-        print(f"comm_probe: all-reduce gave {got}, expected {want}", file=sys.stderr)
-        return 4
+    ramp = (torch.arange(n, device=device) % 7).float()
+    t = torch.empty(n, dtype=torch.float32, device=device)
+    for rnd in range(6):
+        # fresh values every round, written by a kernel right before the exchange: a peer that read this GPU's memory before the
+        # kernel's stores had left the caches - or a rank that summed a stale copy - would see the PREVIOUS round's numbers
+        torch.add(ramp, float((rank + 1) * (rnd + 1)), out=t)
+        tr.wait([tr.all_reduce_async(t)])
+        torch.cuda.synchronize(device)
+        want = ramp * world + float(world * (world + 1) // 2 * (rnd + 1))
+        if not torch.equal(t, want):
+            bad = int((t != want).sum())
+            print(f"comm_probe: all-reduce round {rnd}: {bad} of {n} elements wrong (first: {float(t[t != want][0])}, expected {float(want[t != want][0])})", file=sys.stderr)
+            return 4
     mark("host_max")
     m = tr.host_max([float(rank)])
     if m != [float(world - 1)]:

@@ -48,6 +48,10 @@ __global__ __launch_bounds__(256) void peer_reduce_kernel(float* __restrict__ mi
         for (int q = 1; q < world; ++q) acc += q == rank ? m[i] : s[(size_t)(q - (q > rank ? 1 : 0)) * slice4 + i];
         m[i] = acc;
     }
+    // The sums are read next by the PEERS' copy engines, over xGMI, out of this GPU's memory: they must have left the L2 by the
+    // time the kernel is complete (two ranks time-sharing one GPU - the only place this protocol has run - share the caches and
+    // cannot show a missing write-back).  The host side also records an event (system-scope release) in front of the flag.
+    __threadfence_system();
 }
 }  // namespace
 
@@ -171,7 +175,9 @@ PESR_API int pesr_peer_allreduce(const void* args, void* stream_) {
         const int rc = pesr_launch_status();
         if (rc) return rc;
     }
-    // 2. all-gather: every peer's reduced slice -> my buffer (a peer has read MY copy of its slice before it says REDUCED)
+    // 2. all-gather: every peer's reduced slice -> my buffer (a peer has read MY copy of its slice before it says REDUCED).
+    //    (event record = system-scope release of the kernel's stores in front of the flag the peers' copies wait for)
+    PEER_CK(hipEventRecord(c->fork, stream));
     PEER_CK(tell(REDUCED));
     PEER_CK(phase(REDUCED, true));
     // 3. nobody reads my buffer any more once every peer says DONE: only then may the stream's next work write it
