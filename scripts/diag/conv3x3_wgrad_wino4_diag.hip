@@ -711,6 +711,9 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
         // The staging of the segment BEHIND this one (stores; they go to LDS that nobody reads in this segment: the free ring
         // slots, the other dM buffer) and the loads of the one after that, one step per MFMA of k-steps 2, 3 and 4.
         auto hook = [&](const int n) {
+#ifdef X4_PRIO_HOOK
+            if (n == 0) __builtin_amdgcn_s_setprio(X4_PRIO_HOOK);       // the staging waves' VALU work ahead of the other waves' MFMAs until the loads are out
+#endif
             if (n < 6) { if (n1_valid) stage_step(n, base + 4, par ^ 1, !n1_cont); }
             if (n == 5) {
                 // ... and right behind the last store all loads of the segment after next: woven one per MFMA they were issued up to
@@ -722,6 +725,9 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
                 load_prep(n2);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) load_step(t);
+#ifdef X4_PRIO_HOOK
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
         };
         X4_READ(fa1, fb1, db, vb, 1)
