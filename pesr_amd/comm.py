@@ -208,14 +208,12 @@ class PeerCopy(Transport):
             self.peer_flags = self._exchange(bytes(h) if rc == 0 else None, 0, self.flags.value or 0, "the flag block")
         # self-test: every rank contributes rank + 1 -> world (world + 1) / 2, twice (the epochs count on)
         t = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
-        keep = torch.zeros(1 << 18, dtype=torch.float32, device=device)       # (keeps `t` a piece of a larger caching-allocator block)
         for k in (1, 2):
             self.wait([self.all_reduce_async(t)])
             torch.cuda.current_stream(device).synchronize()
             want = float(world * (world + 1) // 2) * world ** (k - 1)
             if [float(x) for x in t.cpu()] != [want] * 8:
                 raise CommError(f"peer-copy self-test {k}: expected {want}, got {t.cpu().tolist()}")
-        del keep
 
     def _exchange(self, handle, offset: int, own_ptr: int, what: str):
         """All ranks' (handle, offset) -> every rank's pointer as mapped here (own: own_ptr).  handle None = this rank could not
@@ -268,13 +266,13 @@ class PeerCopy(Transport):
         else:
             offs = [(0, off.value)]
         self.regs.append((base, size.value, [pb + dict(offs)[r] - off.value for r, pb in enumerate(peers)]))
+        # scratch for the largest tensor this allocation can hold, NOW (every rank is here, nothing of it is in flight): growing
+        # it later would need a device synchronisation in the middle of a backward pass
+        self._ensure_scratch((size.value - off.value) // 4)
         return self.regs[-1][0], self.regs[-1][2]
 
-    def all_reduce_async(self, t: torch.Tensor):
-        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() % 4 == 0, "peer-copy: fp32, numel % 4 == 0"
-        base, peers = self._lookup(t)
-        rel = t.data_ptr() - base
-        slice_elems = ((t.numel() + self.world - 1) // self.world + 3) & ~3
+    def _ensure_scratch(self, numel: int) -> None:
+        slice_elems = ((numel + self.world - 1) // self.world + 3) & ~3
         need = max(1, self.world - 1) * slice_elems * 4
         if need > self.scratch_bytes:
             with torch.cuda.device(self.device):
@@ -285,6 +283,12 @@ class PeerCopy(Transport):
                 self.scratch = ctypes.c_void_p()
                 _check_hip(self.L.pesr_peer_alloc(need, ctypes.byref(self.scratch), h), "pesr_peer_alloc(scratch)")
                 self.scratch_bytes = need
+
+    def all_reduce_async(self, t: torch.Tensor):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() % 4 == 0, "peer-copy: fp32, numel % 4 == 0"
+        base, peers = self._lookup(t)
+        rel = t.data_ptr() - base
+        self._ensure_scratch(t.numel())          # (a no-op after the registration above)
         self.epoch += 1
         a = _PeerArgs()
         a.rank, a.world, a.epoch, a.numel = self.rank, self.world, self.epoch, t.numel()

@@ -540,6 +540,8 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     // ~850 cycles of transform + stores and 400 - 1100 cycles of queued-up buffer loads all at the same point of the segment, and the
     // matrix pipes of their SIMDs starved meanwhile (in-kernel stamps, profiles/r05_wgrad_notes.txt).
     f32x4 tA, tB;                                             // transform terms that live from one step to the next
+    // (signed constants: written as d4 - 5.0f * d2 hipcc negates d2 with a v_xor per register in front of each v_pk_fma)
+    const f32x4 c_m5 = {-5.0f, -5.0f, -5.0f, -5.0f}, c_m4 = {-4.0f, -4.0f, -4.0f, -4.0f}, c_p4 = {4.0f, 4.0f, 4.0f, 4.0f};
     float* sp_ = nullptr;                                     // the item's LDS address for the segment being stored
     auto stage_step = [&](const int n, int v_slot0, int d_buf, bool four) {
         if (v_role) {
@@ -548,9 +550,9 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
                             d3 = __builtin_bit_cast(f32x4, st[3]), d4 = __builtin_bit_cast(f32x4, st[4]), d5 = __builtin_bit_cast(f32x4, st[5]);
                 if (n == 0) {
                     sp_ = vring + ((v_slot0 + (v_hi ? 2 : 0) + s_rr) & (X4_RING - 1)) * X4_VROW + s_pos;
-                    *(f32x4*)(sp_) = 4.0f * d0 + (d4 - 5.0f * d2);
+                    *(f32x4*)(sp_) = __builtin_elementwise_fma(c_p4, d0, __builtin_elementwise_fma(c_m5, d2, d4));
                 } else if (n == 1) {
-                    tA = d4 - 4.0f * d2; tB = d3 - 4.0f * d1;
+                    tA = __builtin_elementwise_fma(c_m4, d2, d4); tB = __builtin_elementwise_fma(c_m4, d1, d3);
                     *(f32x4*)(sp_ + X4_VPLANE) = tA + tB;
                 } else if (n == 2) {
                     *(f32x4*)(sp_ + 2 * X4_VPLANE) = tA - tB;
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
                 } else if (n == 4) {
                     *(f32x4*)(sp_ + 4 * X4_VPLANE) = tA - tB;
                 } else {
-                    *(f32x4*)(sp_ + 5 * X4_VPLANE) = 4.0f * d1 + (d5 - 5.0f * d3);
+                    *(f32x4*)(sp_ + 5 * X4_VPLANE) = __builtin_elementwise_fma(c_p4, d1, __builtin_elementwise_fma(c_m5, d3, d5));
                 }
             }
         } else {

@@ -196,14 +196,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
                         d2 = __builtin_bit_cast(f32x4, sx[2]), d3 = __builtin_bit_cast(f32x4, sx[3]),
                         d4 = __builtin_bit_cast(f32x4, sx[4]), d5 = __builtin_bit_cast(f32x4, sx[5]);
             char* p = vdst + st_dst[u];
-            *(f32x4*)(p) = 4.0f * d0 + (d4 - 5.0f * d2);
-            *(f32x4*)(p + 5 * plane) = 4.0f * d1 + (d5 - 5.0f * d3);
-            const f32x4 t1 = d4 - 4.0f * d2, t2 = d3 - 4.0f * d1;
+            // (signed constants: written as d4 - 5.0f * d2 hipcc negates d2 with a v_xor per register in front of each v_pk_fma - 20 of
+            // the loop's 154 VALU instructions per wave and chunk, and every VALU instruction costs the fp32 MFMA pipe ~3.7 cycles)
+            const f32x4 m5 = {-5.0f, -5.0f, -5.0f, -5.0f}, m4 = {-4.0f, -4.0f, -4.0f, -4.0f}, p4 = {4.0f, 4.0f, 4.0f, 4.0f};
+            *(f32x4*)(p) = __builtin_elementwise_fma(p4, d0, __builtin_elementwise_fma(m5, d2, d4));
+            *(f32x4*)(p + 5 * plane) = __builtin_elementwise_fma(p4, d1, __builtin_elementwise_fma(m5, d3, d5));
+            const f32x4 t1 = __builtin_elementwise_fma(m4, d2, d4), t2 = __builtin_elementwise_fma(m4, d1, d3);
             *(f32x4*)(p + plane) = t1 + t2;
             *(f32x4*)(p + 2 * plane) = t1 - t2;
             const f32x4 t3 = d4 - d2, t4 = d3 - d1;
-            *(f32x4*)(p + 3 * plane) = t3 + 2.0f * t4;
-            *(f32x4*)(p + 4 * plane) = t3 - 2.0f * t4;
+            const f32x4 p2 = {2.0f, 2.0f, 2.0f, 2.0f}, m2 = {-2.0f, -2.0f, -2.0f, -2.0f};
+            *(f32x4*)(p + 3 * plane) = __builtin_elementwise_fma(p2, t4, t3);
+            *(f32x4*)(p + 4 * plane) = __builtin_elementwise_fma(m2, t4, t3);
         }
     };
 
