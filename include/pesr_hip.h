@@ -82,7 +82,9 @@ int pesr_conv3x3_dgrad(const float* dy, const float* w_packed_dgrad, const float
 #define PESR_WGRAD_WINO23 2
 #define PESR_WGRAD_WINO4_16X16 3 /* as AUTO, but the F(4,3) kernel in round 2's v_mfma_f32_16x16x4_f32 form (8 waves) instead of the
                                   * 32x32x2 form AUTO uses since round 3: same transform, same results up to rounding (cross-checks, A/B) */
-#define PESR_WGRAD_WINO4_1D 4    /* (ABI 13) as AUTO, but with round 3's 1-D F(4,3) transform (half the multiplies) on the 32x32x2 kernel (cross-checks, A/B) */
+#define PESR_WGRAD_WINO4_1D 4    /* (ABI 13) as AUTO, but with round 3's 1-D F(4,3) transform (half the multiplies) on the 12-wave 32x32x2 kernel (cross-checks, A/B) */
+#define PESR_WGRAD_WINO4_12W 5   /* (ABI 16) as AUTO, but on round 4's 12-wave kernel (every wave stages and multiplies) instead of the 16-wave one with
+                                  * four producer waves AUTO uses since round 5: same transform, same order of additions, bit-identical results */
 size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo);
 int pesr_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                        int stride, float alpha, int ps_in, int algo, int accumulate, void* workspace, size_t ws_bytes, void* stream);

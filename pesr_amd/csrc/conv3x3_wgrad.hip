@@ -479,11 +479,11 @@ size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int s
     WgradPlan p;
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return 0;
     size_t need = p.total_bytes;
-    if (stride == 1 && (algo == 0 || algo == 2 || algo == 3 || algo == 4)) {
+    if (stride == 1 && (algo == 0 || algo >= 2)) {
         const size_t ww = pesr_conv3x3_wgrad_wino_ws_bytes(N, H, W, Cin, Cout);
         if (ww > need) need = ww;
     }
-    if (stride == 1 && (algo == 0 || algo == 3 || algo == 4)) {
+    if (stride == 1 && (algo == 0 || algo >= 3)) {
         const size_t w4 = pesr_conv3x3_wgrad_wino4_ws_bytes(N, H, W, Cin, Cout);
         if (w4 > need) need = w4;
     }
@@ -493,20 +493,21 @@ size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int s
 int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                               int stride, float alpha, int ps_in, int algo, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
     WgradPlan p;
-    if (algo < 0 || algo > 4) return PESR_EINVAL;
+    if (algo < 0 || algo > 5) return PESR_EINVAL;
     if (!wgrad_plan(N, H, W, Cin, Cout, stride, &p)) return PESR_EINVAL;
     if (ws_bytes < p.total_bytes || !ws) return PESR_EWORKSPACE;
     if (ps_in && (stride != 1 || Cout % 16)) return PESR_EINVAL;
-    if (stride == 1 && (algo == 0 || algo == 3 || algo == 4)) {   // Winograd F(4,3) where it applies (width % 4 == 0 and >= 48 - the 32x32x2 kernel also 24 / 16 / 12 / 8 -, 64-multiple channels)
-        // auto: the 32x32x2-MFMA form with the transform nested in y (round 4: F(2,3)y x F(4,3)x, 1/3 of the direct form's multiplies);
-        // PESR_WGRAD_WINO4_1D (4): round 3's 1-D F(4,3) transform on the same kernel; PESR_WGRAD_WINO4_16X16 (3): round 2's 16x16x4
-        // form of the 1-D transform - both kept as cross-checks
-        const int rc = pesr_conv3x3_wgrad_wino4_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, accumulate, algo == 3 ? 0 : (algo == 4 ? 1 : 2), ws,
+    if (stride == 1 && (algo == 0 || algo >= 3)) {   // Winograd F(4,3) where it applies (width % 4 == 0 and >= 48 - the 32x32x2 kernel also 24 / 16 / 12 / 8 -, 64-multiple channels)
+        // auto: the 32x32x2-MFMA form with the transform nested in y (F(2,3)y x F(4,3)x, 1/3 of the direct form's multiplies), staging on
+        // producer waves (round 5); PESR_WGRAD_WINO4_12W (5): round 4's 12-wave kernel of the same transform; PESR_WGRAD_WINO4_1D (4):
+        // round 3's 1-D F(4,3) transform on that kernel; PESR_WGRAD_WINO4_16X16 (3): round 2's 16x16x4 form of the 1-D transform -
+        // all three kept as cross-checks
+        const int rc = pesr_conv3x3_wgrad_wino4_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, accumulate, algo == 3 ? 0 : (algo == 4 ? 1 : (algo == 5 ? 2 : 3)), ws,
                                                        ws_bytes, stream);
         if (rc != PESR_EINVAL && rc != PESR_EWORKSPACE) return rc;
     }
     // (the F(2,3) form's own reduce kernel has no accumulate mode: such a call goes to the direct kernel)
-    if (stride == 1 && (algo == 0 || algo == 2 || algo == 3 || algo == 4) && !accumulate) {   // Winograd F(2,3) where it applies (even width >= 48, 64-multiple channels)
+    if (stride == 1 && (algo == 0 || algo >= 2) && !accumulate) {   // Winograd F(2,3) where it applies (even width >= 48, 64-multiple channels)
         const int rc = pesr_conv3x3_wgrad_wino_launch(x, dy, dw, db, N, H, W, Cin, Cout, alpha, ps_in, ws, ws_bytes, stream);
         if (rc != PESR_EINVAL && rc != PESR_EWORKSPACE) return rc;
     }

@@ -767,6 +767,359 @@ __global__ __launch_bounds__(X4_NT) void conv3x3_wgrad_wino4x_kernel(const Wg4Ar
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same kernel with the staging on waves of its OWN (conv3x3_wgrad_wino4p_kernel, 16 waves: 12 consumers + 4 producers,
+// one producer per SIMD).  fp32 MFMAs and VALU instructions share the SIMD's datapath, so the staging's ~400 VALU instructions per
+// segment cost matrix time wherever they run - but in the 12-wave form they sat in the MFMA waves' own instruction streams: nine of the
+// twelve waves left the MFMA loop for ~1000 - 1500 cycles at the same point of every segment, the other three ran ahead into the barrier
+// and waited (in-kernel stamps, profiles/r05_wgrad_notes.txt).  Here a consumer wave's stream is fragment reads, six adds and four
+// MFMAs per k-step and nothing else; a producer wave loads, transforms and stores what the NEXT segment needs and waits at the
+// segment's barrier; its VALU work is spread evenly over the four SIMDs (V wave-item p + dM wave-item p on producers 0..2, the three
+// row-1 dM wave-items on producer 3: 98 / 98 / 98 / 111 VALU-equivalents per segment).  Same LDS image, ring, segment walk, split-K
+// slab and epilogue as above; 128 VGPRs per wave (four waves per SIMD).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int P4_NT = 1024;
+
+struct P4Seg { int img, xs, row; bool cont, valid; };
+__device__ __forceinline__ P4Seg p4_seg_after(const Wg4Args& a, const P4Seg& c, int index, int seg_end) {   // the segment behind c; index = its number in the walk
+    P4Seg n;
+    n.valid = index < seg_end;
+    if (c.row + 2 < a.H) { n.img = c.img; n.xs = c.xs; n.row = c.row + 2; n.cont = true; }
+    else { n.cont = false; n.row = 0; n.xs = c.xs + 1; n.img = c.img; if (n.xs == a.segs_x) { n.xs = 0; n.img = c.img + 1; } }
+    return n;
+}
+
+// The producer waves' whole life (P3: the wave that stages the three row-1 dM wave-items; otherwise V wave-item pw + dM wave-item pw).
+template <bool P3>
+__device__ __forceinline__ void p4_producer(const Wg4Args& a, float* const vring, float* const dmbuf, const int pw, const int lane,
+                                            const int ci0, const int co0, const int seg_begin, const int seg_end, const P4Seg cur) {
+    using Seg = P4Seg;
+    auto seg_after = [&](const Seg& c, int index) { return p4_seg_after(a, c, index, seg_end); };
+    // Wave-items (64 items each): V wave-item k = items 64k .. 64k+63 of the 192 (row rr = item / 96, x-tile (item % 96) >> 3,
+    // ci group item & 7: six input columns of four channels), dM wave-item k of the 384 (row k / 3, x-tile (item % 192) >> 4,
+    // co group item & 15: four gradient columns).  Producers 0..2: slot V = V wave-item p (r[0..5]), slot H = the same item of the
+    // SECOND pair of halo rows where a segment starts a strip (r[6..11]; same columns), slot D = dM wave-item p (r[12..15]).
+    // Producer 3: dM wave-items 3, 4, 5 (r[0..3], r[4..7], r[8..11]).
+    const int XTW = a.W >> 2;
+    const int d_C = a.ps_in ? (a.Cout >> 2) : a.Cout;
+    const unsigned x_row_bytes = (unsigned)a.W * a.Cin * 4, d_row_bytes = (unsigned)a.W * a.Cout * 4;
+    const unsigned x_side_bytes = (unsigned)(a.side - 1) * a.H * x_row_bytes, d_side_bytes = (unsigned)(a.side - 1) * a.H * d_row_bytes;
+        u32x4 r[16];
+    unsigned off[12];                 // byte offsets of the slots' columns from the start of their first row; 2^31 = outside
+    int x0[3];                        // strip-relative first column of the three slots' items (+ 48 * strip)
+    unsigned cb[3], psz[3];           // channel-group byte offset (+ row pitch of the lane's row for V), pixel pitch in bytes
+    int pos[3], rrw[3], tix[3];       // LDS float position inside a plane, row of the pair, x-tile in the strip
+    // slot s of this producer: kind (true = V item), wave-item
+    auto slot_is_v = [&](int s_) { return !P3 && s_ == 0; };
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+        if (!P3 && s_ == 0) {                         // V wave-item pw
+            const int item = 64 * pw + lane, vt = (item % 96) >> 3, vc4 = item & 7;
+            const int sub = a.side > 1 ? vt / XTW : 0;
+            rrw[s_] = item / 96; tix[s_] = vt; pos[s_] = vt * 32 + vc4 * 4;
+            x0[s_] = 4 * (vt - sub * XTW) - 1;
+            psz[s_] = (unsigned)a.Cin * 4;
+            cb[s_] = (unsigned)(((sub * a.H) * a.W) * a.Cin + ci0 + vc4 * 4) * 4 + (unsigned)rrw[s_] * x_row_bytes;
+        } else {                                      // a dM wave-item: pw (slot 1 of producers 0..2) or 3 + s_ (producer 3)
+            const int k = P3 ? 3 + s_ : pw;
+            const int item = 64 * k + lane, dt = (item % 192) >> 4, dc4 = item & 15;
+            const int sub0 = a.side > 1 ? dt / XTW : 0;
+            rrw[s_] = item / 192; tix[s_] = dt; pos[s_] = dt * 64 + dc4 * 4;
+            x0[s_] = 4 * (dt - sub0 * XTW);
+            const int pch = co0 + dc4 * 4;
+            if (a.ps_in) {
+                const int sub = pch / d_C, cc = pch - sub * d_C;
+                cb[s_] = (unsigned)(((sub >> 1) * (2 * a.W) + (sub & 1)) * d_C + cc) * 4;
+                psz[s_] = (unsigned)(2 * d_C) * 4;
+            } else {
+                cb[s_] = (unsigned)((sub0 * a.H * a.W) * a.Cout + pch) * 4;
+                psz[s_] = (unsigned)a.Cout * 4;
+            }
+        }
+    }
+    // producers 0..2 use slots 0 (V) and 1 (dM); slot 2's constants are unused there (H shares slot 0's)
+    int s_xs = 0;
+    auto set_strip = [&](int xs, int grp) {               // (once per strip: the only place the offsets cost VALU instructions)
+        const int dx = (xs - s_xs) * 48;
+        s_xs = xs;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+            x0[s_] += dx;
+            int xx = x0[s_];
+            if (a.side > 1 && grp * a.side + tix[s_] / XTW >= a.N) xx += 0x100000;       // an image of the last group that does not exist
+            const int ncol = slot_is_v(s_) ? 6 : 4;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (j >= ncol) continue;
+                const unsigned x = (unsigned)(xx + j);
+                const unsigned o = x < (unsigned)a.W ? cb[s_] + x * psz[s_] : 0x80000000u;
+                if constexpr (!P3) { if (s_ == 0) off[j] = o; else if (s_ == 1) off[6 + j] = o; }
+                else off[4 * s_ + j] = o;
+            }
+        }
+    };
+    auto uniform_ptr = [](const float* p) -> const float* {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const float*)(((unsigned long long)hi << 32) | lo);
+    };
+    // loads of segment g (a segment that does not exist: nothing is issued)
+    auto load_seg = [&](const Seg& g) {
+        if (!g.valid) return;
+        if constexpr (!P3) {
+            // V pair(s): a continuing segment adds rows row+1, row+2; a strip start needs row-1, row (slot V) and row+1, row+2 (slot H)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && g.cont) continue;
+                const int v_iy0 = g.cont ? g.row + 1 : (h ? g.row + 1 : g.row - 1);
+                const float* const rowp = a.x + ((long)g.img * a.side * a.H + v_iy0) * ((long)a.W * a.Cin);
+                const int iy = v_iy0 + rrw[0];
+                bool lane_ok = true;
+                unsigned bytes;
+                if (g.cont && a.side == 1) {
+                    const int rows = a.H - v_iy0 > 2 ? 2 : (a.H - v_iy0 < 0 ? 0 : a.H - v_iy0);
+                    bytes = (unsigned)rows * x_row_bytes;
+                } else {
+                    bytes = x_side_bytes + 2 * x_row_bytes;
+                    lane_ok = iy >= 0 && iy < a.H;
+                }
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) r[6 * h + j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_ok ? off[j] : 0x80000000u, 0, 0);
+            }
+        }
+        // dM wave-items
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+            if (!P3 && s_ != 1) continue;
+            const int oy = g.row + __builtin_amdgcn_readfirstlane(rrw[s_]);
+            const bool row_ok = oy < a.H;
+            const int ry = row_ok ? oy : 0;
+            const float* const rowp = a.ps_in ? a.dy + ((size_t)g.img * (2 * a.H) + 2 * ry) * (2 * a.W) * d_C
+                                              : a.dy + ((size_t)g.img * a.side * a.H + ry) * a.W * a.Cout;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(rowp), 0,
+                                                  __builtin_amdgcn_readfirstlane(row_ok ? d_side_bytes + d_row_bytes : 0u), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!P3) r[12 + j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[6 + j], 0, 0);
+                else r[4 * s_ + j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[4 * s_ + j], 0, 0);
+            }
+        }
+    };
+    const f32x4 c_m5 = {-5.0f, -5.0f, -5.0f, -5.0f}, c_m4 = {-4.0f, -4.0f, -4.0f, -4.0f}, c_p4 = {4.0f, 4.0f, 4.0f, 4.0f};
+    auto store_v = [&](const int rb, float* p) {           // six planes of one V item
+        const f32x4 d0 = __builtin_bit_cast(f32x4, r[rb]), d1 = __builtin_bit_cast(f32x4, r[rb + 1]), d2 = __builtin_bit_cast(f32x4, r[rb + 2]),
+                    d3 = __builtin_bit_cast(f32x4, r[rb + 3]), d4 = __builtin_bit_cast(f32x4, r[rb + 4]), d5 = __builtin_bit_cast(f32x4, r[rb + 5]);
+        *(f32x4*)(p) = __builtin_elementwise_fma(c_p4, d0, __builtin_elementwise_fma(c_m5, d2, d4));
+        *(f32x4*)(p + 5 * X4_VPLANE) = __builtin_elementwise_fma(c_p4, d1, __builtin_elementwise_fma(c_m5, d3, d5));
+        const f32x4 t1 = __builtin_elementwise_fma(c_m4, d2, d4), t2 = __builtin_elementwise_fma(c_m4, d1, d3);
+        *(f32x4*)(p + X4_VPLANE) = t1 + t2;
+        *(f32x4*)(p + 2 * X4_VPLANE) = t1 - t2;
+        const f32x4 t3 = d4 - d2, t4 = 2.0f * (d3 - d1);
+        *(f32x4*)(p + 3 * X4_VPLANE) = t3 + t4;
+        *(f32x4*)(p + 4 * X4_VPLANE) = t3 - t4;
+    };
+    auto store_d = [&](const int rb, float* p) {           // six planes of one dM item
+        const f32x4 g0 = __builtin_bit_cast(f32x4, r[rb]), g1 = __builtin_bit_cast(f32x4, r[rb + 1]), g2 = __builtin_bit_cast(f32x4, r[rb + 2]),
+                    g3 = __builtin_bit_cast(f32x4, r[rb + 3]);
+        const f32x4 e02 = g0 + g2, e13 = g1 + g3, f02 = g0 + 4.0f * g2, f13 = 2.0f * (g1 + 4.0f * g3);
+        *(f32x4*)(p) = g0;
+        *(f32x4*)(p + X4_DPLANE) = e02 + e13;
+        *(f32x4*)(p + 2 * X4_DPLANE) = e02 - e13;
+        *(f32x4*)(p + 3 * X4_DPLANE) = f02 + f13;
+        *(f32x4*)(p + 4 * X4_DPLANE) = f02 - f13;
+        *(f32x4*)(p + 5 * X4_DPLANE) = g3;
+    };
+    // what was loaded for segment g goes to ring slots v_slot0 .. (+3 at a strip start) and dM buffer d_buf
+    auto store_seg = [&](const Seg& g, int v_slot0, int d_buf) {
+        if (!g.valid) return;
+        if constexpr (!P3) {
+            store_v(0, vring + ((v_slot0 + rrw[0]) & (X4_RING - 1)) * X4_VROW + pos[0]);
+            if (!g.cont) store_v(6, vring + ((v_slot0 + 2 + rrw[0]) & (X4_RING - 1)) * X4_VROW + pos[0]);
+            store_d(12, dmbuf + (d_buf * 2 + rrw[1]) * X4_DROW + pos[1]);
+        } else {
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) store_d(4 * s_, dmbuf + (d_buf * 2 + rrw[s_]) * X4_DROW + pos[s_]);
+        }
+    };
+    Seg n1 = seg_after(cur, seg_begin + 1);
+    set_strip(cur.xs, cur.img);
+    load_seg(cur);
+    store_seg(cur, 0, 0);
+    if (n1.valid && !n1.cont) set_strip(n1.xs, n1.img);
+    load_seg(n1);
+    Seg n2 = seg_after(n1, seg_begin + 2);
+    __syncthreads();
+    int base = 0, par = 0;
+#pragma unroll 1
+    for (int seg = seg_begin; seg < seg_end; ++seg) {
+        // during segment `seg`: store what segment seg + 1 needs (its loads were issued a segment ago), load for seg + 2
+        store_seg(n1, base + 4, par ^ 1);
+        if (n2.valid && !n2.cont) set_strip(n2.xs, n2.img);
+        load_seg(n2);
+        __syncthreads();                                   // the segment's one barrier (the consumers reach it in front of their last k-step)
+        base = (base + (n1.cont ? 2 : 4)) & (X4_RING - 1);
+        par ^= 1;
+        n1 = n2;
+        n2 = seg_after(n2, seg + 3);
+    }
+}
+
+template <bool NEST>
+__global__ __launch_bounds__(P4_NT) void conv3x3_wgrad_wino4p_kernel(const Wg4Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const vring = lds;                             // [8 slots] V rows
+    float* const dmbuf = lds + X4_RING * X4_VROW;         // [2 buffers][2 rows] dM rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 12;
+    const int pw = wave - 12;                             // producer index 0..3
+    const int c32 = lane & 31, ks = lane >> 5;            // consumer fragment lane: channel, k-slot (x-tile 2q + ks of k-step q)
+    const int cot2 = producer ? 0 : wave / 6, xi = producer ? 0 : wave - cot2 * 6;
+
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int cit = bid % a.ci_tiles;  bid /= a.ci_tiles;
+    const int cot = bid % a.co_tiles;
+    const int sp = bid / a.co_tiles;
+    const int ci0 = cit * 32, co0 = cot * 64;
+
+    const int seg_begin = sp * a.segs_per_split;
+    int seg_end = seg_begin + a.segs_per_split;
+    if (seg_end > a.total_segs) seg_end = a.total_segs;
+    if (seg_begin >= seg_end) return;
+
+    using Seg = P4Seg;
+    auto seg_after = [&](const Seg& c, int index) { return p4_seg_after(a, c, index, seg_end); };
+    Seg cur;
+    {
+        const int strip = seg_begin / a.segs_y;
+        cur.row = 2 * (seg_begin - strip * a.segs_y);
+        cur.img = strip / a.segs_x;
+        cur.xs = strip - cur.img * a.segs_x;
+        cur.cont = false; cur.valid = true;
+    }
+
+    constexpr int NACC = NEST ? 4 : 3;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    float bsum = 0.f;
+
+    if (producer) {
+        // The producers run ABOVE the MFMA waves' priority: their ~100 VALU instructions and stores per segment then issue when their
+        // loads are there instead of queueing behind three waves' MFMAs (at equal priority the consumers met the segment's barrier
+        // before the producers: 151.6 us; priority 1 / 2 / 3: 130.1 / 129.5 / 131.6; the round-4 kernel: 146.3 - profiles/r05_wgrad_notes.txt)
+        __builtin_amdgcn_s_setprio(2);
+        if (pw == 3) p4_producer<true>(a, vring, dmbuf, pw, lane, ci0, co0, seg_begin, seg_end, cur);
+        else p4_producer<false>(a, vring, dmbuf, pw, lane, ci0, co0, seg_begin, seg_end, cur);
+    } else {
+        // ================================================= consumers =================================================
+        const int b_lane = xi * X4_VPLANE + ks * 32 + c32;
+        const int a_lane = xi * X4_DPLANE + ks * 64 + cot2 * 32 + c32;
+        Seg n1 = seg_after(cur, seg_begin + 1);
+        __syncthreads();                                       // the first segment is staged
+        int base = 0, par = 0;
+        constexpr int KQ = G4_TXT / 2;
+        float fa0[2], fb0[4], fa1[2], fb1[4];
+#define P4_READ(FA, FB, DB, VB, Q)                                                               \
+        {                                                                                        \
+            FA[0] = DB[(Q) * 128]; FA[1] = DB[X4_DROW + (Q) * 128];                              \
+            FB[0] = VB[0][(Q) * 64]; FB[1] = VB[0][X4_VROW + (Q) * 64];                          \
+            FB[2] = VB[1][(Q) * 64]; FB[3] = VB[1][X4_VROW + (Q) * 64];                          \
+        }
+#define P4_KSTEP(FA, FB)                                                                         \
+        if (NEST) {                                                                              \
+            const float ds_ = FA[0] + FA[1], dd_ = FA[0] - FA[1];                                \
+            const float x0_ = FB[0] - FB[2], x1_ = FB[1] + FB[2], x2_ = FB[2] - FB[1], x3_ = FB[3] - FB[1]; \
+            if (xi == 1) { asm volatile("" : "+v"(bsum)); bsum += ds_; }                         \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], x0_, acc[0], 0, 0, 0);          \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds_, x1_, acc[1], 0, 0, 0);            \
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dd_, x2_, acc[2], 0, 0, 0);            \
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], x3_, acc[3], 0, 0, 0);          \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                   \
+                acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0], FB[ky], acc[ky], 0, 0, 0); \
+                acc[ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1], FB[ky + 1], acc[ky], 0, 0, 0); \
+            }                                                                                    \
+            if (xi == 1) { asm volatile("" : "+v"(bsum)); bsum += FA[0] + FA[1]; }               \
+        }
+        const float* db = dmbuf + a_lane;
+        const float* vb[2] = {vring + b_lane, vring + 2 * X4_VROW + b_lane};
+        P4_READ(fa0, fb0, db, vb, 0)
+#pragma unroll 1
+        for (int seg = seg_begin; seg < seg_end; ++seg) {
+            const int nbase = (base + (n1.cont ? 2 : 4)) & (X4_RING - 1);
+#pragma unroll
+            for (int q = 0; q < KQ - 2; q += 2) {
+                P4_READ(fa1, fb1, db, vb, q + 1)
+                P4_KSTEP(fa0, fb0)
+                P4_READ(fa0, fb0, db, vb, q + 2)
+                P4_KSTEP(fa1, fb1)
+            }
+            P4_READ(fa1, fb1, db, vb, KQ - 1)
+            P4_KSTEP(fa0, fb0)
+            // the segment's one barrier, in front of its last k-step: this segment's last fragments are in registers, the next
+            // segment's rows are stored - its first fragments are read here, under that k-step's MFMAs
+            __syncthreads();
+            db = dmbuf + ((par ^ 1) * 2) * X4_DROW + a_lane;
+            vb[0] = vring + nbase * X4_VROW + b_lane;
+            vb[1] = vring + ((nbase + 2) & (X4_RING - 1)) * X4_VROW + b_lane;
+            P4_READ(fa0, fb0, db, vb, 0)
+            P4_KSTEP(fa1, fb1)
+            base = nbase; par ^= 1;
+            n1 = seg_after(n1, seg + 2);
+        }
+#undef P4_READ
+#undef P4_KSTEP
+    }
+    __syncthreads();
+
+    if (a.bias_part && cit == 0) {     // the xi = 1 waves hold column sums of dy: lane pairs (c, c + 32) meet in LDS, fixed order
+        float* red = lds;
+        if (!producer && xi == 1) red[cot2 * 64 + lane] = bsum;
+        __syncthreads();
+        if (tid < 64 && co0 + tid < a.Cout) {
+            const int h = tid >> 5, c = tid & 31;
+            a.bias_part[(size_t)sp * a.Cout + co0 + tid] = red[h * 64 + c] + red[h * 64 + 32 + c];
+        }
+        __syncthreads();
+    }
+    float* const ob = lds;
+    if (!producer) {
+        if (NEST) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float hs = 0.5f * (acc[1][j] + acc[2][j]), hd = 0.5f * (acc[1][j] - acc[2][j]);
+                acc[0][j] = acc[0][j] + hs; acc[1][j] = hd; acc[2][j] = hs + acc[3][j];
+            }
+        }
+        float* o = ob + ((cot2 * 6 + xi) * 3) * 1024 + c32;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rw = (j >> 2) * 8 + ks * 4 + (j & 3);
+                o[ky * 1024 + rw * 32] = acc[ky][j];
+            }
+    }
+    __syncthreads();
+    float* const out = a.slab + (size_t)sp * 9 * a.Cout * a.Cin;
+    const unsigned tap = (unsigned)a.Cout * a.Cin;
+    for (int e = tid; e < 2 * 3 * 1024; e += P4_NT) {
+        const int col = e & 31, rw = (e >> 5) & 31, ky = (e >> 10) % 3, h = e / 3072;
+        const float* u = ob + (h * 6 * 3 + ky) * 1024 + rw * 32 + col;
+        const float u0 = u[0], u1 = u[3072], u2 = u[2 * 3072], u3 = u[3 * 3072], u4 = u[4 * 3072], u5 = u[5 * 3072];
+        const float s12 = u1 + u2, d12 = u1 - u2, s34 = u3 + u4, d34 = u3 - u4;
+        const float w0 = (0.25f * u0 - (1.0f / 6.0f) * s12) + (1.0f / 24.0f) * s34;
+        const float w1 = ((-1.0f / 6.0f) * d12) + (1.0f / 12.0f) * d34;
+        const float w2 = ((-1.0f / 6.0f) * s12) + ((1.0f / 6.0f) * s34 + u5);
+        const unsigned go = ((unsigned)(ky * 3) * a.Cout + co0 + h * 32 + rw) * a.Cin + ci0 + col;
+        out[go] = w0; out[go + tap] = w1; out[go + 2 * tap] = w2;
+    }
+}
+
 namespace {
 struct Wg4Plan { int co_tiles, ci_tiles, segs_x, segs_y, total_segs, split, segs_per_split, side; size_t slab_bytes, total_bytes; };
 
@@ -813,7 +1166,8 @@ size_t pesr_conv3x3_wgrad_wino4_ws_bytes(int N, int H, int W, int Cin, int Cout)
 }
 
 // returns PESR_EINVAL when the shape is not covered (the caller then tries the F(2,3) form / the direct kernel)
-// variant 0: the 16x16x4 kernel (8 waves); 1: the 32x32x2 kernel (12 waves), 1-D transform; 2: the same kernel with the transform nested in y
+// variant 0: the 16x16x4 kernel (8 waves); 1: the 32x32x2 kernel (12 waves), 1-D transform; 2: the same kernel with the transform nested in y;
+// 3: the y-nested transform with the staging on four producer waves (16 waves; the product)
 int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                                     float alpha, int ps_in, int accumulate, int variant, void* ws, size_t ws_bytes, hipStream_t stream) {
     Wg4Plan p;
@@ -840,9 +1194,11 @@ int pesr_conv3x3_wgrad_wino4_launch(const float* x, const float* dy, float* dw, 
     attr_once_x([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4x_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_wino4p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int grid = p.split * p.co_tiles * p.ci_tiles;
-    if (variant == 2) hipLaunchKernelGGL(conv3x3_wgrad_wino4x_kernel<true>, dim3(grid), dim3(X4_NT), ldsx, stream, a);
+    if (variant == 3) hipLaunchKernelGGL(conv3x3_wgrad_wino4p_kernel<true>, dim3(grid), dim3(P4_NT), ldsx, stream, a);
+    else if (variant == 2) hipLaunchKernelGGL(conv3x3_wgrad_wino4x_kernel<true>, dim3(grid), dim3(X4_NT), ldsx, stream, a);
     else if (variant == 1) hipLaunchKernelGGL(conv3x3_wgrad_wino4x_kernel<false>, dim3(grid), dim3(X4_NT), ldsx, stream, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_wino4_kernel, dim3(grid), dim3(G4_NT), lds, stream, a);
     int rc = pesr_launch_status();

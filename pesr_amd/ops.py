@@ -240,7 +240,7 @@ def wgrad_kernel_for(N, H, W, Cin, Cout):
             if ok and side == 1 and USE_WGRAD_WINO4_16X16:
                 return "conv3x3_wgrad_wino4_kernel", 0.5
             if ok and not USE_WGRAD_WINO4_16X16:     # (rows shorter than a strip - images side by side - exist on the 32x32x2 kernel only)
-                return "conv3x3_wgrad_wino4x_kernel", (0.5 if USE_WGRAD_WINO4_1D else 1.0 / 3.0)
+                return ("conv3x3_wgrad_wino4x_kernel", 0.5) if USE_WGRAD_WINO4_1D else ("conv3x3_wgrad_wino4p_kernel", 1.0 / 3.0)
         if W >= 48 and W % 2 == 0 and ((W // 2 + 23) // 24) * 24 * 8 <= (W // 2) * 9:
             return "conv3x3_wgrad_wino_kernel", 2.0 / 3.0
     return "conv3x3_wgrad_kernel", 1.0
@@ -584,7 +584,7 @@ def _out(t, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23, WGRAD_WINO4_16X16, WGRAD_WINO4_1D = 0, 1, 2, 3, 4      # include/pesr_hip.h PESR_WGRAD_*
+WGRAD_AUTO, WGRAD_DIRECT, WGRAD_WINO23, WGRAD_WINO4_16X16, WGRAD_WINO4_1D, WGRAD_WINO4_12W = 0, 1, 2, 3, 4, 5      # include/pesr_hip.h PESR_WGRAD_*
 # PESR_WGRAD_WINO4_16X16=1: round 2's 16x16x4-MFMA form of the F(4,3) weight gradient instead of the 32x32x2 form (A/B switch)
 USE_WGRAD_WINO4_16X16 = __import__("os").environ.get("PESR_WGRAD_WINO4_16X16", "0") == "1"
 # PESR_WGRAD_WINO4_1D=1: round 3's 1-D F(4,3) transform on the 32x32x2 kernel instead of the y-nested one (A/B switch)

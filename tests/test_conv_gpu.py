@@ -281,9 +281,13 @@ def test_conv3x3_wgrad_all_algorithms(N, H, W, Cin, Cout):
     x = _rand(N, Cin, H, W, seed=900); w = _rand(Cout, Cin, 3, 3, seed=910, scale=0.1)
     dy = _rand(N, Cout, H, W, seed=920)
     _, dw_ref, db_ref = O.conv3x3_grads(x.double(), w.double(), dy.double())
-    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO23, ops.WGRAD_DIRECT, ops.WGRAD_WINO4_16X16, ops.WGRAD_WINO4_1D):
+    got = {}
+    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO23, ops.WGRAD_DIRECT, ops.WGRAD_WINO4_16X16, ops.WGRAD_WINO4_1D, ops.WGRAD_WINO4_12W):
         dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, alpha=0.5, algo=algo)
         _close(dw.cpu().double(), 0.5 * dw_ref, 1e-5); _close(db.cpu().double(), 0.5 * db_ref, 1e-5)
+        got[algo] = (dw, db)
+    # the 16-wave kernel (producer waves) and round 4's 12-wave kernel: same transform, same order of additions
+    assert torch.equal(got[ops.WGRAD_AUTO][0], got[ops.WGRAD_WINO4_12W][0]) and torch.equal(got[ops.WGRAD_AUTO][1], got[ops.WGRAD_WINO4_12W][1])
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(16, 24, 24, 256, 512), (4, 9, 24, 64, 128), (9, 6, 24, 64, 64), (6, 7, 16, 64, 64),
@@ -295,12 +299,12 @@ def test_conv3x3_wgrad_narrow_images_side_by_side(N, H, W, Cin, Cout):
     transforms (y-nested, 1-D) against the oracle, with and without accumulation; the result must differ in its bits from the
     direct kernel's (i.e. the shape really ran on the Winograd kernel), and repeat bit-identically."""
     from pesr_amd import ops
-    assert ops.wgrad_kernel_for(N, H, W, Cin, Cout)[0] == "conv3x3_wgrad_wino4x_kernel"
+    assert ops.wgrad_kernel_for(N, H, W, Cin, Cout)[0] == "conv3x3_wgrad_wino4p_kernel"
     x = _rand(N, Cin, H, W, seed=930); w = _rand(Cout, Cin, 3, 3, seed=931, scale=0.1)
     dy = _rand(N, Cout, H, W, seed=932)
     _, dw_ref, db_ref = O.conv3x3_grads(x.double(), w.double(), dy.double())
     dw_d, _ = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, algo=ops.WGRAD_DIRECT)
-    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO4_1D):
+    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO4_1D, ops.WGRAD_WINO4_12W):
         dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, algo=algo)
         _close(dw.cpu().double(), dw_ref, 1e-5); _close(db.cpu().double(), db_ref, 1e-5)
         assert not torch.equal(dw, dw_d)
@@ -319,7 +323,7 @@ def test_conv3x3_wgrad_winograd4_pixel_shuffle_fused():
     x = _rand(N, C, H, W, seed=1); w = _rand(4 * C, C, 3, 3, seed=2, scale=0.1)
     dys = _rand(N, C, 2 * H, 2 * W, seed=4)
     _, dw_ref, db_ref = O.conv3x3_grads(x.double(), w.double(), F.pixel_unshuffle(dys, 2).double())
-    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO23, ops.WGRAD_WINO4_16X16, ops.WGRAD_WINO4_1D):
+    for algo in (ops.WGRAD_AUTO, ops.WGRAD_WINO23, ops.WGRAD_WINO4_16X16, ops.WGRAD_WINO4_1D, ops.WGRAD_WINO4_12W):
         dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dys), 1, ps_in=True, algo=algo)
         _close(dw.cpu().double(), dw_ref, 1e-5); _close(db.cpu().double(), db_ref, 1e-5)
 
