@@ -18,4 +18,5 @@ bash scripts/gpu_job.sh py layer_times scripts/layer_times.py
 bash scripts/gpu_job.sh py linear_time scripts/linear_time.py
 bash scripts/gpu_job.sh py rgb_layer_time scripts/rgb_layer_time.py
 bash scripts/gpu_job.sh py split_bf16_kernel_times scripts/bf16x3_time.py
-bash scripts/gpu_job.sh py wgrad_phases scripts/x4_phases.py exp/libx4st.so
+# (profiles/r05_wgrad_phases.txt: in-kernel stamps of the 12-wave weight-gradient kernel, a -DX4_STAMPS build of scripts/diag/conv3x3_wgrad_wino4_diag.hip:
+#  bash scripts/build_variant.sh x4st conv3x3_wgrad_wino4_diag.hip -DX4_STAMPS; bash scripts/gpu_job.sh py wgrad_phases scripts/x4_phases.py exp/libx4st.so)
