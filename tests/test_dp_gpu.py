@@ -246,11 +246,13 @@ def _oracle_step(config, nproc, dt, perturb_seed=0):
 # "ipc": the same two ranks on one GPU, gradients exchanged by comm.PeerCopy - IPC mappings of each other's flat gradient buffers,
 # stream wait / write-value operations, peer copies, one reduce kernel (no workgroup resident while it waits): the rehearsal of the
 # CU-free exchange VERDICT r04 asked for, against the same full-batch oracle
-LAUNCHES = [(1, "nccl", False), (2, "nccl", False), (2, "gloo", True), (2, "ipc", True)]
+# "ipc4": FOUR ranks on one GPU over comm.PeerCopy (chunk ownership, the order of the rank-ordered sum and the all-gather's
+# copies only become non-trivial beyond two ranks; the driver's scaling run uses 2, 4 and 8)
+LAUNCHES = [(1, "nccl", False), (2, "nccl", False), (2, "gloo", True), (2, "ipc", True), (4, "ipc", True)]
 
 
 @pytest.mark.parametrize("config", ["small", "pretrain", "tv"])
-@pytest.mark.parametrize("nproc,backend,share", LAUNCHES, ids=["nccl1", "nccl2", "gloo2-one-gpu", "ipc2-one-gpu"])
+@pytest.mark.parametrize("nproc,backend,share", LAUNCHES, ids=["nccl1", "nccl2", "gloo2-one-gpu", "ipc2-one-gpu", "ipc4-one-gpu"])
 def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_path):
     """N ranks, each on its shard, against the CPU oracle's step on the GLOBAL batch.  Gradients of the first step are held to
     the fp64 criterion of helpers.grads_vs_fp64, with the float64 oracle computed here: per tensor, our distance to the fp64
@@ -263,6 +265,8 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
     kinks) and its allowance follows from the same measurement."""
     if not share and torch.cuda.device_count() < nproc:
         pytest.skip(f"{nproc} GPUs needed, {torch.cuda.device_count()} visible")
+    if nproc == 4 and config == "small":
+        pytest.skip("four ranks: the L1 and TV-only steps (well-conditioned gradients) carry the check")
     got = _launch_worker(nproc, config, backend, share, str(tmp_path / "dp.pt"))
     assert got["world"] == nproc
     from dp_worker import CONFIGS
