@@ -233,6 +233,9 @@ def bench_infer512(args, device):
 
 
 def main():
+    if os.environ.get("PESR_DUMP_STACKS_AFTER"):       # debugging aid for a hung multi-rank run: every thread's Python stack to stderr after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PESR_DUMP_STACKS_AFTER"]), exit=False)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)

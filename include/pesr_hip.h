@@ -331,6 +331,7 @@ int pesr_peer_ctx_create(int world, void** ctx);
 int pesr_peer_ctx_destroy(void* ctx);
 int pesr_peer_alloc(size_t bytes, void** ptr, unsigned char* handle64);
 int pesr_peer_free(void* ptr);
+int pesr_peer_release(void* my_flags, size_t bytes);   /* (ABI 17) abandon a stuck exchange: fill this rank's own flag block with 0xffffffff so that every wait of its streams runs out; the transport is unusable afterwards */
 int pesr_peer_export(const void* ptr, unsigned char* handle64, size_t* offset, size_t* alloc_bytes);
 int pesr_peer_open(const unsigned char* handle64, void** base);
 int pesr_peer_close(void* base);

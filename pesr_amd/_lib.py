@@ -90,6 +90,7 @@ SIGNATURES.update({
     "pesr_adam_step_dev": (c_int, [_P, _P, _P, _P, c_long, _P, c_float, c_float, c_float, c_float, _P]),
     "pesr_peer_alloc": (c_int, [c_size_t, _P, _P]),
     "pesr_peer_free": (c_int, [_P]),
+    "pesr_peer_release": (c_int, [_P, c_size_t]),
     "pesr_peer_export": (c_int, [_P, _P, _P, _P]),
     "pesr_peer_open": (c_int, [_P, _P]),
     "pesr_peer_close": (c_int, [_P]),

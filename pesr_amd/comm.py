@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 from typing import List, Optional
 
 import torch
@@ -206,14 +207,40 @@ class PeerCopy(Transport):
             h = (ctypes.c_ubyte * 64)()
             rc = self.L.pesr_peer_alloc(self.FLAG_BYTES, ctypes.byref(self.flags), h)
             self.peer_flags = self._exchange(bytes(h) if rc == 0 else None, 0, self.flags.value or 0, "the flag block")
-        # self-test: every rank contributes rank + 1 -> world (world + 1) / 2, twice (the epochs count on)
+        # self-test: every rank contributes rank + 1 -> world (world + 1) / 2, twice (the epochs count on).  With a DEADLINE: an exchange
+        # that does not complete (a flag write that never arrives) is abandoned - this rank's own flag words are forced, its streams
+        # run out - and every rank raises together; the caller falls back to another transport.
         t = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
+        deadline = float(os.environ.get("PESR_PEER_SELFTEST_TIMEOUT", "30"))
+        err = None
         for k in (1, 2):
-            self.wait([self.all_reduce_async(t)])
-            torch.cuda.current_stream(device).synchronize()
+            done = self.all_reduce_async(t)
+            t0 = time.monotonic()
+            while not done.query() and time.monotonic() - t0 < deadline:
+                time.sleep(0.001)
+            if not done.query():
+                err = f"self-test {k} did not complete within {deadline:.0f} s"
+                with torch.cuda.device(device):
+                    self.L.pesr_peer_release(self.flags, self.FLAG_BYTES)
+                torch.cuda.synchronize(device)
+                break
+            self.wait([done])
             want = float(world * (world + 1) // 2) * world ** (k - 1)
             if [float(x) for x in t.cpu()] != [want] * 8:
-                raise CommError(f"peer-copy self-test {k}: expected {want}, got {t.cpu().tolist()}")
+                err = f"self-test {k}: expected {want}, got {t.cpu().tolist()}"
+                break
+        if world > 1:
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=group)
+            bad = [f"rank {r}: {e}" for r, e in enumerate(errs) if e]
+            if bad and err is None:                          # (a peer gave up: its flag writes may never come - do not wait for them later)
+                with torch.cuda.device(device):
+                    self.L.pesr_peer_release(self.flags, self.FLAG_BYTES)
+                torch.cuda.synchronize(device)
+            err = "; ".join(bad) if bad else None
+        if err:
+            self.close(collective=False)
+            raise CommError("peer-copy " + err)
 
     def _exchange(self, handle, offset: int, own_ptr: int, what: str):
         """All ranks' (handle, offset) -> every rank's pointer as mapped here (own: own_ptr).  handle None = this rank could not
@@ -324,10 +351,10 @@ class PeerCopy(Transport):
     def begin_capture(self) -> None:
         raise CommError("the peer-copy transport's stream memory operations are not captured into a hipGraph: use the eager step")
 
-    def close(self) -> None:
+    def close(self, collective: bool = True) -> None:
         if self.flags:
             torch.cuda.synchronize(self.device)
-            if self.world > 1:
+            if self.world > 1 and collective:
                 dist.barrier(group=self.group)          # nobody unmaps a buffer a peer may still be reading
             for b in self._opened:
                 self.L.pesr_peer_close(b)

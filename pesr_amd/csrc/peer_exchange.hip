@@ -61,6 +61,12 @@ PESR_API int pesr_peer_alloc(size_t bytes, void** ptr, unsigned char* handle64) 
     if (e != hipSuccess) return (int)e;
     e = hipMemset(*ptr, 0, bytes);
     if (e != hipSuccess) return (int)e;
+    // hipMemset of device memory returns before the zeroes are written (it is only ORDERED on the null stream, which the peers'
+    // streams know nothing about): a peer that opens the handle and writes its first flag word could be overtaken by them - the
+    // word is 0 again and this rank waits for ever.  Seen with four ranks on one busy GPU (the transport created in the middle of
+    // a calibration: all four stuck in the constructor's self-test), never with an idle one.
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
     hipIpcMemHandle_t h;
     e = hipIpcGetMemHandle(&h, *ptr);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
@@ -69,6 +75,21 @@ PESR_API int pesr_peer_alloc(size_t bytes, void** ptr, unsigned char* handle64) 
 }
 
 PESR_API int pesr_peer_free(void* ptr) { return (int)hipFree(ptr); }
+
+// Abandon an exchange that does not complete: every wait of THIS rank's streams is a ">= epoch" on a word of its own flag block, so
+// filling the block with 0xffffffff (on a stream of its own: the stuck ones cannot be used) lets all of them run out.  The copies
+// then move whatever the peers' buffers hold - the caller discards the result and the transport.
+PESR_API int pesr_peer_release(void* my_flags, size_t bytes) {
+    if (!my_flags || !bytes) return PESR_EINVAL;
+    hipStream_t s;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    e = hipMemsetAsync(my_flags, 0xff, bytes, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return (int)e;
+}
 
 // IPC handle of the ALLOCATION that contains ptr (the caching allocator hands out pieces of its blocks) and ptr's offset in it.
 PESR_API int pesr_peer_export(const void* ptr, unsigned char* handle64, size_t* offset, size_t* alloc_bytes) {

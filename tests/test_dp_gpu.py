@@ -202,6 +202,56 @@ def test_dp_policy_calibration_one_rank_rccl(monkeypatch):
         _close_group()
 
 
+def test_peer_exchange_that_never_completes_is_abandoned():
+    """pesr_peer_release (ABI 17): an all-reduce whose peer never answers - here a "peer" that is only a second buffer of this
+    process, nobody writes its flag words - leaves the transport's streams waiting; forcing this rank's own flag block lets every
+    wait run out, the device synchronises again and the memory can be freed.  (comm.PeerCopy's constructor does this when its
+    self-test passes a deadline, every rank raises together and the caller falls back to another transport.)"""
+    import ctypes
+    from pesr_amd import _lib, comm
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    h = (ctypes.c_ubyte * 64)()
+    mine_f, peer_f, scratch, ctx = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.pesr_peer_alloc(4096, ctypes.byref(mine_f), h) == 0 and L.pesr_peer_alloc(4096, ctypes.byref(peer_f), h) == 0
+    assert L.pesr_peer_alloc(1 << 16, ctypes.byref(scratch), h) == 0 and L.pesr_peer_ctx_create(2, ctypes.byref(ctx)) == 0
+    a_, b_ = torch.ones(1024, device=dev), torch.full((1024,), 2.0, device=dev)
+    args = comm._PeerArgs()
+    args.rank, args.world, args.epoch, args.numel = 0, 2, 1, 1024
+    args.mine, args.my_flags, args.scratch, args.ctx = a_.data_ptr(), mine_f.value, scratch.value, ctx.value
+    args.peer[0], args.peer[1] = a_.data_ptr(), b_.data_ptr()
+    args.peer_flags[0], args.peer_flags[1] = mine_f.value, peer_f.value
+    s = torch.cuda.Stream(device=dev)
+    assert L.pesr_peer_allreduce(ctypes.byref(args), ctypes.c_void_p(s.cuda_stream)) == 0
+    done = torch.cuda.Event(); done.record(s)
+    import time
+    time.sleep(0.5)
+    assert not done.query()                                   # waiting for a READY nobody sends
+    assert L.pesr_peer_release(mine_f, 4096) == 0
+    t0 = time.monotonic()
+    while not done.query() and time.monotonic() - t0 < 20:
+        time.sleep(0.01)
+    assert done.query()
+    torch.cuda.synchronize(dev)
+    assert torch.equal(a_[:512].cpu(), torch.full((512,), 3.0))       # (the "exchange" itself ran on what was there: 1 + 2 on this rank's half)
+    L.pesr_peer_ctx_destroy(ctx)
+    for p in (mine_f, peer_f, scratch):
+        assert L.pesr_peer_free(p) == 0
+
+
+def test_peer_copy_constructor_gives_up_together():
+    """The constructor's self-test has a deadline: with one rank's first exchange patched out (tests/peer_abandon_worker.py) the
+    other cannot complete - both ranks raise CommError, their streams run out, device and process group stay usable."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "peer_abandon_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rank 0: CommError" in r.stdout and "rank 1: CommError" in r.stdout and "did not complete within 3 s" in r.stdout, r.stdout
+    assert "rank 0: ok" in r.stdout and "rank 1: ok" in r.stdout
+
+
 def _launch_worker(nproc, config, backend, share_gpu, out):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -364,23 +414,24 @@ def test_nn_dataparallel_two_devices_matches_single_device():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in D.parameters())
 
 
-def test_bench_py_two_ranks_share_one_gpu(tmp_path):
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_bench_py_two_ranks_share_one_gpu(tmp_path, nproc):
     """Every world > 1 branch of bench.py (rank / world from the launcher, broadcast of the initial weights, the schedule
     calibration with its max-over-ranks exchange, barriers around the timed region, per-rank gather, rank 0's JSON line, transport
-    shutdown) on a one-GPU box: two ranks time-share cuda:0 over gloo (test hook PESR_DP_SHARE_GPU=1).  The 8-GPU run is the
+    shutdown) on a one-GPU box: two (and four) ranks time-share cuda:0 over gloo (test hook PESR_DP_SHARE_GPU=1).  The 8-GPU run is the
     driver's; this is the rehearsal of its script path at a toy model size."""
     import json
     env = dict(os.environ)
     env.pop("PESR_FORCE_DP", None)
     env.update(PESR_DP_BACKEND="gloo", PESR_DP_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "2",
            "--batch", "4", "--patch_size", "24", "--num_channels", "64", "--num_blocks", "2", "--calib-steps", "1"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["n_gpus"] == nproc and d["config"]["global_batch"] == 4 * nproc and d["config"]["parallelism"] == f"dp{nproc}" and d["scaling"] == "weak"
     assert d["value"] > 0 and d["steps"] == 2 and "test_hook" in d
     pol = d["dp_policy"]
     # the CU-free exchange over peer memory is rehearsed in child processes and timed as a fourth candidate (two ranks on one GPU
@@ -389,7 +440,7 @@ def test_bench_py_two_ranks_share_one_gpu(tmp_path):
     assert set(pol["ms_per_step"]) == {"overlap", "defer_g", "defer_all", "overlap@peer-copy"} and pol["graph_error"] is None      # gloo: no graph candidate
     assert (pol["transport"], pol["chosen"]) in [("torch.distributed[gloo]", c) for c in ("overlap", "defer_g", "defer_all")] + [("peer-copy", "overlap@peer-copy")]
     assert d["per_rank_ms_per_step"]["max"] >= d["per_rank_ms_per_step"]["min"] > 0
-    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    assert abs(d["value"] - 4 * nproc * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
     assert "cpu_baseline" not in d and "side" not in d            # rank 0 of a multi-rank run reports the step only
 
 
