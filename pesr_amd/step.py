@@ -11,6 +11,8 @@ global batch (train.py:137-140), so its local value is multiplied by world_size 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -318,7 +320,8 @@ class Trainer:
             from . import comm
             dev = (self.optim_G or self.optim_D).flat.flat_g.device
             group = (self.optim_G or self.optim_D).buckets.group
-            ok_here, why = comm.probe_direct(dev, group, kind="peer")
+            # (a candidate, not the default: its rehearsal may cost the run 90 s at most - env PESR_DP_PEER_PROBE_TIMEOUT)
+            ok_here, why = comm.probe_direct(dev, group, kind="peer", timeout=float(os.environ.get("PESR_DP_PEER_PROBE_TIMEOUT", "90")))
             (bad,) = tr.host_max([0.0 if ok_here else 1.0])
             if bad:
                 peer_note = "probe: " + (why or "another rank's probe failed")
