@@ -804,15 +804,15 @@ __device__ __forceinline__ void p4_producer(const Wg4Args& a, float* const vring
     const int d_C = a.ps_in ? (a.Cout >> 2) : a.Cout;
     const unsigned x_row_bytes = (unsigned)a.W * a.Cin * 4, d_row_bytes = (unsigned)a.W * a.Cout * 4;
     const unsigned x_side_bytes = (unsigned)(a.side - 1) * a.H * x_row_bytes, d_side_bytes = (unsigned)(a.side - 1) * a.H * d_row_bytes;
-        u32x4 r[16];
+    u32x4 r[16];
     unsigned off[12];                 // byte offsets of the slots' columns from the start of their first row; 2^31 = outside
-    int x0[3];                        // strip-relative first column of the three slots' items (+ 48 * strip)
-    unsigned cb[3], psz[3];           // channel-group byte offset (+ row pitch of the lane's row for V), pixel pitch in bytes
-    int pos[3], rrw[3], tix[3];       // LDS float position inside a plane, row of the pair, x-tile in the strip
-    // slot s of this producer: kind (true = V item), wave-item
+    constexpr int NS = P3 ? 3 : 2;    // slots of this producer: three dM wave-items, or a V wave-item (slot 0, the halo pair shares it) and a dM one
+    int x0[NS];                       // strip-relative first column of the slots' items (+ 48 * strip)
+    unsigned cb[NS], psz[NS];         // channel-group byte offset (+ row pitch of the lane's row for V), pixel pitch in bytes
+    int pos[NS], rrw[NS], tix[NS];    // LDS float position inside a plane, row of the pair, x-tile in the strip
     auto slot_is_v = [&](int s_) { return !P3 && s_ == 0; };
 #pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_) {
+    for (int s_ = 0; s_ < NS; ++s_) {
         if (!P3 && s_ == 0) {                         // V wave-item pw
             const int item = 64 * pw + lane, vt = (item % 96) >> 3, vc4 = item & 7;
             const int sub = a.side > 1 ? vt / XTW : 0;
@@ -837,13 +837,12 @@ __device__ __forceinline__ void p4_producer(const Wg4Args& a, float* const vring
             }
         }
     }
-    // producers 0..2 use slots 0 (V) and 1 (dM); slot 2's constants are unused there (H shares slot 0's)
     int s_xs = 0;
     auto set_strip = [&](int xs, int grp) {               // (once per strip: the only place the offsets cost VALU instructions)
         const int dx = (xs - s_xs) * 48;
         s_xs = xs;
 #pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_) {
+        for (int s_ = 0; s_ < NS; ++s_) {
             x0[s_] += dx;
             int xx = x0[s_];
             if (a.side > 1 && grp * a.side + tix[s_] / XTW >= a.N) xx += 0x100000;       // an image of the last group that does not exist
@@ -853,8 +852,7 @@ __device__ __forceinline__ void p4_producer(const Wg4Args& a, float* const vring
                 if (j >= ncol) continue;
                 const unsigned x = (unsigned)(xx + j);
                 const unsigned o = x < (unsigned)a.W ? cb[s_] + x * psz[s_] : 0x80000000u;
-                if constexpr (!P3) { if (s_ == 0) off[j] = o; else if (s_ == 1) off[6 + j] = o; }
-                else off[4 * s_ + j] = o;
+                off[(P3 ? 4 : 6) * s_ + j] = o;
             }
         }
     };
@@ -890,8 +888,7 @@ __device__ __forceinline__ void p4_producer(const Wg4Args& a, float* const vring
         }
         // dM wave-items
 #pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_) {
-            if (!P3 && s_ != 1) continue;
+        for (int s_ = P3 ? 0 : 1; s_ < NS; ++s_) {
             const int oy = g.row + __builtin_amdgcn_readfirstlane(rrw[s_]);
             const bool row_ok = oy < a.H;
             const int ry = row_ok ? oy : 0;
