@@ -315,6 +315,39 @@ def test_conv3x3_wgrad_narrow_images_side_by_side(N, H, W, Cin, Cout):
         _close(acc_w.cpu().double(), 2 * dw_ref, 1e-5); _close(acc_b.cpu().double(), 2 * db_ref, 1e-5)
 
 
+def test_conv3x3_wgrad_producer_kernel_random_shape_sweep():
+    """The 16-wave weight-gradient kernel (four producer waves) over random shapes the planner accepts - odd heights, strips that
+    end half empty, several images side by side in a strip with an odd image count, one segment per split-K slice, with and without
+    the bias gradient, accumulating -: bit-identical to round 4's 12-wave kernel (same transform, same order of additions) and
+    within 1e-5 of the oracle."""
+    from pesr_amd import ops
+    import random
+    rng = random.Random(31)
+    done = 0
+    for it in range(200):
+        if done == 24:
+            break
+        N = rng.randint(1, 13); H = rng.randint(1, 27)
+        W = rng.choice([8, 12, 16, 24, 48, 48, 96, 92, 144]); Cin = rng.choice([64, 128, 256]); Cout = rng.choice([64, 128, 192])
+        if ops.wgrad_kernel_for(N, H, W, Cin, Cout)[0] != "conv3x3_wgrad_wino4p_kernel":
+            continue
+        done += 1
+        x = _rand(N, Cin, H, W, seed=3000 + it); w = _rand(Cout, Cin, 3, 3, seed=3100 + it, scale=0.1)
+        dy = _rand(N, Cout, H, W, seed=3200 + it)
+        _, dw_ref, db_ref = O.conv3x3_grads(x.double(), w.double(), dy.double())
+        want_bias = bool(it & 1)
+        dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, algo=ops.WGRAD_AUTO, want_bias=want_bias)
+        dw2, db2 = ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, algo=ops.WGRAD_WINO4_12W, want_bias=want_bias)
+        assert torch.equal(dw, dw2), (N, H, W, Cin, Cout)
+        _close(dw.cpu().double(), dw_ref, 1e-5)
+        if want_bias:
+            assert torch.equal(db, db2), (N, H, W, Cin, Cout)
+            _close(db.cpu().double(), db_ref, 1e-5)
+            ops.conv3x3_wgrad(_nhwc(x), _nhwc(dy), 1, algo=ops.WGRAD_AUTO, dw_out=dw, db_out=db, accumulate=True)
+            _close(dw.cpu().double(), 2 * dw_ref, 1e-5); _close(db.cpu().double(), 2 * db_ref, 1e-5)
+    assert done == 24
+
+
 def test_conv3x3_wgrad_winograd4_pixel_shuffle_fused():
     """Weight gradient of an upsampler conv (its output gradient arrives pixel-shuffled) on the F(4,3) kernel."""
     import torch.nn.functional as F
