@@ -5,6 +5,7 @@ scalar losses rtol 1e-5 (2e-5 after two optimizer steps)."""
 import warnings
 
 import numpy as np
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -275,24 +276,36 @@ def test_gv2c_generator_full_batch1():
 
 
 def test_train_entrypoint_runs(tmp_path):
-    import importlib.util, os
-    spec = importlib.util.spec_from_file_location("entry_train", os.path.join(os.path.dirname(os.path.dirname(__file__)), "train.py"))
-    Tm = importlib.util.module_from_spec(spec); spec.loader.exec_module(Tm)
-    common = ["--synthetic", "16", "--num_channels", "64", "--num_blocks", "2", "--patch_size", "8", "--batch_size", "4",
-              "--num_epochs", "1", "--max_iters", "2", "--check_point", str(tmp_path / "ck"), "--snapshot_every", "1"]
-    Tm.main(common + ["--phase", "pretrain"])
+    """train.py end to end (pretrain, train from the pretrained checkpoint, train with --hip_graph true) in a FRESH interpreter:
+    its DataLoader workers are forked, and forking this test process - tens of GB of mappings after the tests before it - took
+    ~10 s per worker (139 s for this test; 7 s of it the entry point itself)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck, ckg = str(tmp_path / "ck"), str(tmp_path / "ck_graph")
+    prog = f"""
+import importlib.util, os, sys
+sys.path.insert(0, {root!r})
+spec = importlib.util.spec_from_file_location("entry_train", os.path.join({root!r}, "train.py"))
+Tm = importlib.util.module_from_spec(spec); spec.loader.exec_module(Tm)
+def common(ck, iters):
+    return ["--synthetic", "16", "--num_channels", "64", "--num_blocks", "2", "--patch_size", "8", "--batch_size", "4",
+            "--num_epochs", "1", "--max_iters", str(iters), "--check_point", ck, "--snapshot_every", "1"]
+Tm.main(common({ck!r}, 2) + ["--phase", "pretrain"])
+best = os.path.join({ck!r}, "pretrain", "best_model.pt")
+assert os.path.exists(best)
+Tm.main(common({ck!r}, 2) + ["--phase", "train", "--pretrained_model", best])
+# --hip_graph: two iterations eager, then the captured step replayed twice (bit-equality of replay and eager is pinned at
+# Trainer level in test_gan_step_hipgraph_replay_is_bit_identical_to_eager; D is initialised unseeded here, as in the
+# reference, so two runs of the entry point are not comparable)
+Tm.main(common({ckg!r}, 4) + ["--phase", "train", "--pretrained_model", best, "--hip_graph", "true"])
+print("ENTRY_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0 and "ENTRY_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert (tmp_path / "ck" / "pretrain" / "best_model.pt").exists()
-    Tm.main(common + ["--phase", "train", "--pretrained_model", str(tmp_path / "ck" / "pretrain" / "best_model.pt")])
     sd = torch.load(tmp_path / "ck" / "train" / "model_1.pt", map_location="cpu")
     assert list(sd.keys()) == list(OM.generator_shapes(64, 2).keys())      # the reference's checkpoint schema
-    # --hip_graph: two iterations eager, then the captured step replayed twice (bit-equality of replay and eager is pinned at
-    # Trainer level in test_gan_step_hipgraph_replay_is_bit_identical_to_eager; D is initialised unseeded here, as in the
-    # reference, so two runs of the entry point are not comparable)
-    four = [a if a != "2" or common[i - 1] != "--max_iters" else "4" for i, a in enumerate(common)]
-    ck = tmp_path / "ck_graph"
-    Tm.main([a if a != str(tmp_path / "ck") else str(ck) for a in four] +
-            ["--phase", "train", "--pretrained_model", str(tmp_path / "ck" / "pretrain" / "best_model.pt"), "--hip_graph", "true"])
-    sdg = torch.load(ck / "train" / "model_1.pt", map_location="cpu")
+    sdg = torch.load(tmp_path / "ck_graph" / "train" / "model_1.pt", map_location="cpu")
     assert list(sdg.keys()) == list(sd.keys()) and all(bool(torch.isfinite(v).all()) for v in sdg.values())
     assert any(not torch.equal(sdg[k], sd[k]) for k in sd)                  # it trained
 
