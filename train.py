@@ -96,7 +96,8 @@ def make_loaders(args, rank, world, need_train=True):
     if train_set is not None:
         sampler = DistributedSampler(train_set, world, rank, shuffle=True, drop_last=True) if world > 1 else None
         train_loader = DataLoader(train_set, batch_size=args.batch_size // world, shuffle=sampler is None, sampler=sampler,
-                                  num_workers=4, pin_memory=True, drop_last=True)
+                                  num_workers=4, pin_memory=True, drop_last=True, persistent_workers=True)   # (forked once: a fork of a
+        # process with a GPU context's mappings takes seconds, and without this flag every epoch forks its four workers anew)
     val_loader = DataLoader(val_set, batch_size=1, shuffle=False, num_workers=1, pin_memory=True)
     return train_loader, val_loader, sampler
 
