@@ -374,6 +374,10 @@ def main():
         ops.KERNEL_EVENTS.enable(shape=watch, every=args.event_every)
     for o in optims:
         o.buckets.measure_exposed = not use_graph
+    dp_transports = trainer._transports() if dp_on else []
+    for t_ in dp_transports:
+        t_.collective_times()                      # (drop whatever the warm-up left)
+        t_.time_collectives = not use_graph         # HIP events on the communication stream around every all-reduce of the timed steps
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -389,6 +393,22 @@ def main():
     exposed = [o.buckets.exposed_ms() for o in optims]
     for o in optims:
         o.buckets.measure_exposed = False
+    coll = []
+    for t_ in dp_transports:
+        t_.time_collectives = False
+        coll += t_.collective_times()
+    # which engine moved the peer copies (only the peer-memory transport has any), and: are the replicas still identical?
+    peer_engine = None
+    if dp_transports and dp_transports[0].name == "peer-copy" and world > 1:
+        peer_engine = dp_transports[0].copy_engine_probe(optims[-1].flat.flat_g)
+    replica_check = None
+    if world > 1:
+        sums = torch.stack([o.flat.flat_p.double().sum() for o in optims] + [o.flat.flat_p.double().abs().sum() for o in optims])
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replica_check = {"identical": bool(torch.equal(lo, hi)), "what": "sum and abs-sum (float64) of every optimizer's flat parameter buffer after the "
+                         "timed steps: MIN over ranks == MAX over ranks (replicas that received different gradient sums diverge)"}
     if use_graph and not args.no_kernel_events:     # events cannot be read back from inside a graph: two eager steps for them
         ops.KERNEL_EVENTS.enable(shape=watch)
         for _ in range(2):
@@ -474,8 +494,32 @@ def main():
                                  "all-reduces launched from the autograd hooks under backward; defer_g = G's gradients as ONE all-reduce after "
                                  "its backward pass; defer_all = D's too; graph+X = the step with schedule X captured as one hipGraph; the timed "
                                  "region ran `chosen`")
+    if dp_info is not None and dp_on:
+        from pesr_amd import comm as _comm
+        out["dp_bringup"] = _comm.bringup_log()
+        out["dp_transport"] = {"name": dp_transports[0].name if dp_transports else None,
+                               "fallback_reason": dp_info.get("fallback_reason") or getattr(dp_transports[0], "fallback_reason", None) if dp_transports else None}
+    if coll:
+        # per bucket size: mean time on the communication stream (from the collective's start - which includes waiting for the slowest
+        # peer to arrive - to its end) and the rates that follow: algbw = bytes / time, busbw = algbw x 2 (N - 1) / N (ring convention)
+        by = {}
+        for nb, ms_ in coll:
+            by.setdefault(nb, []).append(ms_)
+        fac = 2.0 * (world - 1) / world if world > 1 else 1.0
+        out["dp_collectives"] = {"per_step": round(len(coll) / args.steps, 2),
+                                 "buckets": [{"bytes": nb, "n": len(v), "mean_ms": round(sum(v) / len(v), 3), "min_ms": round(min(v), 3),
+                                              "algbw_GB_per_s": round(nb / (sum(v) / len(v)) / 1e6, 1), "busbw_GB_per_s": round(fac * nb / (sum(v) / len(v)) / 1e6, 1),
+                                              "busbw_best_GB_per_s": round(fac * nb / min(v) / 1e6, 1)} for nb, v in sorted(by.items())],
+                                 "total_ms_per_step": round(sum(m for _, m in coll) / args.steps, 3),
+                                 "note": "rank 0, HIP events on the transport's communication stream around every gradient all-reduce of the timed steps; "
+                                         "the time includes waiting for the last rank to reach the collective and any slowdown from sharing the GPU with backward kernels"}
+    if peer_engine is not None:
+        out["peer_copy_engine"] = peer_engine
+    if replica_check is not None:
+        out["replica_check"] = replica_check
     if any(n for _, n in exposed):
         out["comm_exposed_ms"] = round(sum(ms for ms, n in exposed if n), 3)
+        out["comm_exposed_ms_by_optimizer"] = {("D" if o is trainer.optim_D else "G"): round(ms, 3) for o, (ms, n) in zip(optims, exposed) if n}
         out["comm_exposed_note"] = ("per step: time the compute stream stood waiting in FlatAdam.step for gradient all-reduces that "
                                     "backward had not covered (HIP events around the waits, D + G optimizers, rank 0)")
     if per_rank:

@@ -336,6 +336,10 @@ int pesr_peer_export(const void* ptr, unsigned char* handle64, size_t* offset, s
 int pesr_peer_open(const unsigned char* handle64, void** base);
 int pesr_peer_close(void* base);
 int pesr_peer_allreduce(const void* args, void* stream);
+/* (ABI 18) measurement helper: which engine moves a copy out of a peer mapping?  Times hipMemcpyAsync(dst <- src, bytes) alone, then started
+ * while a kernel holds every wave slot of this GPU for hog_us microseconds (100 .. 50000), and that kernel: out_ms[3] = {alone, under the
+ * hog, hog}.  A blit kernel waits for the hog, a copy engine does not.  Synchronises its own two streams. */
+int pesr_peer_copy_probe(const void* src, void* dst, size_t bytes, int hog_us, float* out_ms);
 
 /* ---- generic k x k conv, odd k != 3 (reference `Conv(in, out, kernel_size, stride, bias)`, model/basic.py:4-7, accepts any
  * kernel size; its networks only use 3): padding k/2, NHWC activations, w OIHW [Cout][Cin][k][k] (not packed).  Plain VALU

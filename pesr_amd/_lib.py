@@ -97,6 +97,7 @@ SIGNATURES.update({
     "pesr_peer_allreduce": (c_int, [_P, _P]),
     "pesr_peer_ctx_create": (c_int, [c_int, _P]),
     "pesr_peer_ctx_destroy": (c_int, [_P]),
+    "pesr_peer_copy_probe": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "pesr_gan_loss_fwd_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     "pesr_conv_kxk_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pesr_conv_kxk_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

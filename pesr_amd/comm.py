@@ -41,6 +41,40 @@ class CommError(RuntimeError):
     pass
 
 
+# ---- ONE wall-clock budget for everything a multi-rank run does before its first timed step (round 6) ---------------------------
+# Probes in child processes (`probe_direct`, RCCL and peer memory), the transports' self-tests and Trainer.calibrate_dp_policy all
+# draw on it: PESR_DP_BRINGUP_BUDGET seconds (default 300) from the first get_transport() of the process.  When it is spent the
+# remaining probes / candidates are skipped, every rank runs `overlap` on the best transport that is up, and the reason is kept in
+# the calibration record (`fallback_reason`).  Decisions are taken on the MAX over ranks of the time spent, so all ranks agree.
+_BRINGUP = {"t0": None, "log": []}
+
+
+def bringup_budget() -> float:
+    return float(os.environ.get("PESR_DP_BRINGUP_BUDGET", "300"))
+
+
+def bringup_start() -> None:
+    if _BRINGUP["t0"] is None:
+        _BRINGUP["t0"] = time.monotonic()
+
+
+def bringup_spent() -> float:
+    bringup_start()
+    return time.monotonic() - _BRINGUP["t0"]
+
+
+def bringup_left() -> float:
+    return bringup_budget() - bringup_spent()
+
+
+def bringup_note(what: str, seconds: float, ok=True, detail: str = "") -> None:
+    _BRINGUP["log"].append({"what": what, "s": round(seconds, 2), "ok": bool(ok), **({"detail": detail[:300]} if detail else {})})
+
+
+def bringup_log():
+    return {"budget_s": bringup_budget(), "spent_s": round(bringup_spent(), 2), "steps": list(_BRINGUP["log"])}
+
+
 class _UniqueId(ctypes.Structure):
     _fields_ = [("internal", ctypes.c_char * NCCL_UNIQUE_ID_BYTES)]
 
@@ -88,9 +122,33 @@ class Transport:
     name = "?"
     world = 1
     capturable = False
+    # time_collectives = True: transports that own their communication stream (DirectRccl, PeerCopy) bracket every all-reduce with
+    # HIP timing events ON THAT STREAM; collective_times() -> [(bytes, ms)] (bench.py's per-bucket GB/s).  Not under capture.
+    time_collectives = False
 
     def all_reduce_async(self, t: torch.Tensor):
         raise NotImplementedError
+
+    def _timing_begin(self, stream, nbytes):
+        if not self.time_collectives or torch.cuda.is_current_stream_capturing():
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        return (nbytes, e0)
+
+    def _timing_end(self, br, stream):
+        if br is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(stream)
+            self.__dict__.setdefault("_timed", []).append((br[0], br[1], e1))
+
+    def collective_times(self):
+        """-> [(bytes, milliseconds on the communication stream)] of the all-reduces since the last call (synchronises)."""
+        ev, self.__dict__["_timed"] = self.__dict__.get("_timed", []), []
+        if not ev:
+            return []
+        torch.cuda.synchronize()
+        return [(n, a.elapsed_time(b)) for n, a, b in ev]
 
     def wait(self, handles) -> None:
         raise NotImplementedError
@@ -144,7 +202,9 @@ class DirectRccl(Transport):
         ready.record(cur)                      # fork: the collective reads what the current stream has written so far
         self.stream.wait_event(ready)
         dt = NCCL_FLOAT32 if t.dtype == torch.float32 else NCCL_FLOAT64
+        br = self._timing_begin(self.stream, t.numel() * t.element_size()) if op == NCCL_SUM else None
         _check(rccl_lib().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, op, self._comm, self.stream.cuda_stream), "ncclAllReduce")
+        self._timing_end(br, self.stream)
         done = torch.cuda.Event()
         done.record(self.stream)
         return done
@@ -196,39 +256,53 @@ class PeerCopy(Transport):
         self.L = _lib.lib()
         self.device, self.rank, self.world, self.group = device, rank, world, group
         self.epoch = 0
-        self.regs = []                   # registered allocations: (base, bytes, [every rank's mapping of its allocation; own = base])
+        # registered STORAGES (round 6): {(storage address, bytes): (the storage - kept alive, so the address cannot be
+        # handed to another tensor while it is registered -, [every rank's mapping of ITS storage's first byte; own = the address])}
+        self.regs = {}
+        self._verified = set()           # (storage key, byte offset, numel) whose placement every rank has confirmed to be the same
+        self._open_cache = {}            # (rank, IPC handle) -> base of that allocation as mapped here (one mapping per allocation)
         self._opened = []
         self.scratch, self.scratch_bytes = ctypes.c_void_p(), 0
         self.ctx = ctypes.c_void_p()
         with torch.cuda.device(device):
             self.stream = torch.cuda.Stream(device=device)
-            _check_hip(self.L.pesr_peer_ctx_create(world, ctypes.byref(self.ctx)), "pesr_peer_ctx_create")
+            # (a context or flag block that cannot be made HERE goes through the same agreed-error path as a failed mapping: every
+            # rank raises together instead of one rank leaving the others in the collective)
+            rc_ctx = self.L.pesr_peer_ctx_create(world, ctypes.byref(self.ctx))
             self.flags = ctypes.c_void_p()
             h = (ctypes.c_ubyte * 64)()
-            rc = self.L.pesr_peer_alloc(self.FLAG_BYTES, ctypes.byref(self.flags), h)
-            self.peer_flags = self._exchange(bytes(h) if rc == 0 else None, 0, self.flags.value or 0, "the flag block")
+            rc = self.L.pesr_peer_alloc(self.FLAG_BYTES, ctypes.byref(self.flags), h) if rc_ctx == 0 else rc_ctx
+            try:
+                self.peer_flags = self._exchange(bytes(h) if rc == 0 else None, 0, self.flags.value or 0, "the context / flag block")
+            except CommError:
+                self.close(collective=False)
+                raise
         # self-test: every rank contributes rank + 1 -> world (world + 1) / 2, twice (the epochs count on).  With a DEADLINE: an exchange
         # that does not complete (a flag write that never arrives) is abandoned - this rank's own flag words are forced, its streams
         # run out - and every rank raises together; the caller falls back to another transport.
         t = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
         deadline = float(os.environ.get("PESR_PEER_SELFTEST_TIMEOUT", "30"))
         err = None
-        for k in (1, 2):
-            done = self.all_reduce_async(t)
-            t0 = time.monotonic()
-            while not done.query() and time.monotonic() - t0 < deadline:
-                time.sleep(0.001)
-            if not done.query():
-                err = f"self-test {k} did not complete within {deadline:.0f} s"
-                with torch.cuda.device(device):
-                    self.L.pesr_peer_release(self.flags, self.FLAG_BYTES)
-                torch.cuda.synchronize(device)
-                break
-            self.wait([done])
-            want = float(world * (world + 1) // 2) * world ** (k - 1)
-            if [float(x) for x in t.cpu()] != [want] * 8:
-                err = f"self-test {k}: expected {want}, got {t.cpu().tolist()}"
-                break
+        try:
+            for k in (1, 2):
+                done = self.all_reduce_async(t)
+                t0 = time.monotonic()
+                while not done.query() and time.monotonic() - t0 < deadline:
+                    time.sleep(0.001)
+                if not done.query():
+                    err = f"self-test {k} did not complete within {deadline:.0f} s"
+                    with torch.cuda.device(device):
+                        self.L.pesr_peer_release(self.flags, self.FLAG_BYTES)
+                    torch.cuda.synchronize(device)
+                    break
+                self.wait([done])
+                want = float(world * (world + 1) // 2) * world ** (k - 1)
+                if [float(x) for x in t.cpu()] != [want] * 8:
+                    err = f"self-test {k}: expected {want}, got {t.cpu().tolist()}"
+                    break
+        except CommError as e:              # (raised by every rank together: _lookup's agreed-error path)
+            self.close(collective=False)
+            raise
         if world > 1:
             errs = [None] * world
             dist.all_gather_object(errs, err, group=group)
@@ -241,14 +315,23 @@ class PeerCopy(Transport):
         if err:
             self.close(collective=False)
             raise CommError("peer-copy " + err)
+        # the self-test tensor's registration is dropped: its small-pool block will hold other tensors later, and nothing may be
+        # looked up through a placement that was agreed for THIS tensor
+        torch.cuda.synchronize(device)
+        self.regs.clear()
+        self._verified.clear()
 
-    def _exchange(self, handle, offset: int, own_ptr: int, what: str):
+    def _exchange(self, handle, offset: int, own_ptr: int, what: str, extra_ok=None):
         """All ranks' (handle, offset) -> every rank's pointer as mapped here (own: own_ptr).  handle None = this rank could not
-        make one: every rank then raises together (a rank that raised alone would leave the others waiting in the collective)."""
+        make one: every rank then raises together (a rank that raised alone would leave the others waiting in the collective).
+        extra_ok: a callable run after the mappings exist (scratch allocation); its exception counts as this rank's failure in the
+        same agreed round."""
         mine = (self.rank, handle, int(offset))
         if self.world == 1:
             if handle is None:
                 raise CommError(f"peer-copy: {what} failed")
+            if extra_ok is not None:
+                extra_ok()
             return [own_ptr]
         got = [None] * self.world
         dist.all_gather_object(got, mine, group=self.group)
@@ -259,15 +342,23 @@ class PeerCopy(Transport):
                 if r == self.rank:
                     out.append(own_ptr)
                     continue
-                base = ctypes.c_void_p()
-                hb = (ctypes.c_ubyte * 64).from_buffer_copy(h)
-                with torch.cuda.device(self.device):
-                    rc = self.L.pesr_peer_open(hb, ctypes.byref(base))
-                if rc != 0:
-                    err = f"pesr_peer_open(rank {r}) error {rc}"
-                    break
-                self._opened.append(base)
-                out.append(base.value + off)
+                base = self._open_cache.get((r, h))
+                if base is None:
+                    bp = ctypes.c_void_p()
+                    hb = (ctypes.c_ubyte * 64).from_buffer_copy(h)
+                    with torch.cuda.device(self.device):
+                        rc = self.L.pesr_peer_open(hb, ctypes.byref(bp))
+                    if rc != 0:
+                        err = f"pesr_peer_open(rank {r}) error {rc}"
+                        break
+                    self._opened.append(bp)
+                    base = self._open_cache[(r, h)] = bp.value
+                out.append(base + off)
+            if err is None and extra_ok is not None:
+                try:
+                    extra_ok()
+                except Exception as e:
+                    err = f"{type(e).__name__}: {e}"
         ok = [None] * self.world
         dist.all_gather_object(ok, err is None, group=self.group)     # (second round: a mapping that failed on ONE rank stops all)
         if bad or not all(ok):
@@ -275,28 +366,35 @@ class PeerCopy(Transport):
         return out
 
     def _lookup(self, t: torch.Tensor):
-        p = t.data_ptr()
-        for base, nbytes, peers in self.regs:
-            if base <= p and p + t.numel() * 4 <= base + nbytes:
-                return base, peers
-        # first use of this allocation (a flat gradient buffer): all ranks get here in the same order
-        h = (ctypes.c_ubyte * 64)()
-        off, size = ctypes.c_size_t(), ctypes.c_size_t()
-        with torch.cuda.device(self.device):
-            rc = self.L.pesr_peer_export(ctypes.c_void_p(p), h, ctypes.byref(off), ctypes.byref(size))
-        base = p - off.value
-        peers = self._exchange(bytes(h) if rc == 0 else None, 0, base, "the export of a gradient buffer")        # every rank's allocation BASE as mapped here
-        # the same tensor sits at the same offset FROM ITS OWN BASE only if the allocators behaved alike: exchange the offsets too
-        offs = [None] * self.world
-        if self.world > 1:
-            dist.all_gather_object(offs, (self.rank, off.value), group=self.group)
-        else:
-            offs = [(0, off.value)]
-        self.regs.append((base, size.value, [pb + dict(offs)[r] - off.value for r, pb in enumerate(peers)]))
-        # scratch for the largest tensor this allocation can hold, NOW (every rank is here, nothing of it is in flight): growing
-        # it later would need a device synchronisation in the middle of a backward pass
-        self._ensure_scratch((size.value - off.value) // 4)
-        return self.regs[-1][0], self.regs[-1][2]
+        """-> every rank's mapping (as seen here) of the address that corresponds to t.data_ptr().  Registration is per STORAGE (a
+        flat gradient buffer), not per allocator block: each rank exports the allocation that holds its storage together with the
+        storage's offset in it, so two buffers the caching allocator happened to place in one block - or at different offsets on
+        different ranks - each get their own, correct, mapping.  Every new (offset, length) inside a storage is confirmed once to be
+        the same on all ranks (buckets are cut alike everywhere; a mismatch raises on every rank instead of summing the wrong bytes).
+        All ranks get here in the same order: the collectives line up."""
+        st = t.untyped_storage()
+        key = (st.data_ptr(), st.nbytes())
+        rel = t.data_ptr() - key[0]
+        ent = self.regs.get(key)
+        if ent is None:
+            h = (ctypes.c_ubyte * 64)()
+            off, size = ctypes.c_size_t(), ctypes.c_size_t()
+            with torch.cuda.device(self.device):
+                rc = self.L.pesr_peer_export(ctypes.c_void_p(key[0]), h, ctypes.byref(off), ctypes.byref(size))
+            # scratch for the largest tensor this storage can hold, NOW (every rank is here, nothing of it is in flight): growing
+            # it later would need a device synchronisation in the middle of a backward pass; a failure is agreed like a mapping's
+            peers = self._exchange(bytes(h) if rc == 0 else None, off.value, key[0], "the export of a gradient buffer",
+                                   extra_ok=lambda: self._ensure_scratch(key[1] // 4))
+            ent = self.regs[key] = (st, peers)
+        vkey = (key, rel, t.numel())
+        if vkey not in self._verified:
+            if self.world > 1:
+                seen = [None] * self.world
+                dist.all_gather_object(seen, (rel, t.numel(), key[1]), group=self.group)
+                if any(x != seen[0] for x in seen):
+                    raise CommError(f"peer-copy: the ranks disagree on a bucket's placement (offset, numel, buffer bytes): {seen}")
+            self._verified.add(vkey)
+        return [pb + rel for pb in ent[1]]
 
     def _ensure_scratch(self, numel: int) -> None:
         slice_elems = ((numel + self.world - 1) // self.world + 3) & ~3
@@ -306,29 +404,55 @@ class PeerCopy(Transport):
                 torch.cuda.synchronize(self.device)
                 if self.scratch:
                     self.L.pesr_peer_free(self.scratch)
+                    self.scratch, self.scratch_bytes = ctypes.c_void_p(), 0
                 h = (ctypes.c_ubyte * 64)()
-                self.scratch = ctypes.c_void_p()
-                _check_hip(self.L.pesr_peer_alloc(need, ctypes.byref(self.scratch), h), "pesr_peer_alloc(scratch)")
-                self.scratch_bytes = need
+                sc = ctypes.c_void_p()
+                _check_hip(self.L.pesr_peer_alloc(need, ctypes.byref(sc), h), "pesr_peer_alloc(scratch)")
+                self.scratch, self.scratch_bytes = sc, need
+
+    def copy_engine_probe(self, t: torch.Tensor, nbytes: int = 64 << 20, hog_us: int = 20000):
+        """Which engine moves this transport's peer copies?  A copy of `nbytes` out of the NEXT rank's mapping of tensor t's buffer into
+        scratch, timed alone and started while a kernel holds every wave slot of this GPU for hog_us (pesr_peer_copy_probe): a blit
+        kernel has to wait for the hog, a copy engine does not.  -> dict (bench.py's `peer_copy_engine`); all ranks call it together."""
+        if self.world < 2:
+            return None
+        peers = self._lookup(t)
+        nbytes = min(int(nbytes), t.numel() * 4, self.scratch_bytes)
+        out = (ctypes.c_float * 3)()
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            dist.barrier(group=self.group)           # nobody is writing the buffers that are read here
+        with torch.cuda.device(self.device):
+            rc = self.L.pesr_peer_copy_probe(ctypes.c_void_p(peers[(self.rank + 1) % self.world]), self.scratch, nbytes, int(hog_us), out)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        if rc != 0:
+            return {"error": f"pesr_peer_copy_probe: error {rc}"}
+        alone, under, hog = float(out[0]), float(out[1]), float(out[2])
+        return {"bytes": nbytes, "copy_alone_ms": round(alone, 3), "copy_under_cu_hog_ms": round(under, 3), "cu_hog_ms": round(hog, 3),
+                "GB_per_s_alone": round(nbytes / alone / 1e6, 1) if alone > 0 else None,
+                "engine": "copy engine (not held up by a kernel on every wave slot)" if under < alone + 0.5 * hog else
+                          "blit kernel on the compute units (waited for the hog kernel)"}
 
     def all_reduce_async(self, t: torch.Tensor):
         assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() % 4 == 0, "peer-copy: fp32, numel % 4 == 0"
-        base, peers = self._lookup(t)
-        rel = t.data_ptr() - base
+        peers = self._lookup(t)                  # every rank's mapping of THIS tensor's first byte
         self._ensure_scratch(t.numel())          # (a no-op after the registration above)
         self.epoch += 1
         a = _PeerArgs()
         a.rank, a.world, a.epoch, a.numel = self.rank, self.world, self.epoch, t.numel()
         a.mine, a.my_flags, a.scratch, a.ctx = t.data_ptr(), self.flags.value, self.scratch.value, self.ctx.value
         for r in range(self.world):
-            a.peer[r] = peers[r] + rel        # (peers[r] is rank r's mapping of the address that corresponds to `base`)
+            a.peer[r] = peers[r]
             a.peer_flags[r] = self.peer_flags[r]
         cur = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(cur)                      # fork: the exchange reads what the current stream has written so far
         self.stream.wait_event(ready)
+        br = self._timing_begin(self.stream, t.numel() * 4)
         with torch.cuda.device(self.device):
             _check_hip(self.L.pesr_peer_allreduce(ctypes.byref(a), ctypes.c_void_p(self.stream.cuda_stream)), "pesr_peer_allreduce")
+        self._timing_end(br, self.stream)
         done = torch.cuda.Event()
         done.record(self.stream)
         return done
@@ -359,11 +483,15 @@ class PeerCopy(Transport):
             for b in self._opened:
                 self.L.pesr_peer_close(b)
             self._opened = []
+            self._open_cache.clear()
             if self.scratch:
                 self.L.pesr_peer_free(self.scratch)
             self.L.pesr_peer_free(self.flags)
+            self.flags, self.scratch = ctypes.c_void_p(), ctypes.c_void_p()
+            self.regs.clear()
+        if self.ctx:
             self.L.pesr_peer_ctx_destroy(self.ctx)
-            self.flags, self.scratch, self.ctx = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            self.ctx = ctypes.c_void_p()
 
 
 def _check_hip(rc: int, what: str) -> None:
@@ -401,23 +529,20 @@ class TorchGroup(Transport):
 def probe_direct(device: Optional[torch.device], group=None, timeout: Optional[float] = None, kind: str = "rccl"):
     """Can the direct RCCL transport (kind "rccl") / the peer-memory transport (kind "peer") come up among THESE ranks?  Answered in child processes (`pesr_amd.comm_probe`, one per rank,
     rendezvous among themselves over gloo on a port rank 0 picks): communicator, a 32 MB all-reduce with a known answer, a MAX
-    all-reduce, teardown.  A child that has not exited after `timeout` seconds (env PESR_DP_PROBE_TIMEOUT, default 180) is killed.
+    all-reduce, teardown.  A child that has not exited after `timeout` seconds (env PESR_DP_PROBE_TIMEOUT, default 180; never more
+    than what is left of the bring-up budget minus a reserve for the calibration) is killed.
     Returns (ok on THIS rank, reason); the caller agrees the answer over the ranks.  Why a child: `ncclCommInitRank` called through
     ctypes cannot be abandoned once it hangs (a partial failure - some ranks in, some out - leaves the others waiting in C),
-    and no multi-GPU node was available to run that path before the first one the benchmark sees."""
+    and no multi-GPU node was available to run that path before the first one the benchmark sees.
+    The rendezvous port is picked by bind-and-close on rank 0 and re-bound by the children a moment later; should another process
+    take it in between, the children fail to meet - that ONE kind of failure is retried once on a fresh port (agreed over the ranks:
+    every rank takes part in the second round or none does)."""
     import socket
     import subprocess
     import sys
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     timeout = float(timeout if timeout is not None else os.environ.get("PESR_DP_PROBE_TIMEOUT", "180"))
-    port = [0]
-    if rank == 0:
-        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-            s.bind(("", 0))
-            port[0] = s.getsockname()[1]
-    if world > 1:
-        src = 0 if group is None else dist.get_global_rank(group, 0)
-        dist.broadcast_object_list(port, src=src, group=group)
+    timeout = min(timeout, max(15.0, bringup_left() - 45.0))       # (never more than what the bring-up budget leaves, less a reserve for the calibration)
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     index = device.index if device is not None and device.type == "cuda" and device.index is not None else 0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -427,22 +552,52 @@ def probe_direct(device: Optional[torch.device], group=None, timeout: Optional[f
             "ROLE_NAME", "MASTER_PORT", "PESR_FORCE_DP"}
     env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC")}
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-    cmd = [sys.executable, "-m", "pesr_amd.comm_probe", str(rank), str(world), str(index), addr, str(port[0]), str(max(10.0, timeout - 10.0)), kind]
-    try:
-        p = subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-    except OSError as e:
-        return False, f"probe child did not start: {e}"
-    try:
-        _, err = p.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        p.kill()
-        _, err = p.communicate()
-        marks = [l for l in err.decode(errors="replace").splitlines() if l.startswith("comm_probe:")]
-        return False, f"probe child still running after {timeout:.0f} s (killed)" + (f"; last step: {marks[-1][12:]}" if marks else "")
-    if p.returncode != 0:
-        tail = err.decode(errors="replace").strip().splitlines()[-1:] or [""]
-        return False, f"probe child exited {p.returncode}: {tail[0][:300]}"
-    return True, ""
+    t_all = time.monotonic()
+
+    def attempt(tmo):
+        port = [0]
+        if rank == 0:
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("", 0))
+                port[0] = sk.getsockname()[1]
+        if world > 1:
+            src = 0 if group is None else dist.get_global_rank(group, 0)
+            dist.broadcast_object_list(port, src=src, group=group)
+        cmd = [sys.executable, "-m", "pesr_amd.comm_probe", str(rank), str(world), str(index), addr, str(port[0]), str(max(10.0, tmo - 10.0)), kind]
+        try:
+            p = subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        except OSError as e:
+            return False, f"probe child did not start: {e}", False
+        try:
+            _, err = p.communicate(timeout=tmo)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            _, err = p.communicate()
+            marks = [l for l in err.decode(errors="replace").splitlines() if l.startswith("comm_probe:")]
+            return False, f"probe child still running after {tmo:.0f} s (killed)" + (f"; last step: {marks[-1][12:]}" if marks else ""), False
+        if p.returncode != 0:
+            text = err.decode(errors="replace")
+            marks = [l for l in text.splitlines() if l.startswith("comm_probe:")]
+            tail = text.strip().splitlines()[-1:] or [""]
+            # a failure before the communicator step = the children never met (port taken, store timeout): worth one more port
+            at_rendezvous = not any("communicator" in m for m in marks)
+            return False, f"probe child exited {p.returncode}: {tail[0][:300]}", at_rendezvous
+        return True, "", False
+
+    ok, why, retry = attempt(timeout)
+    if world > 1:
+        # retry only if EVERY failing rank failed at the rendezvous and at least one did; all ranks take the same decision
+        flags = [None] * world
+        dist.all_gather_object(flags, (ok, retry), group=group)
+        again = any(not o for o, _ in flags) and all(o or r for o, r in flags) and bringup_left() > 90.0
+    else:
+        again = (not ok) and retry and bringup_left() > 90.0
+    if again:
+        ok2, why2, _ = attempt(max(15.0, min(timeout, bringup_left() - 45.0)))
+        why = "" if ok2 else f"{why2} (second attempt; first: {why})"
+        ok = ok2
+    bringup_note(f"probe[{kind}]", time.monotonic() - t_all, ok, why)
+    return ok, why
 
 
 def make_transport(device: Optional[torch.device], group=None, prefer: Optional[str] = None) -> Transport:
@@ -474,10 +629,12 @@ def make_transport(device: Optional[torch.device], group=None, prefer: Optional[
             fb.fallback_reason = "probe: " + (why or "another rank's probe failed")
             return fb
     tr, reason = None, ""
+    t_init = time.monotonic()
     try:
         tr = DirectRccl(device, dist.get_rank(group), dist.get_world_size(group), group)
     except (CommError, OSError, RuntimeError) as e:      # (decided together below)
         reason = f"{type(e).__name__}: {e}"
+    bringup_note("rccl-direct communicator + self-test", time.monotonic() - t_init, tr is not None, reason)
     ok = torch.tensor([1.0 if tr is not None else 0.0], device=agree_dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if float(ok.item()) == 1.0:
@@ -496,6 +653,7 @@ _TRANSPORTS = {}
 
 def get_transport(device: Optional[torch.device], group=None) -> Transport:
     """One transport per (process group, device), shared by the optimizers of a process (ONE communicator for G and D)."""
+    bringup_start()
     key = (None if group is None else id(group), None if device is None or device.type != "cuda" else device.index)
     tr = _TRANSPORTS.get(key)
     if tr is None:

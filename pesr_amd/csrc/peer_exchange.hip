@@ -35,8 +35,16 @@ struct PeerArgs {           // mirrors PesrPeerArgs of include/pesr_hip.h
 struct PeerCtx {
     hipStream_t side[PEER_MAX];
     hipEvent_t fork, join[PEER_MAX];
+    hipEvent_t release;               // hipEventReleaseToSystem: recorded in front of every flag the PEERS' copies wait for (round 6)
     int n;
 };
+
+// occupies every wave slot of the GPU for `ticks` of the 100 MHz wall clock (pesr_peer_copy_probe): a copy that needs a compute unit
+// (a blit kernel) cannot start before it ends, a copy engine does not care
+__global__ __launch_bounds__(1024) void peer_hog_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 
 __global__ __launch_bounds__(256) void peer_reduce_kernel(float* __restrict__ mine, const float* __restrict__ scratch, int world, int rank,
                                                           size_t n4, size_t slice4) {
@@ -123,6 +131,9 @@ PESR_API int pesr_peer_ctx_create(int world, void** ctx) {
     PeerCtx* c = new PeerCtx();
     c->n = world - 1;
     hipError_t e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+    // HIP events release at DEVICE scope by default; the stores in front of a flag that another GPU's copy engine waits for must be
+    // visible at SYSTEM scope (the default was relied on and had only ever run with both ranks behind one L2)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->release, hipEventDisableTiming | hipEventReleaseToSystem);
     for (int i = 0; i < c->n && e == hipSuccess; ++i) {
         e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
@@ -136,6 +147,7 @@ PESR_API int pesr_peer_ctx_destroy(void* ctx) {
     PeerCtx* c = (PeerCtx*)ctx;
     if (!c) return PESR_OK;
     (void)hipEventDestroy(c->fork);
+    (void)hipEventDestroy(c->release);
     for (int i = 0; i < c->n; ++i) { (void)hipStreamDestroy(c->side[i]); (void)hipEventDestroy(c->join[i]); }
     delete c;
     return PESR_OK;
@@ -186,6 +198,9 @@ PESR_API int pesr_peer_allreduce(const void* args, void* stream_) {
         return r;
     };
     // 1. reduce-scatter: my slice of every peer's buffer -> scratch, then the one kernel
+    //    (`stream` has waited for the compute stream's event: the system-scope release event makes the backward kernels' stores
+    //    to the flat gradient buffer visible to the peers' copy engines before READY is)
+    PEER_CK(hipEventRecord(c->release, stream));
     PEER_CK(tell(READY));
     PEER_CK(phase(READY, false));
     const size_t my_n = len(a.rank);
@@ -197,8 +212,8 @@ PESR_API int pesr_peer_allreduce(const void* args, void* stream_) {
         if (rc) return rc;
     }
     // 2. all-gather: every peer's reduced slice -> my buffer (a peer has read MY copy of its slice before it says REDUCED).
-    //    (event record = system-scope release of the kernel's stores in front of the flag the peers' copies wait for)
-    PEER_CK(hipEventRecord(c->fork, stream));
+    //    (system-scope release of the reduce kernel's stores in front of the flag the peers' copies wait for)
+    PEER_CK(hipEventRecord(c->release, stream));
     PEER_CK(tell(REDUCED));
     PEER_CK(phase(REDUCED, true));
     // 3. nobody reads my buffer any more once every peer says DONE: only then may the stream's next work write it
@@ -206,4 +221,44 @@ PESR_API int pesr_peer_allreduce(const void* args, void* stream_) {
     for (int d = 1; d < a.world; ++d) PEER_CK(await(DONE, (a.rank + d) % a.world));
 #undef PEER_CK
     return PESR_OK;
+}
+
+// Which engine moves a peer copy?  (round 6)  Times hipMemcpyAsync(dst <- src, bytes) on `copy_stream`
+// three ways, HIP events on that stream: alone; started right after a kernel that occupies every wave slot of this GPU for hog_us
+// microseconds was launched on a second stream; and the hog kernel itself.  A copy executed by a blit KERNEL cannot start before the hog ends
+// (out_ms[1] ~ hog + alone); one executed by a COPY ENGINE (SDMA) is not held up (out_ms[1] ~ out_ms[0]).
+// out_ms[3] = {copy alone, copy under the hog, hog}.  Synchronises; a measurement helper, not part of the step.
+PESR_API int pesr_peer_copy_probe(const void* src, void* dst, size_t bytes, int hog_us, float* out_ms) {
+    if (!src || !dst || !bytes || !out_ms || hog_us < 100 || hog_us > 50000) return PESR_EINVAL;
+    hipStream_t sc = nullptr, sh = nullptr;
+    hipEvent_t e[6] = {};
+    hipError_t r = hipStreamCreateWithFlags(&sc, hipStreamNonBlocking);
+    if (r == hipSuccess) r = hipStreamCreateWithFlags(&sh, hipStreamNonBlocking);
+    for (int i = 0; i < 6 && r == hipSuccess; ++i) r = hipEventCreate(&e[i]);
+    int dev = 0, cus = 256;
+    if (r == hipSuccess) r = hipGetDevice(&dev);
+    if (r == hipSuccess) r = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (r == hipSuccess) r = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, sc);           // warm-up (mappings, first-use setup)
+    if (r == hipSuccess) r = hipStreamSynchronize(sc);
+    if (r == hipSuccess) r = hipEventRecord(e[0], sc);
+    if (r == hipSuccess) r = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, sc);
+    if (r == hipSuccess) r = hipEventRecord(e[1], sc);
+    if (r == hipSuccess) r = hipStreamSynchronize(sc);
+    if (r == hipSuccess) {
+        r = hipEventRecord(e[4], sh);
+        hipLaunchKernelGGL(peer_hog_kernel, dim3(2 * cus), dim3(1024), 0, sh, (long long)hog_us * 100);      // 2 x 16 waves per CU = every slot
+        if (r == hipSuccess) r = hipGetLastError();
+        if (r == hipSuccess) r = hipEventRecord(e[5], sh);
+        if (r == hipSuccess) r = hipEventRecord(e[2], sc);
+        if (r == hipSuccess) r = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, sc);
+        if (r == hipSuccess) r = hipEventRecord(e[3], sc);
+    }
+    if (r == hipSuccess) r = hipStreamSynchronize(sc);
+    if (r == hipSuccess) r = hipStreamSynchronize(sh);
+    for (int k = 0; k < 3 && r == hipSuccess; ++k) r = hipEventElapsedTime(&out_ms[k], e[2 * k], e[2 * k + 1]);
+    for (int i = 0; i < 6; ++i) if (e[i]) (void)hipEventDestroy(e[i]);
+    if (sc) (void)hipStreamDestroy(sc);
+    if (sh) (void)hipStreamDestroy(sh);
+    if (r != hipSuccess) (void)hipGetLastError();
+    return (int)r;
 }

@@ -271,25 +271,44 @@ class Trainer:
                 assert not any(o.buckets._launched)
                 o.buckets.transport = tr
 
-    def calibrate_dp_policy(self, kind, next_batch, steps=3, graph=True, candidates=None, margin=0.015, peer_candidate=False):
+    @staticmethod
+    def calibration_batches(kind, steps=3, graph=True, candidates=None, peer_candidate=False):
+        """Worst-case number of batches calibrate_dp_policy draws from next_batch() (train.py's guard against running off the end
+        of an epoch inside the calibration): every eager candidate 1 + steps, the peer-memory candidate the same, the capture one
+        batch and its replays 1 + steps."""
+        n = len(candidates) if candidates else (3 if kind == "gan" else 2)
+        return (n + (1 if peer_candidate else 0)) * (steps + 1) + ((1 + steps + 1) if graph else 0)
+
+    def calibrate_dp_policy(self, kind, next_batch, steps=3, graph=True, candidates=None, margin=0.015, peer_candidate=False,
+                            will_capture=False):
         """Pick the data-parallel schedule by timing it (call it inside the warm-up, on every rank, after at least two eager
         steps).  Each eager candidate of DP_POLICIES runs one untimed step (the policy switch) and `steps` timed ones; then,
         if the transport is capturable, the step is captured as a hipGraph with the best eager bucket policy and its replays
         are timed the same way.  peer_candidate (more than one rank, each with its own GPU): the CU-free exchange over peer memory
         (comm.PeerCopy) is first rehearsed in child processes (comm.probe_direct kind "peer": a hang there costs killed children,
         not the job), then timed under the "overlap" schedule as `overlap@peer-copy`; it replaces the transport only if it wins.
+        will_capture: the caller is going to capture the step whatever comes out (train.py --hip_graph true): the peer-memory
+        candidate - not capturable - is then not timed at all.
         Every rank uses the SLOWEST rank's time per candidate (Transport.host_max), so all ranks
         choose alike.  The first candidate ("overlap") stays unless another one is faster by more than `margin` (1.5 %): the
         bucket schedule decides RCCL's reduction order, i.e. the last bits of a run, and that must not hang on a 0.1 % timing
-        race between equally good schedules (a graph replay keeps its eager policy's order: plain "faster" decides).  Returns {"chosen", "ms_per_step": {candidate: ms}, "graph_error",
-        "transport"}; afterwards `self.dp_step` is the step function to call (eager method or graph replay).
+        race between equally good schedules (a graph replay keeps its eager policy's order: plain "faster" decides).
+        ONE wall-clock budget (comm.bringup_budget(), env PESR_DP_BRINGUP_BUDGET, default 300 s from the first transport of the
+        process: probes, self-tests and this calibration together): before every candidate the ranks agree on the time spent (MAX
+        over ranks); once it exceeds the budget the remaining candidates are skipped, `overlap` on the transport that is up is
+        used, and `fallback_reason` says so.  Returns {"chosen", "ms_per_step": {candidate: ms}, "graph_error", "transport",
+        "fallback_reason", "bringup"}; afterwards `self.dp_step` is the step function to call (eager method or graph replay).
         These are real optimizer steps on real batches - nothing is thrown away."""
         import time
+
+        from . import comm
         eager = self.gan_step if kind == "gan" else self.pretrain_step
         trs = self._transports((self.optim_D, self.optim_G) if kind == "gan" else (self.optim_G,))
         assert len(trs) == 1, "calibrate_dp_policy: the optimizers must share one enabled transport"
         tr = trs[0]
         cands = list(candidates) if candidates else (["overlap", "defer_g", "defer_all"] if kind == "gan" else ["overlap", "defer_g"])
+        t_cal = time.monotonic()
+        fallback_reason = getattr(tr, "fallback_reason", None)
 
         def sync():
             if torch.cuda.is_available():              # (the world-size-2 gloo test of this selection logic runs on the CPU)
@@ -305,46 +324,76 @@ class Trainer:
             sync()
             return 1e3 * (time.perf_counter() - t0) / steps
 
-        mine = []
+        def budget_left():
+            """Agreed over the ranks: the budget minus the LARGEST time any rank has spent."""
+            (spent,) = tr.host_max([comm.bringup_spent()])
+            return comm.bringup_budget() - spent
+
+        mine, timed_cands = [], []
         for c in cands:
+            if timed_cands and budget_left() <= 0.0:
+                fallback_reason = ((fallback_reason + "; ") if fallback_reason else "") + \
+                    f"bring-up budget of {comm.bringup_budget():.0f} s spent after candidates {timed_cands}: the rest skipped, overlap kept"
+                break
             self.set_dp_policy(c)
             mine.append(timed(eager))
+            timed_cands.append(c)
+        budget_hit = len(timed_cands) < len(cands)
         agreed = tr.host_max(mine)
-        ms = dict(zip(cands, agreed))
-        faster = [c for c in cands[1:] if ms[c] < ms[cands[0]] * (1.0 - margin)]
-        best = min(faster, key=lambda c: (ms[c], cands.index(c))) if faster else cands[0]
+        ms = dict(zip(timed_cands, agreed))
+        if budget_hit:
+            best = cands[0]                            # (not a measured choice any more: the safe default)
+        else:
+            faster = [c for c in cands[1:] if ms[c] < ms[cands[0]] * (1.0 - margin)]
+            best = min(faster, key=lambda c: (ms[c], cands.index(c))) if faster else cands[0]
         self.set_dp_policy(best)
         self.dp_step, chosen, graph_error = eager, best, None
         peer_note = None
+        if will_capture and peer_candidate:
+            peer_candidate, peer_note = False, "off: the caller captures the step (--hip_graph true) and the peer-memory exchange is not capturable"
         if peer_candidate and tr.world > 1 and tr.name != "peer-copy":
-            from . import comm
             dev = (self.optim_G or self.optim_D).flat.flat_g.device
             group = (self.optim_G or self.optim_D).buckets.group
-            # (a candidate, not the default: its rehearsal may cost the run 90 s at most - env PESR_DP_PEER_PROBE_TIMEOUT)
-            ok_here, why = comm.probe_direct(dev, group, kind="peer", timeout=float(os.environ.get("PESR_DP_PEER_PROBE_TIMEOUT", "90")))
-            (bad,) = tr.host_max([0.0 if ok_here else 1.0])
-            if bad:
-                peer_note = "probe: " + (why or "another rank's probe failed")
+            left = budget_left()
+            if budget_hit or left < 60.0:
+                peer_note = f"skipped: {max(left, 0.0):.0f} s of the bring-up budget left"
             else:
-                ptr_ = None
-                try:
-                    ptr_ = comm.PeerCopy(dev, comm.dist.get_rank(group), tr.world, group)
-                except Exception as e:                   # (PeerCopy's constructor fails on every rank or on none)
-                    peer_note = f"{type(e).__name__}: {e}"
-                if ptr_ is not None:
-                    self.set_dp_transport(ptr_)
-                    self.set_dp_policy("overlap")
-                    (t_peer,) = tr.host_max([timed(eager)])
-                    ms["overlap@peer-copy"] = t_peer
-                    if t_peer < ms[best] * (1.0 - margin):
-                        chosen, tr = "overlap@peer-copy", ptr_
-                        comm.adopt_transport(ptr_)       # (closed with the others at shutdown)
-                        graph = False                    # (not capturable)
-                    else:
-                        self.set_dp_transport(tr)
-                        self.set_dp_policy(best)
-                        ptr_.close()
-        if graph and tr.capturable:
+                # (a candidate, not the default: its rehearsal may cost the run 90 s at most - env PESR_DP_PEER_PROBE_TIMEOUT - and
+                # never more than the bring-up budget leaves)
+                ok_here, why = comm.probe_direct(dev, group, kind="peer", timeout=min(float(os.environ.get("PESR_DP_PEER_PROBE_TIMEOUT", "90")), left - 30.0))
+                (bad,) = tr.host_max([0.0 if ok_here else 1.0])
+                if bad:
+                    peer_note = "probe: " + (why or "another rank's probe failed")
+                else:
+                    ptr_ = None
+                    t_p = time.monotonic()
+                    try:
+                        ptr_ = comm.PeerCopy(dev, comm.dist.get_rank(group), tr.world, group)
+                    except Exception as e:                   # (PeerCopy's constructor raises on every rank together: its failures are agreed)
+                        peer_note = f"{type(e).__name__}: {e}"
+                    comm.bringup_note("peer-copy transport + self-test", time.monotonic() - t_p, ptr_ is not None, peer_note or "")
+                    (bad,) = tr.host_max([0.0 if ptr_ is not None else 1.0])      # (belt and braces: one more agreement on the old transport)
+                    if bad and ptr_ is not None:
+                        ptr_.close(collective=False)
+                        ptr_, peer_note = None, "the peer-memory transport did not come up on another rank"
+                    if ptr_ is not None:
+                        self.set_dp_transport(ptr_)
+                        self.set_dp_policy("overlap")
+                        try:
+                            (t_peer,) = tr.host_max([timed(eager)])
+                        except comm.CommError as e:          # (a placement mismatch found at a bucket's first use: raised on every rank)
+                            t_peer, peer_note = None, f"CommError: {e}"
+                        if t_peer is not None:
+                            ms["overlap@peer-copy"] = t_peer
+                        if t_peer is not None and t_peer < ms[best] * (1.0 - margin):
+                            chosen, tr = "overlap@peer-copy", ptr_
+                            comm.adopt_transport(ptr_)       # (closed with the others at shutdown)
+                            graph = False                    # (not capturable)
+                        else:
+                            self.set_dp_transport(tr)
+                            self.set_dp_policy(best)
+                            ptr_.close()
+        if graph and tr.capturable and not budget_hit and budget_left() > 20.0:
             fn, err = None, None
             try:
                 lr, hr = next_batch()
@@ -365,8 +414,13 @@ class Trainer:
                     self.dp_step, chosen = fn, "graph+" + best
                 else:
                     self._graph.pop(kind, None)         # frees the graph's private memory pool
+        elif graph and tr.capturable:
+            graph_error = "not attempted: bring-up budget spent"
+        comm.bringup_note("calibrate_dp_policy", time.monotonic() - t_cal, True, chosen)
         return {"chosen": chosen, "ms_per_step": {k: round(v, 3) for k, v in ms.items()}, "graph_error": graph_error,
-                "transport": tr.name, "steps_per_candidate": steps, "margin": margin, "peer_candidate": peer_note or ("timed" if "overlap@peer-copy" in ms else "off")}
+                "transport": tr.name, "steps_per_candidate": steps, "margin": margin,
+                "peer_candidate": peer_note or ("timed" if "overlap@peer-copy" in ms else "off"),
+                "fallback_reason": fallback_reason, "bringup": comm.bringup_log()}
 
     def _replay(self, kind, lr, hr, gp_u=None):
         assert self._graph and kind in self._graph, f"capture_{kind}_step first"

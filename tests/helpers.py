@@ -85,7 +85,56 @@ def adam_close(got, ref, lr, steps, what=""):
         assert rest.mean() <= 0.06 * lr + 2e-6 * scale, f"{what}: mean err of the rest {rest.mean():.3e} = {rest.mean() / lr:.3f} lr"
 
 
-def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0, detail=None):
+# ---- parity margins as a record (round 6) ----------------------------------------------------------------------------------
+# Every gradient comparison against the float64 truth writes {tensor: [our error, the reference's own fp32 error, allowance]}
+# (all relative to the tensor's maximum) into ONE json file on the GPU box (gpurun_out/parity_margins.json, copied to
+# profiles/r06_parity_margins.json and committed).  With a committed record present the tests also hold the WORST error /
+# allowance ratio of each comparison to the recorded one + 20 % (floor 0.05): a kernel change can no longer eat a 3 x
+# allowance silently - it has to re-record, and the diff of the json shows what moved.
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MARGINS_OUT = os.environ.get("PESR_MARGINS_OUT") or os.path.join(_REPO, "gpurun_out", "parity_margins.json")
+MARGINS_REF = os.environ.get("PESR_MARGINS_REF") or os.path.join(_REPO, "profiles", "r06_parity_margins.json")
+
+
+def _load_json(path):
+    import json
+    try:
+        with open(path) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
+
+
+def record_margins(record_id, rows, extra=None):
+    """rows: {tensor: (our error, reference's fp32 error, allowance)}.  Merges into MARGINS_OUT and checks against MARGINS_REF.
+    -> (worst ratio, its tensor, median of our errors)"""
+    import json
+    errs = sorted(r[0] for r in rows.values())
+    median = errs[len(errs) // 2] if errs else 0.0
+    worst = max(((r[0] / r[2] if r[2] > 0 else 0.0, k) for k, r in rows.items()), default=(0.0, None))
+    rec = {"worst_ratio": round(worst[0], 4), "worst_tensor": worst[1], "median_error": float(f"{median:.3e}"), "tensors": len(rows),
+           "rows": {k: [float(f"{a:.3e}"), float(f"{b:.3e}"), float(f"{c:.3e}")] for k, (a, b, c) in sorted(rows.items())}}
+    if extra:
+        rec.update(extra)
+    try:
+        os.makedirs(os.path.dirname(MARGINS_OUT), exist_ok=True)
+        allrec = _load_json(MARGINS_OUT)
+        allrec[record_id] = rec
+        allrec["_columns"] = "rows: tensor -> [our max error vs fp64, the reference's own fp32 error vs fp64, allowance], each / the tensor's maximum"
+        with open(MARGINS_OUT, "w") as fh:
+            json.dump(allrec, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    assert worst[0] <= 1.0, f"{record_id}: {worst[1]} at {worst[0]:.2f} of its allowance"
+    ref = _load_json(MARGINS_REF).get(record_id)
+    if ref is not None:
+        lim = max(1.2 * float(ref["worst_ratio"]), 0.05)
+        assert worst[0] <= lim, (f"{record_id}: worst error / allowance {worst[0]:.3f} ({worst[1]}) exceeds the recorded "
+                                 f"{ref['worst_ratio']} ({ref['worst_tensor']}) + 20 %: re-record profiles/r06_parity_margins.json if intended")
+    return worst[0], worst[1], median
+
+
+def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0, detail=None, record=None, median_max=None):
     """Gradient parity where fp32 itself is ill-conditioned (ReLU / LeakyReLU kinks, BatchNorm batch statistics, L1's sign):
     `g` holds the REFERENCE's fp32 gradient samples, `g64` the same computation done in float64
     (tests/golden/make_golden_fp64.py).  Per tensor, our error against the fp64 truth may be at most `factor` x the
@@ -93,11 +142,14 @@ def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0, detail=None):
     tensor of the network (the errors are noise - a flipped ReLU mask is a discrete event - so a single tensor's own error is a
     one-sample estimate); the distance to the reference's fp32 values is then bounded by the sum of both errors.
     get_grad(name) -> our gradient tensor.  Returns (tensors checked, (worst error / allowance, its name)).
-    detail: a dict that receives {name: (our error, the reference's own fp32 error)}, both relative to the tensor's maximum."""
+    detail: a dict that receives {name: (our error, the reference's own fp32 error)}, both relative to the tensor's maximum.
+    record: an id under which the margins are written to / checked against the parity-margin record (record_margins);
+    median_max: bound on the MEDIAN of our per-tensor errors (the whole-step bar: 1e-5)."""
     keys = [k[len(prefix) + 5:] for k in g.files if k.startswith(prefix + "gidx.")]
     assert keys
     net_floor = float(g64[prefix + "floor_worst"])
     worst = (0.0, None)
+    rows = {}
     for key in keys:
         mx = float(g64[f"{prefix}gmax64.{key}"])
         if mx == 0.0:        # e.g. classifier.2.bias under RSGAN: pred_real - pred_fake cancels its gradient exactly
@@ -110,7 +162,12 @@ def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0, detail=None):
         tol = max(factor * e_ref, 2.0 * net_floor, 1e-6)
         if detail is not None:
             detail[key] = (float(e_ours), float(e_ref))
+        rows[prefix + key] = (float(e_ours), float(e_ref), float(tol))
         assert e_ours <= tol, f"grad {prefix}{key}: error vs fp64 {e_ours:.2e} > {tol:.2e} (reference's own fp32 error {e_ref:.2e})"
         if e_ours / tol > worst[0]:
             worst = (e_ours / tol, key)
+    if record is not None:
+        _, _, median = record_margins(record, rows)
+        if median_max is not None:
+            assert median <= median_max, f"{record}: median gradient error {median:.2e} of the maximum > {median_max:.0e}"
     return len(keys), worst

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/pesr_hip.h but not exported by libpesr_hip.so"
-    assert lib.pesr_abi_version() == 17
+    assert lib.pesr_abi_version() == 18
 
 
 def test_ctypes_signatures_cover_the_header():

@@ -220,7 +220,7 @@ def test_split_mode_gv2b_generator_full_batch16():
     g64 = load_golden("gv2b_fp64")
     params = dict(G.named_parameters())
     detail = {}
-    n, w = grads_vs_fp64(lambda k: params[k].grad, g, g64, detail=detail)
+    n, w = grads_vs_fp64(lambda k: params[k].grad, g, g64, detail=detail, record="gv2b[split-bf16]")
     SIGN_SUMS = {"add_mean.bias", "upsample.4.bias", "body.0.body.0.bias", "body.0.body.0.weight"}
     for k, (e_ours, e_ref) in sorted(detail.items(), key=lambda kv: kv[1][0]):
         print(f"  {k:28s} ours {e_ours:.2e}   reference fp32 {e_ref:.2e}")

@@ -280,7 +280,10 @@ def main(argv=None):
     if dp_on and args.dp_policy != "auto":
         trainer.set_dp_policy(args.dp_policy)
     CALIB_STEPS = 3
-    calib_need = (4 if gan else 3) * (CALIB_STEPS + 1) + 2          # iterations the calibration consumes at most
+    peer_cand = str2bool(args.dp_peer_candidate) and world > 1
+    # iterations the calibration consumes at most (its own worst-case count: eager candidates, the peer-memory candidate, the capture's
+    # batch and the replays - ADVICE r05: the peer candidate was not counted and the calibration could run off the end of an epoch)
+    calib_need = Trainer.calibration_batches("gan" if gan else "pretrain", CALIB_STEPS, graph=args.hip_graph == "auto", peer_candidate=peer_cand) + 2
 
     for epoch in range(1, args.num_epochs + 1):
         # The reference calls scheduler.step() at epoch START (train.py:156,185-186); under its pinned torch 0.4 the
@@ -312,8 +315,9 @@ def main(argv=None):
                 if dp_calibrate and iters >= 1 and n_iters - consumed[0] >= calib_need:
                     # every rank is at the same iteration of equally long loaders: the calibration's collectives line up.  Its
                     # steps are real training steps (their losses are not added to this epoch's averages).
-                    info = trainer.calibrate_dp_policy("gan" if gan else "pretrain", next_batch, steps=CALIB_STEPS, peer_candidate=str2bool(args.dp_peer_candidate),
-                                                       graph=args.hip_graph == "auto")
+                    info = trainer.calibrate_dp_policy("gan" if gan else "pretrain", next_batch, steps=CALIB_STEPS, peer_candidate=peer_cand,
+                                                       graph=args.hip_graph == "auto",
+                                                       will_capture=args.hip_graph != "auto" and str2bool(args.hip_graph))
                     dp_calibrate = False
                     if rank == 0:
                         print("data-parallel schedule:", info)
