@@ -309,6 +309,45 @@ int pesr_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 int pesr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* state, float beta1, float beta2, float eps,
                        float grad_scale, void* stream);
 
+/* ---- convs whose epilogue leaves the BatchNorm sums (round 6, ABI 18): SURVEY K10 for the Discriminator's BasicBlocks (reference
+ * model/basic.py:26-30: conv -> BatchNorm2d(train) -> LeakyReLU).  Replaces aten::native_batch_norm's statistics pass and
+ * aten::native_batch_norm_backward's reduction pass: the conv kernel that WRITES a tensor also leaves, per pixel tile, the per-channel sums the
+ * BatchNorm needs of it - no pass of its own over the tensor, no atomics (one row of [2][C] floats per pixel tile, added up in a fixed order
+ * by pesr_bn_finalize / pesr_bn_lrelu_bwd_fused).
+ *   mode PESR_BN_FWD_STATS      rows hold sum(y), sum(y^2) of the stored output y (a conv in front of a BatchNorm);
+ *   mode PESR_BN_BWD_MASK_SUMS  the kernel is the input gradient that produces the gradient g of a BatchNorm + LeakyReLU OUTPUT; it stores
+ *                               g' = g * lrelu'(gamma * xhat(z) + beta) instead of g and the rows hold sum(g'), sum(g' * xhat).
+ * pesr_conv3x3_bn_rows(which, ...): rows the call will write - 0 when the fused form does not cover the shape (split-K layers, odd channel
+ * counts): the caller then uses the un-fused calls.  which: 0 = pesr_conv3x3_fwd_bn, 1 = pesr_conv3x3_dgrad_bn, 2 = pesr_conv3x3_wino4_bn
+ * (arguments as that call takes them).  Workspace sizes: as for the un-fused calls. */
+#define PESR_BN_FWD_STATS 1
+#define PESR_BN_BWD_MASK_SUMS 2
+typedef struct PesrBnFuse {
+    int mode;
+    int rows;                     /* capacity of `part` in rows of 2 * C floats */
+    float* part;                  /* [rows][2][C], written by the conv kernel */
+    const float* z;               /* PESR_BN_BWD_MASK_SUMS: the BatchNorm's input, shape of the conv's output */
+    const float* mean_invstd;     /* PESR_BN_BWD_MASK_SUMS: [2][C] saved by the forward */
+    const float* gamma;
+    const float* beta;
+    float slope;                  /* negative slope of the activation behind the BatchNorm */
+} PesrBnFuse;
+long pesr_conv3x3_bn_rows(int which, int N, int H, int W, int Cin, int Cout, int stride);
+int pesr_conv3x3_fwd_bn(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int stride,
+                        void* workspace, size_t ws_bytes, const PesrBnFuse* fuse, void* stream);
+int pesr_conv3x3_dgrad_bn(const float* dy, const float* w_packed_dgrad, float* dx, int N, int H, int W, int Cin, int Cout, int stride,
+                          void* workspace, size_t ws_bytes, const PesrBnFuse* fuse, void* stream);
+int pesr_conv3x3_wino4_bn(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
+                          void* workspace, size_t ws_bytes, const PesrBnFuse* fuse, void* stream);
+/* rows of sums -> mean / invstd [2][C] (+ running statistics, num_batches_tracked as nn.BatchNorm2d updates them); M = N * H * W */
+int pesr_bn_finalize(const float* part, int rows, int C, long M, float eps, float momentum, float* mean_invstd, float* running_mean,
+                     float* running_var, long long* num_batches, void* stream);
+/* rows of (sum g', sum g' xhat) + the masked gradient g' -> dz = gamma invstd (g' - mean g' - xhat mean(g' xhat)), dgamma, dbeta (NULL: not
+ * wanted; accumulate: added to).  workspace: 2 * C floats. */
+int pesr_bn_lrelu_bwd_fused(const float* z, const float* g_masked, const float* part, int rows, const float* gamma, const float* beta,
+                            const float* mean_invstd, float* dz, float* dgamma, float* dbeta, int N, int H, int W, int C, int accumulate,
+                            void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- gradient exchange over peer memory (round 5, ABI 15): the replacement of nn.DataParallel's reduce_add (reference
  * train.py:114-118) as a reduce-scatter + all-gather that keeps no workgroup resident - stream wait / write-value operations and
  * peer copies on one stream, ONE small kernel over 1/N of the bytes (pesr_amd/csrc/peer_exchange.hip).

@@ -88,6 +88,12 @@ SIGNATURES.update({
     "pesr_psnr_y": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "pesr_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "pesr_adam_step_dev": (c_int, [_P, _P, _P, _P, c_long, _P, c_float, c_float, c_float, c_float, _P]),
+    "pesr_conv3x3_bn_rows": (c_long, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pesr_conv3x3_fwd_bn": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "pesr_conv3x3_dgrad_bn": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "pesr_conv3x3_wino4_bn": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "pesr_bn_finalize": (c_int, [_P, c_int, c_int, c_long, c_float, c_float, _P, _P, _P, _P, _P]),
+    "pesr_bn_lrelu_bwd_fused": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "pesr_peer_alloc": (c_int, [c_size_t, _P, _P]),
     "pesr_peer_free": (c_int, [_P]),
     "pesr_peer_release": (c_int, [_P, c_size_t]),

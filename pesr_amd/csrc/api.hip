@@ -44,6 +44,71 @@ PESR_API size_t pesr_conv3x3_workspace_bytes(int N, int OH, int OW, int Cout) {
     return tiles < 640 ? (size_t)8 * N * OH * OW * Cout * sizeof(float) : 0;
 }
 
+// ---- convs whose epilogue leaves BatchNorm sums (round 6, ABI 18; common.h BnEpi) ------------------------------------------------
+static PesrBnFuseArgs fuse_args(const PesrBnFuse* f, int dry) {
+    PesrBnFuseArgs a{};
+    a.dry = dry;
+    if (f) { a.mode = f->mode; a.rows = f->rows; a.part = f->part; a.z = f->z; a.mean_invstd = f->mean_invstd; a.gamma = f->gamma; a.beta = f->beta; a.slope = f->slope; }
+    return a;
+}
+PESR_API long pesr_conv3x3_bn_rows(int which, int N, int H, int W, int Cin, int Cout, int stride) {
+    PesrBnFuseArgs a = fuse_args(nullptr, 1);
+    int rc = PESR_EINVAL;
+    // the planners decide split-K from the workspace the caller would pass: the same sizes as ops.py / pesr_conv3x3_workspace_bytes
+    if (which == 0) {
+        const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+        const size_t wsb = pesr_conv3x3_workspace_bytes(N, OH, OW, Cout);
+        rc = pesr_conv3x3_launch(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, pad16(Cin), pad64(Cout), stride, 1.f, PESR_ACT_NONE, 0.f,
+                                 0, 0, 0, Cin, Cout, wsb ? (void*)8 : nullptr, wsb, nullptr, &a);
+    } else if (which == 1) {
+        if (stride == 1) {
+            const size_t wsb = pesr_conv3x3_workspace_bytes(N, H, W, Cin);
+            rc = pesr_conv3x3_launch(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, pad16(Cout), pad64(Cin), 1, 1.f, PESR_ACT_NONE, 0.f, 0, 0,
+                                     1, Cout, Cin, wsb ? (void*)8 : nullptr, wsb, nullptr, &a);
+        } else if (stride == 2) {
+            rc = pesr_conv3x3_s2_dgrad_launch(nullptr, nullptr, nullptr, nullptr, N, H, W, Cout, Cin, 1.f, nullptr, &a);
+        }
+    } else if (which == 2) {
+        rc = pesr_conv3x3_wino4_launch(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, 1.f, PESR_ACT_NONE, 0.f, 0, 0, nullptr, 0,
+                                       nullptr, &a);
+    }
+    return rc ? 0 : a.rows_out;
+}
+PESR_API int pesr_conv3x3_fwd_bn(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
+                                 int stride, void* workspace, size_t ws_bytes, const PesrBnFuse* fuse, void* stream) {
+    if (!fuse) return PESR_EINVAL;
+    PesrBnFuseArgs a = fuse_args(fuse, 0);
+    return pesr_conv3x3_launch(x, w_packed, bias, nullptr, nullptr, y, N, H, W, pad16(Cin), pad64(Cout), stride, 1.f, PESR_ACT_NONE, 0.f, 0, 0, 0, Cin,
+                               Cout, workspace, ws_bytes, (hipStream_t)stream, &a);
+}
+PESR_API int pesr_conv3x3_dgrad_bn(const float* dy, const float* w_packed_dgrad, float* dx, int N, int H, int W, int Cin, int Cout, int stride,
+                                   void* workspace, size_t ws_bytes, const PesrBnFuse* fuse, void* stream) {
+    if (!fuse) return PESR_EINVAL;
+    PesrBnFuseArgs a = fuse_args(fuse, 0);
+    if (stride == 1)
+        return pesr_conv3x3_launch(dy, w_packed_dgrad, nullptr, nullptr, nullptr, dx, N, H, W, pad16(Cout), pad64(Cin), 1, 1.f, PESR_ACT_NONE, 0.f, 0, 0,
+                                   1, Cout, Cin, workspace, ws_bytes, (hipStream_t)stream, &a);
+    if (stride == 2) return pesr_conv3x3_s2_dgrad_launch(dy, w_packed_dgrad, nullptr, dx, N, H, W, Cout, Cin, 1.f, (hipStream_t)stream, &a);
+    return PESR_EINVAL;
+}
+PESR_API int pesr_conv3x3_wino4_bn(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
+                                   void* workspace, size_t ws_bytes, const PesrBnFuse* fuse, void* stream) {
+    if (!fuse) return PESR_EINVAL;
+    PesrBnFuseArgs a = fuse_args(fuse, 0);
+    return pesr_conv3x3_wino4_launch(x, w_packed, bias, nullptr, nullptr, y, N, H, W, Cin, Cout, 1.f, PESR_ACT_NONE, 0.f, 0, 0, workspace, ws_bytes,
+                                     (hipStream_t)stream, &a);
+}
+PESR_API int pesr_bn_finalize(const float* part, int rows, int C, long M, float eps, float momentum, float* mean_invstd, float* running_mean,
+                              float* running_var, long long* num_batches, void* stream) {
+    return pesr_bn_finalize_launch(part, rows, C, M, eps, momentum, mean_invstd, running_mean, running_var, num_batches, (hipStream_t)stream);
+}
+PESR_API int pesr_bn_lrelu_bwd_fused(const float* z, const float* g_masked, const float* part, int rows, const float* gamma, const float* beta,
+                                     const float* mean_invstd, float* dz, float* dgamma, float* dbeta, int N, int H, int W, int C, int accumulate,
+                                     void* workspace, size_t ws_bytes, void* stream) {
+    return pesr_bn_lrelu_bwd_fused_launch(z, g_masked, part, rows, gamma, beta, mean_invstd, dz, dgamma, dbeta, (long)N * H * W, C, (long)H * W,
+                                          accumulate, workspace, ws_bytes, (hipStream_t)stream);
+}
+
 PESR_API size_t pesr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo) {
     return pesr_conv3x3_wgrad_ws_bytes(N, H, W, Cin, Cout, stride, algo);
 }

@@ -69,18 +69,51 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
 }
 
-// second stage of the statistics (fixed-order row reduce of the per-block partials, reduce_rows.h) and the finalize step in
-// ONE launch: block = 64 channels; the small layers' BatchNorm is launch-bound, every launch saved is ~4.5 us
+// The same fixed-order two-column row reduce for MANY rows (round 6: one row per pixel tile of a conv kernel whose epilogue leaves the
+// sums - up to a few thousand): 1024 threads = CL channel lanes x 1024 / CL row lanes; a thread adds rows rl, rl + RL, ... in increasing
+// order (four loads in flight), the row lanes are combined through LDS in lane order.  CL = 64 is reduce_rows_block2's shape (and
+// arithmetic); CL = 16 gives a layer of 64 channels four blocks of 64 row lanes instead of one block of 16.
+template <int CL>
+__device__ __forceinline__ void bn_rows2(const float* __restrict__ part, int nb, int ncols, int col0, int col1, bool valid, double* red,
+                                         double* out0, double* out1) {
+    constexpr int RL = 1024 / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    double s = 0.0, u = 0.0;
+    if (valid) {
+        int k = rl;
+        for (; k + 3 * RL < nb; k += 4 * RL) {
+            const float* p0 = part + (size_t)k * ncols;
+            const float a = p0[col0], b = p0[(size_t)RL * ncols + col0], c = p0[(size_t)2 * RL * ncols + col0], d = p0[(size_t)3 * RL * ncols + col0];
+            const float e = p0[col1], f = p0[(size_t)RL * ncols + col1], g = p0[(size_t)2 * RL * ncols + col1], h = p0[(size_t)3 * RL * ncols + col1];
+            s += (double)a; s += (double)b; s += (double)c; s += (double)d;
+            u += (double)e; u += (double)f; u += (double)g; u += (double)h;
+        }
+        for (; k < nb; k += RL) { s += (double)part[(size_t)k * ncols + col0]; u += (double)part[(size_t)k * ncols + col1]; }
+    }
+    __syncthreads();
+    red[rl * CL + cl] = s; red[1024 + rl * CL + cl] = u;
+    __syncthreads();
+    double t0 = 0.0, t1 = 0.0;
+    if (rl == 0) {
+        t0 = red[cl]; t1 = red[1024 + cl];
+        for (int j = 1; j < RL; ++j) { t0 += red[j * CL + cl]; t1 += red[1024 + j * CL + cl]; }
+    }
+    *out0 = t0; *out1 = t1;
+}
+
+// second stage of the statistics (fixed-order row reduce of the per-block partials) and the finalize step in
+// ONE launch: block = CL channels; the small layers' BatchNorm is launch-bound, every launch saved is ~4.5 us
+template <int CL>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nb, int C, long M, float eps,
                                                            float momentum, float* __restrict__ mean_invstd,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            long long* __restrict__ num_batches) {
-    __shared__ double red[2][16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double red[2048];
+    const int c = blockIdx.x * CL + (threadIdx.x % CL);
     double s, ss;
-    reduce_rows_block2(part, nb, 2 * C, c, C + c, c < C, red[0], red[1], &s, &ss);
+    bn_rows2<CL>(part, nb, 2 * C, c, C + c, c < C, red, &s, &ss);
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
-    if (c >= C || (threadIdx.x >> 6) != 0) return;
+    if (c >= C || threadIdx.x / CL != 0) return;
     const double mean = s / (double)M;
     double var = ss / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -94,13 +127,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 }
 
 // second stage for backward, same fusion: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat (+ dbeta, dgamma)
+template <int CL>
 __global__ __launch_bounds__(1024) void bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums,
                                                            float* __restrict__ dbeta, float* __restrict__ dgamma, int accumulate) {
-    __shared__ double red[2][16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double red[2048];
+    const int c = blockIdx.x * CL + (threadIdx.x % CL);
     double s0, s1;
-    reduce_rows_block2(part, nb, 2 * C, c, C + c, c < C, red[0], red[1], &s0, &s1);
-    if (c >= C || (threadIdx.x >> 6) != 0) return;
+    bn_rows2<CL>(part, nb, 2 * C, c, C + c, c < C, red, &s0, &s1);
+    if (c >= C || threadIdx.x / CL != 0) return;
     const float a = (float)s0, b = (float)s1;
     sums[c] = a; sums[C + c] = b;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;        // dbeta = sum dz, dgamma = sum dz*xhat
@@ -129,9 +163,11 @@ __global__ void bn_apply_kernel(const f32x4* __restrict__ x, const float* __rest
     }
 }
 
+// premasked: dy already is dz = dy * lrelu'(z) (written by the conv kernel that produced it, common.h BnEpi mode 2)
 __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean_invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums,
-                                    f32x4* __restrict__ dx, long M, int C, float slope, long HW, long dy_sn, long dy_sc, long dy_sp) {
+                                    f32x4* __restrict__ dx, long M, int C, float slope, long HW, long dy_sn, long dy_sc, long dy_sp,
+                                    int premasked) {
     const int C4 = C >> 2;
     const long total = M * C4;
     const float invM = 1.0f / (float)M;
@@ -150,14 +186,33 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const float* __
         }
         const f32x4 xh = (x[e] - mu) * is;
         const f32x4 z = ga * xh + be;
-        f32x4 dz;
-        dz.x = z.x > 0.f ? g.x : g.x * slope; dz.y = z.y > 0.f ? g.y : g.y * slope;
-        dz.z = z.z > 0.f ? g.z : g.z * slope; dz.w = z.w > 0.f ? g.w : g.w * slope;
+        f32x4 dz = g;
+        if (!premasked) {
+            dz.x = z.x > 0.f ? g.x : g.x * slope; dz.y = z.y > 0.f ? g.y : g.y * slope;
+            dz.z = z.z > 0.f ? g.z : g.z * slope; dz.w = z.w > 0.f ? g.w : g.w * slope;
+        }
         dx[e] = ga * is * (dz - sdz - xh * sdzx);
     }
 }
 
 namespace {
+// many rows (a conv epilogue's pixel tiles, the 3 -> C kernel's 2048 workgroups): 16-channel blocks of 64 row lanes; few rows (bn_reduce's
+// <= 512 blocks): the 64-channel blocks of 16 row lanes these kernels always had (same order of additions as before round 6)
+static void bn_finalize_launch(const float* part, int rows, int C, long M, float eps, float momentum, float* mean_invstd, float* running_mean,
+                               float* running_var, long long* num_batches, hipStream_t stream) {
+    if (rows > 512)
+        hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, stream, part, rows, C, M, eps, momentum, mean_invstd,
+                           running_mean, running_var, num_batches);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3((C + 63) / 64), dim3(1024), 0, stream, part, rows, C, M, eps, momentum, mean_invstd,
+                           running_mean, running_var, num_batches);
+}
+static void bn_bwd_sums_launch(const float* part, int rows, int C, float* sums, float* dbeta, float* dgamma, int accumulate, hipStream_t stream) {
+    if (rows > 512)
+        hipLaunchKernelGGL(bn_bwd_sums_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, stream, part, rows, C, sums, dbeta, dgamma, accumulate);
+    else
+        hipLaunchKernelGGL(bn_bwd_sums_kernel<64>, dim3((C + 63) / 64), dim3(1024), 0, stream, part, rows, C, sums, dbeta, dgamma, accumulate);
+}
 static void bn_grid(long M, long* nb, long* rpb) {
     long b = (M + 63) / 64; if (b > 512) b = 512; if (b < 1) b = 1;
     *rpb = (M + b - 1) / b;
@@ -182,8 +237,7 @@ int pesr_bn_lrelu_fwd_launch(const float* x, const float* gamma, const float* be
     float* part = (float*)((char*)ws + dsum_bytes);
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, part, M, C, rpb, slope, 0L, 1L, 0L, HW);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, M, eps, momentum,
-                       mean_invstd, running_mean, running_var, num_batches);
+    bn_finalize_launch(part, (int)nb, C, M, eps, momentum, mean_invstd, running_mean, running_var, num_batches, stream);
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     long ysn = HW * C, ysc = 1, ysp = C;
@@ -213,8 +267,7 @@ int pesr_conv_rgb_bn_lrelu_fwd_launch(const float* x, const float* w, float* z, 
     int rc = pesr_conv_rgb_in_stats_launch(x, w, z, part, N, H, W, C, stream);
     if (rc) return rc;
     const long M = (long)N * H * W, HW = (long)H * W;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, rows, C, M, eps, momentum,
-                       mean_invstd, running_mean, running_var, num_batches);
+    bn_finalize_launch(part, rows, C, M, eps, momentum, mean_invstd, running_mean, running_var, num_batches, stream);
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     long ysn = HW * C, ysc = 1, ysp = C;
@@ -240,12 +293,36 @@ int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma
     if (dy_nchw) { sn = HW * C; sc = HW; sp = 1; }
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb, slope,
                        sn, sc, sp, HW);
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, sums, dbeta, dgamma,
-                       accumulate);
+    bn_bwd_sums_launch(part, (int)nb, C, sums, dbeta, dgamma, accumulate, stream);
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, dy, mean_invstd, gamma, beta, (const float*)sums,
-                       (f32x4*)dx, M, C, slope, HW, sn, sc, sp);
+                       (f32x4*)dx, M, C, slope, HW, sn, sc, sp, 0);
+    return pesr_launch_status();
+}
+
+// ---- round 6: the two halves of the BatchNorm whose sums come out of a conv kernel's epilogue (common.h BnEpi) -----------------------
+// forward: part[rows][2][C] (sum, sum of squares per pixel tile) -> mean / invstd / running statistics; the apply pass is
+// pesr_bn_lrelu_apply_launch.  backward: part[rows][2][C] (sum g', sum g' * xhat; g' = the already masked gradient the conv kernel
+// stored) -> dgamma / dbeta and dz = gamma * invstd * (g' - mean(g') - xhat * mean(g' * xhat)).
+int pesr_bn_finalize_launch(const float* part, int rows, int C, long M, float eps, float momentum, float* mean_invstd, float* running_mean,
+                            float* running_var, long long* num_batches, hipStream_t stream) {
+    if (C % 4 || rows < 1 || !part) return PESR_EINVAL;
+    bn_finalize_launch(part, rows, C, M, eps, momentum, mean_invstd, running_mean, running_var, num_batches, stream);
+    return pesr_launch_status();
+}
+
+int pesr_bn_lrelu_bwd_fused_launch(const float* z, const float* gmasked, const float* part, int rows, const float* gamma, const float* beta,
+                                   const float* mean_invstd, float* dz, float* dgamma, float* dbeta, long M, int C, long HW, int accumulate,
+                                   void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (C % 4 || rows < 1 || !part) return PESR_EINVAL;
+    if (!ws || ws_bytes < 2 * (size_t)C * sizeof(float)) return PESR_EWORKSPACE;
+    float* sums = (float*)ws;
+    bn_bwd_sums_launch(part, rows, C, sums, dbeta, dgamma, accumulate, stream);
+    const long total = M * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)z, gmasked, mean_invstd, gamma, beta, (const float*)sums,
+                       (f32x4*)dz, M, C, 0.f, HW, HW * C, 1L, (long)C, 1);
     return pesr_launch_status();
 }
 
@@ -281,14 +358,14 @@ int pesr_bn_lrelu_bwd_eval_launch(const float* x, const float* dy, const float* 
     if (dgamma || dbeta) {
         hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb,
                            slope, sn, sc, sp, HW);
-        hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)part, (int)nb, C, sums, dbeta, dgamma, 0);
+        bn_bwd_sums_launch(part, (int)nb, C, sums, dbeta, dgamma, 0, stream);
     }
     hipError_t e = hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
     const long total = M * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)x, dy, mean_invstd, gamma, beta, (const float*)sums,
-                       (f32x4*)dx, M, C, slope, HW, sn, sc, sp);
+                       (f32x4*)dx, M, C, slope, HW, sn, sc, sp, 0);
     return pesr_launch_status();
 }
 

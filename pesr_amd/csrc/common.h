@@ -61,3 +61,29 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// ---- BatchNorm sums out of a conv kernel's epilogue (round 6; SURVEY K10, reference model/basic.py:26-30) ------------------------
+// mode 1 (a conv in front of a BatchNorm): the workgroup leaves the per-channel sum and sum of squares of what it stored in
+//   part[row0 + pixel tile][2][C] - bn_reduce_kernel<0>'s row layout, so bn_finalize_kernel takes the rows as they are.
+// mode 2 (the input gradient that PRODUCES the gradient of a BatchNorm + LeakyReLU output y = lrelu(gamma * xhat(z) + beta)):
+//   the stored value is g' = v * lrelu'(gamma * xhat + beta) and the rows hold sum g' and sum g' * xhat (bn_reduce_kernel<1>'s
+//   sums): the BatchNorm backward then only needs its apply pass.
+// No atomics: one row per pixel tile, the n-tiles' channels side by side; a thread adds its few dozen pixels in fp32, everything
+// across threads in double, in a fixed order.
+// The struct is the LAST by-value parameter of the conv kernels and is read through a laundered kernarg pointer AFTER the main
+// loop (pesr_bn_epi): left to itself hipcc loads every kernel argument in the prologue and keeps it in SGPRs through the loop,
+// and the 9 extra registers pushed three direct-conv configurations over the SGPR budget (spills to scratch).
+struct BnEpi {
+    int mode;
+    float slope;
+    float* part;
+    const float* z;           // mode 2: the BatchNorm's input, same shape as the kernel's output
+    const float* mi;          // mode 2: mean_invstd [2][C]
+    const float* gamma;
+    const float* beta;
+};
+__device__ __forceinline__ const BnEpi* pesr_bn_epi(unsigned kernarg_offset) {
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));      // opaque from here on: nothing read through it can be hoisted above this point
+    return (const BnEpi*)(ka + kernarg_offset);
+}

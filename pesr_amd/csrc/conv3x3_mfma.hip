@@ -61,6 +61,12 @@ struct ConvArgs {
     size_t slab_bytes;
     int ps_in;                  // 1: x is a pixel-shuffled tensor [N][2H][2W][Cin/4] read as its
                                 //    un-shuffled, sub-pixel-major [N][H][W][Cin] view (dgrad of a PS conv)
+    // ---- BatchNorm sums from the epilogue (round 6; common.h BnEpi - the kernel's LAST parameter): the first row of this problem ----
+    int bn_row0;
+    // host only (planning):
+    int bn_mode, bn_cap;
+    int dry;                    // host only: plan, report bn_rows, do not launch
+    long bn_rows;               // host only: rows this problem writes (0: the fused form does not cover it - split-K, odd channel counts)
 };
 
 __device__ __forceinline__ unsigned tap_code(const ConvArgs& a, int t) {
@@ -70,7 +76,7 @@ __device__ __forceinline__ unsigned tap_code(const ConvArgs& a, int t) {
 // The kernel body as a device function of (args, logical block id, blocks in this problem's grid): conv3x3_mfma_kernel is the
 // one-problem launch; conv3x3_s2dgrad4_kernel runs the four parity classes of a stride-2 input gradient in ONE launch.
 template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL, int MODE>
-__device__ __forceinline__ void conv3x3_mfma_body(const ConvArgs& a, const int block_id, const int grid_blocks) {
+__device__ __forceinline__ void conv3x3_mfma_body(const ConvArgs& a, const int block_id, const int grid_blocks, const unsigned bn_kernarg_off) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BN = WAVES_N * WN * 16;
     constexpr int WL = (BN * 4 + NT - 1) / NT;  // float4 units per thread per weight slab
@@ -353,6 +359,21 @@ __device__ __forceinline__ void conv3x3_mfma_body(const ConvArgs& a, const int b
             }
         __syncthreads();
         const size_t slab_off = (size_t)ks * ((size_t)a.N * a.OH * a.OW * a.cout_store);
+        // BatchNorm sums (NT % C4 == 0: a thread keeps its four channels over all its pixels)
+        const BnEpi* const bn = pesr_bn_epi(bn_kernarg_off);
+        const int bn_mode = a.ksplit == 1 ? bn->mode : 0;
+        const bool bn_on = bn_mode != 0;
+        const float* const bn_z = bn->z;
+        const float bn_slope = bn->slope;
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bmu = st1, bis = st1, bga = st1, bbe = st1;
+        if (bn_mode == 2) {
+            const int cq = n0 + (tid % C4) * 4;
+            if (cq < a.cout_store) {
+                bmu = *(const f32x4*)(bn->mi + cq); bis = *(const f32x4*)(bn->mi + a.cout_store + cq);
+                bga = *(const f32x4*)(bn->gamma + cq); bbe = *(const f32x4*)(bn->beta + cq);
+            }
+        }
         for (int u = tid; u < MT * C4; u += NT) {
             const int m = u / C4, c4 = u - m * C4;
             const int co = n0 + c4 * 4;
@@ -386,7 +407,35 @@ __device__ __forceinline__ void conv3x3_mfma_body(const ConvArgs& a, const int b
                 v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
                 v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
             }
+            if (bn_on) {
+                if (bn_mode == 2) {
+                    const f32x4 xh = (*(const f32x4*)(bn_z + idx) - bmu) * bis;
+                    const f32x4 zz = bga * xh + bbe;
+                    v.x = zz.x > 0.f ? v.x : v.x * bn_slope; v.y = zz.y > 0.f ? v.y : v.y * bn_slope;
+                    v.z = zz.z > 0.f ? v.z : v.z * bn_slope; v.w = zz.w > 0.f ? v.w : v.w * bn_slope;
+                    st1 += v; st2 += v * xh;
+                } else {
+                    st1 += v; st2 += v * v;
+                }
+            }
             *(f32x4*)(a.y + idx) = v;
+        }
+        if (bn_on) {
+            __syncthreads();                                 // every thread is done with the accumulator tile in `ob`
+            f32x4* const red = (f32x4*)smem;                 // [2][NT]
+            red[tid] = st1; red[NT + tid] = st2;
+            __syncthreads();
+            if (tid < C4 && n0 + tid * 4 < a.cout_store) {
+                f64x4 d1 = {0.0, 0.0, 0.0, 0.0}, d2 = {0.0, 0.0, 0.0, 0.0};
+                for (int k = 0; k < NT / C4; ++k) {
+                    d1 += __builtin_convertvector(red[k * C4 + tid], f64x4);
+                    d2 += __builtin_convertvector(red[NT + k * C4 + tid], f64x4);
+                }
+                const int row = a.bn_row0 + (img * a.tiles_y + ty) * a.tiles_x + tx;
+                float* const pr = bn->part + (size_t)row * 2 * a.cout_store + n0 + tid * 4;
+                *(f32x4*)pr = __builtin_convertvector(d1, f32x4);
+                *(f32x4*)(pr + a.cout_store) = __builtin_convertvector(d2, f32x4);
+            }
         }
         return;
     }
@@ -438,8 +487,9 @@ __device__ __forceinline__ void conv3x3_mfma_body(const ConvArgs& a, const int b
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int HL, int MODE>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(const ConvArgs a) {
-    conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, S, HL, MODE>(a, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_mfma_kernel(const ConvArgs a, const BnEpi bn) {
+    (void)bn;       // read through pesr_bn_epi() in the epilogue
+    conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, S, HL, MODE>(a, blockIdx.x, gridDim.x, (unsigned)((sizeof(ConvArgs) + 7) & ~(size_t)7));
 }
 
 // Input gradient of a stride-2 conv: its four output parity classes (1 / 2 / 2 / 4 taps, conv3x3_mfma.hip's host side) as ONE
@@ -452,13 +502,15 @@ struct ConvArgs4 {
     int tiles[4];
 };
 template <int WAVES_M, int WAVES_N, int WM, int WN, int HL>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_s2dgrad4_kernel(const ConvArgs4 a4) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_s2dgrad4_kernel(const ConvArgs4 a4, const BnEpi bn) {
+    (void)bn;
+    constexpr unsigned BO = (unsigned)((sizeof(ConvArgs4) + 7) & ~(size_t)7);
     const int bx = blockIdx.x;
     switch (blockIdx.y) {
-        case 0: if (bx < a4.tiles[0]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 2>(a4.c[0], bx, a4.tiles[0]); break;
-        case 1: if (bx < a4.tiles[1]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 1>(a4.c[1], bx, a4.tiles[1]); break;
-        case 2: if (bx < a4.tiles[2]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 1>(a4.c[2], bx, a4.tiles[2]); break;
-        default: if (bx < a4.tiles[3]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 0>(a4.c[3], bx, a4.tiles[3]); break;
+        case 0: if (bx < a4.tiles[0]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 2>(a4.c[0], bx, a4.tiles[0], BO); break;
+        case 1: if (bx < a4.tiles[1]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 1>(a4.c[1], bx, a4.tiles[1], BO); break;
+        case 2: if (bx < a4.tiles[2]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 1>(a4.c[2], bx, a4.tiles[2], BO); break;
+        default: if (bx < a4.tiles[3]) conv3x3_mfma_body<WAVES_M, WAVES_N, WM, WN, 1, HL, 0>(a4.c[3], bx, a4.tiles[3], BO); break;
     }
 }
 
@@ -527,6 +579,10 @@ int pesr_conv_splitk_finish_launch(const float* slab, const float* bias, const f
 // host side
 // ---------------------------------------------------------------------------------------------
 namespace {
+
+// the BnEpi of the call in progress on this thread (set by set_bn at the top of the two entry points, read by the launchers below:
+// it rides beside ConvArgs through the dispatch templates without widening every signature)
+static thread_local BnEpi g_bn_epi;
 
 static void set_tap(ConvArgs& a, int t, int dy, int dx, int w) {
     const unsigned long long code = (unsigned)(dy | (dx << 2) | (w << 4));
@@ -600,8 +656,13 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int t
     size_t lds; int mode; long grid;
     const int rc = prep_cfg<WAVES_M, WAVES_N, WM, WN, S, HL>(a, hext, wext, target_wgs, &lds, &mode, &grid);
     if (rc) return rc;
+    // rows of BatchNorm partial sums the epilogue can leave: one per pixel tile (not with split-K: the finish kernel sums slabs)
+    a.bn_rows = (a.ksplit == 1 && a.cout_store % 4 == 0 && NT % (WAVES_N * WN * 4) == 0 && !a.ps) ? (long)a.N * a.tiles_y * a.tiles_x : 0;
+    if (a.dry) return PESR_OK;
+    if (a.bn_mode && (a.bn_rows == 0 || a.bn_row0 + a.bn_rows > a.bn_cap || !g_bn_epi.part)) return PESR_EINVAL;
     const size_t out_bytes = (size_t)a.N * a.OH * a.OW * a.cout_store * sizeof(float);
     const float* bias = a.bias; const float* skip = a.skip; const float* mask = a.mask;
+    const BnEpi a_bn = g_bn_epi;
 #define PESR_LAUNCH_MODE(M_)                                                                              \
     {                                                                                                      \
         auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, M_>;                              \
@@ -609,7 +670,7 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int t
         attr_once([&] {                                                           \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         });                                                                                                  \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);                          \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a, a_bn);                    \
     }
     if (mode == 2) PESR_LAUNCH_MODE(2) else if (mode == 1) PESR_LAUNCH_MODE(1) else PESR_LAUNCH_MODE(0)
 #undef PESR_LAUNCH_MODE
@@ -624,22 +685,29 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, int HL>
 static int launch_s2dgrad4(ConvArgs4& a4, const int* hext, const int* wext, hipStream_t stream) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     size_t lds = 0; long gmax = 0;
+    long rows = 0;
+    const bool rows_ok = a4.c[0].cout_store % 4 == 0 && NT % (WAVES_N * WN * 4) == 0;
     for (int k = 0; k < 4; ++k) {
         a4.tiles[k] = 0;
+        a4.c[k].bn_row0 = (int)rows;                     // the four classes' pixel tiles one after the other
         if (a4.c[k].GH <= 0 || a4.c[k].GW <= 0) continue;
         size_t l; int mode; long grid;
         const int rc = prep_cfg<WAVES_M, WAVES_N, WM, WN, 1, HL>(a4.c[k], hext[k], wext[k], 256, &l, &mode, &grid);
         if (rc) return rc;
         if (mode != (k == 0 ? 2 : (k == 3 ? 0 : 1)) || a4.c[k].ksplit != 1) return PESR_EINVAL;
         a4.tiles[k] = (int)grid;
+        rows += (long)a4.c[k].N * a4.c[k].tiles_y * a4.c[k].tiles_x;
         if (l > lds) lds = l;
         if (grid > gmax) gmax = grid;
     }
+    a4.c[0].bn_rows = rows_ok ? rows : 0;
+    if (a4.c[0].dry) return PESR_OK;
+    if (a4.c[0].bn_mode && (!rows_ok || rows > a4.c[0].bn_cap || !g_bn_epi.part)) return PESR_EINVAL;
     if (gmax == 0) return PESR_OK;
     auto kern = conv3x3_s2dgrad4_kernel<WAVES_M, WAVES_N, WM, WN, HL>;
     static PesrDeviceOnce attr_once;
     attr_once([&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    hipLaunchKernelGGL(kern, dim3((unsigned)gmax, 4), dim3(NT), lds, stream, a4);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gmax, 4), dim3(NT), lds, stream, a4, g_bn_epi);
     return pesr_launch_status();
 }
 
@@ -676,10 +744,21 @@ static int dispatch(ConvArgs& a, int hext, int wext, hipStream_t stream) {
 
 // Plain conv (forward).  Also serves the stride-1 dgrad when given dgrad-packed weights
 // (pack.hip mode 1: Cin/Cout swapped) and flip=1 (tap t reads weight tap 8-t).
+static void set_bn(ConvArgs& a, PesrBnFuseArgs* f) {
+    a.bn_mode = 0; a.dry = 0; a.bn_rows = 0; a.bn_row0 = 0; a.bn_cap = 0;
+    g_bn_epi = BnEpi{};
+    if (!f) return;
+    a.dry = f->dry;
+    if (f->dry || !f->mode) return;
+    a.bn_mode = f->mode; a.bn_cap = f->rows;
+    g_bn_epi.mode = f->mode; g_bn_epi.slope = f->slope; g_bn_epi.part = f->part;
+    g_bn_epi.z = f->z; g_bn_epi.mi = f->mean_invstd; g_bn_epi.gamma = f->gamma; g_bn_epi.beta = f->beta;
+}
+
 int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask,
                         float* y, int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act,
                         float slope, int ps, int ps_in, int flip, int cin_real, int cout_store, void* ws, size_t ws_bytes,
-                        hipStream_t stream) {
+                        hipStream_t stream, PesrBnFuseArgs* fuse) {
     // cin_real / cout_store: physical channel counts of x / y (0 = same as Cin / Cout).  The RGB layers
     // (3 -> N, N -> 3) run here zero-padded to Cin = 16 / Cout = 64 with 3-channel tensors in memory.
     if (cin_real == 0) cin_real = Cin;
@@ -700,7 +779,11 @@ int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, cons
     a.alpha = alpha; a.slope = slope; a.act = act; a.ps = ps; a.ps_in = ps_in;
     a.cin_real = cin_real; a.cout_store = cout_store;
     a.slab = (float*)ws; a.slab_bytes = ws_bytes;
-    return stride == 1 ? dispatch<1>(a, 3, 3, stream) : dispatch<2>(a, 3, 3, stream);
+    set_bn(a, fuse);
+    if (fuse && fuse->mode == 2 && (mask || skip || bias || act != PESR_ACT_NONE)) return PESR_EINVAL;
+    const int rc = stride == 1 ? dispatch<1>(a, 3, 3, stream) : dispatch<2>(a, 3, 3, stream);
+    if (fuse) fuse->rows_out = rc ? 0 : a.bn_rows;
+    return rc;
 }
 
 // Input gradient of a stride-2 3x3 conv (pad 1): dx[y][x] = sum over taps with (y+1-ky), (x+1-kx)
@@ -708,7 +791,7 @@ int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, cons
 // four small stride-1 problems over dy with 1, 2, 2 and 4 taps - no multiply-by-zero work.
 // wp is the dgrad packing (pack.hip mode 1; tap index = ky*3+kx of the forward weights).
 int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* mask, float* dx, int N, int H, int W,
-                                 int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream) {
+                                 int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream, PesrBnFuseArgs* fuse) {
     // H, W: spatial size of dx (the forward input); dy is [N][OH][OW][Cout_fwd]
     if (Cout_fwd % 16) return PESR_EINVAL;
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
@@ -736,8 +819,11 @@ int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* 
         a.alpha = alpha; a.slope = 0.f; a.act = PESR_ACT_NONE; a.ps = 0; a.ps_in = 0;
         a.cin_real = Cout_fwd; a.cout_store = Cin_fwd;
         a.slab = nullptr; a.slab_bytes = 0; a.ksplit = 1;
+        set_bn(a, fuse);
         hext[k] = py + 1; wext[k] = px + 1;
     }
+    if (fuse && fuse->mode == 2 && mask) return PESR_EINVAL;
+    if (fuse) fuse->rows_out = 0;
     // One configuration for the four classes.  The 48-pixel tiles wherever ONE class alone would leave the 144-pixel tiles at about
     // one workgroup per CU (measured with the four classes in one grid, same box: 256 <- 256 @48: 112.7 us against 154.6 with the
     // 144 x 256 tiles; 512 <- 512 @24: 120.6 against 183.2; four launches: 139.7 / 185.8), else the largest tile that fills the chip
@@ -746,6 +832,8 @@ int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* 
     const long M = (long)N * a4.c[0].GH * a4.c[0].GW;          // pixels of one class
     if (Cout % 64) {
         // (channel counts the merged kernel has no configuration for: one launch per class, as before)
+        if (fuse && !fuse->dry && fuse->mode) return PESR_EINVAL;
+        if (fuse && fuse->dry) return PESR_OK;
         for (int k = 0; k < 4; ++k) {
             if (a4.c[k].GH <= 0 || a4.c[k].GW <= 0) continue;
             const int rc = dispatch<1>(a4.c[k], hext[k], wext[k], stream);
@@ -753,8 +841,11 @@ int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* 
         }
         return PESR_OK;
     }
-    if (Cout >= 128 && (long)pesr_cdiv(M, 144) * (Cout / 64) <= 320) return launch_s2dgrad4<1, 4, 3, 1, 2>(a4, hext, wext, stream);
-    if (Cout % 256 == 0 && 4 * (M / 144) * (Cout / 256) >= 192) return launch_s2dgrad4<1, 8, 9, 2, 2>(a4, hext, wext, stream);
-    if (Cout % 128 == 0 && 4 * (M / 144) * (Cout / 128) >= 192) return launch_s2dgrad4<1, 8, 9, 1, 2>(a4, hext, wext, stream);
-    return launch_s2dgrad4<1, 4, 9, 1, 4>(a4, hext, wext, stream);
+    int rc;
+    if (Cout >= 128 && (long)pesr_cdiv(M, 144) * (Cout / 64) <= 320) rc = launch_s2dgrad4<1, 4, 3, 1, 2>(a4, hext, wext, stream);
+    else if (Cout % 256 == 0 && 4 * (M / 144) * (Cout / 256) >= 192) rc = launch_s2dgrad4<1, 8, 9, 2, 2>(a4, hext, wext, stream);
+    else if (Cout % 128 == 0 && 4 * (M / 144) * (Cout / 128) >= 192) rc = launch_s2dgrad4<1, 8, 9, 1, 2>(a4, hext, wext, stream);
+    else rc = launch_s2dgrad4<1, 4, 9, 1, 4>(a4, hext, wext, stream);
+    if (fuse) fuse->rows_out = rc ? 0 : a4.c[0].bn_rows;
+    return rc;
 }

@@ -69,7 +69,8 @@ constexpr int W4_BN = 64, W4_MG = 9;
 // chunk's V buffer" is one add per fragment offset and chunk: the loop loses its per-read address add (87 -> 38 v_add_u32 per
 // chunk and wave; G body forward 185.1 -> 182.6 us, 227.7 -> 229.4 patches/s).
 template <bool DENSE, int TXTC>
-__global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
+__global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a, const BnEpi bn_arg) {
+    (void)bn_arg;                                          // BatchNorm sums from the epilogue (common.h BnEpi): read through pesr_bn_epi() behind the main loop
     static_assert(!(DENSE && TXTC), "the constant-row-length form is for the non-dense layout");
     constexpr int NT = 512;                                // threads of the workgroup
     constexpr int NXL = 3;                                 // xi planes per wave
@@ -329,6 +330,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     const int co = n0 + cb * 16 + g * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias && a.ksplit == 1) bias4 = *(const f32x4*)(a.bias + co);
+    const BnEpi* const bn = pesr_bn_epi((unsigned)((sizeof(Wino4Args) + 7) & ~(size_t)7));
+    const int bn_mode = a.ksplit == 1 ? bn->mode : 0;
+    const bool bn_on = bn_mode != 0;
+    const float* const bn_z = bn->z;
+    const float bn_slope = bn->slope;
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bmu = st1, bis = st1, bga = st1, bbe = st1;
+    if (bn_mode == 2) {
+        bmu = *(const f32x4*)(bn->mi + co); bis = *(const f32x4*)(bn->mi + a.Cout + co);
+        bga = *(const f32x4*)(bn->gamma + co); bbe = *(const f32x4*)(bn->beta + co);
+    }
     // batches of three m-tiles x two outputs: a batch's LDS reads and skip / mask loads are issued before its first store.
     // (Round 4 measured the skip / mask loads issued ONE BATCH AHEAD, the first batch's in front of the exchange barrier: 175.9 vs
     // 172.6 us with bias + ReLU, 179.4 vs 177.1 with the skip, 179.0 vs 177.3 with the mask - slower in every form; and a PERSISTENT
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
     // profiles/r04_ab_notes.txt)
 #pragma unroll
     for (int ib = 0; ib < W4_MG; ib += 3) {
-        f32x4 v[6], mkv[6], skv[6];
+        f32x4 v[6], mkv[6], skv[6], zv[6];
         size_t idx[6];
         bool ok[6];
 #pragma unroll
@@ -368,6 +380,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
             if (a.ksplit == 1) {
                 if (a.mask) mkv[e] = *(const f32x4*)(a.mask + idx[e]);
                 if (a.skip) skv[e] = *(const f32x4*)(a.skip + idx[e]);
+                if (bn_mode == 2) zv[e] = *(const f32x4*)(bn_z + idx[e]);
             }
         }
 #pragma unroll
@@ -391,7 +404,40 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a) {
                 o.x = o.x > 0.f ? o.x : o.x * a.slope; o.y = o.y > 0.f ? o.y : o.y * a.slope;
                 o.z = o.z > 0.f ? o.z : o.z * a.slope; o.w = o.w > 0.f ? o.w : o.w * a.slope;
             }
+            if (bn_on) {
+                if (bn_mode == 2) {
+                    const f32x4 xh = (zv[e] - bmu) * bis;
+                    const f32x4 zz = bga * xh + bbe;
+                    o.x = zz.x > 0.f ? o.x : o.x * bn_slope; o.y = zz.y > 0.f ? o.y : o.y * bn_slope;
+                    o.z = zz.z > 0.f ? o.z : o.z * bn_slope; o.w = zz.w > 0.f ? o.w : o.w * bn_slope;
+                    st1 += o; st2 += o * xh;
+                } else {
+                    st1 += o; st2 += o * o;
+                }
+            }
             *(f32x4*)(a.y + idx[e]) = o;
+        }
+    }
+    if (bn_on) {
+        // a lane's 18 outputs are pixels of ITS four channels (co .. co + 3): the 16 r-lanes x 2 xi-half waves of a (cb, g) pair
+        // meet through LDS and are added in double, in the fixed order (xt, r)
+        __syncthreads();                                   // the exchange slots are dead
+        f32x4* const red = (f32x4*)smem;                   // [2][8 waves][64 lanes]
+        red[wave * 64 + lane] = st1; red[512 + wave * 64 + lane] = st2;
+        __syncthreads();
+        if (tid < 16) {                                    // tid = cb * 4 + g: channels n0 + 4 tid .. + 3
+            const int cb_ = tid >> 2, g_ = tid & 3;
+            f64x4 d1 = {0.0, 0.0, 0.0, 0.0}, d2 = {0.0, 0.0, 0.0, 0.0};
+            for (int xt_ = 0; xt_ < 2; ++xt_)
+                for (int r_ = 0; r_ < 16; ++r_) {
+                    const int e = (xt_ * 4 + cb_) * 64 + g_ * 16 + r_;
+                    d1 += __builtin_convertvector(red[e], f64x4);
+                    d2 += __builtin_convertvector(red[512 + e], f64x4);
+                }
+            const int row = (img * a.tiles_y + ty) * a.tiles_x + tx;
+            float* const pr = bn->part + (size_t)row * 2 * a.Cout + n0 + tid * 4;
+            *(f32x4*)pr = __builtin_convertvector(d1, f32x4);
+            *(f32x4*)(pr + a.Cout) = __builtin_convertvector(d2, f32x4);
         }
     }
 }
@@ -498,9 +544,18 @@ int pesr_conv3x3_wino4_score_impl(int N, int H, int W, int Cin, int Cout, int al
 
 int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
                               int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
-                              void* ws, size_t ws_bytes, hipStream_t stream) {
+                              void* ws, size_t ws_bytes, hipStream_t stream, PesrBnFuseArgs* fuse) {
     W4Plan p;
-    if (!w4_plan(N, H, W, Cin, Cout, ws != nullptr && !ps, ws_bytes, !ps && !ps_in, &p)) return PESR_EINVAL;
+    if (fuse) fuse->rows_out = 0;
+    if (!w4_plan(N, H, W, Cin, Cout, (ws != nullptr || (fuse && fuse->dry)) && !ps, (fuse && fuse->dry) ? (size_t)-1 : ws_bytes, !ps && !ps_in, &p)) return PESR_EINVAL;
+    // BatchNorm sums from the epilogue: one row per pixel tile; not with split-K (the finish kernel sums the slabs) or a shuffled store
+    const long bn_rows = (p.ksplit == 1 && !ps) ? p.tiles / p.n_tiles : 0;
+    if (fuse) {
+        fuse->rows_out = bn_rows;
+        if (fuse->dry) return PESR_OK;
+        if (fuse->mode && (bn_rows == 0 || bn_rows > fuse->rows || !fuse->part)) return PESR_EINVAL;
+        if (fuse->mode == 2 && (mask || skip || bias || act != PESR_ACT_NONE)) return PESR_EINVAL;
+    }
     if (ps && (Cout % 256 || skip || mask)) return PESR_EINVAL;    // a 64-channel n-tile must stay inside one sub-pixel plane
     if (ps_in && Cin % 64) return PESR_EINVAL;
     Wino4Args a{};
@@ -513,6 +568,11 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     a.ksplit = p.ksplit; a.chunks_per_split = p.chunks_per_split; a.slab = (float*)ws;
     a.stack = p.stack; a.stack_n = N; a.v_row = p.v_row;
     if (p.stack) a.N = 1;
+    BnEpi bn{};
+    if (fuse && fuse->mode) {
+        bn.mode = fuse->mode; bn.part = fuse->part; bn.z = fuse->z; bn.mi = fuse->mean_invstd; bn.gamma = fuse->gamma;
+        bn.beta = fuse->beta; bn.slope = fuse->slope;
+    }
     static PesrDeviceOnce attr_once;
     attr_once([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -521,10 +581,10 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid((unsigned)(p.tiles * p.ksplit));
-    if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0>), grid, dim3(512), p.lds, stream, a);
-    else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12>), grid, dim3(512), p.lds, stream, a);
-    else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24>), grid, dim3(512), p.lds, stream, a);
-    else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0>), grid, dim3(512), p.lds, stream, a);
+    if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0>), grid, dim3(512), p.lds, stream, a, bn);
+    else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12>), grid, dim3(512), p.lds, stream, a, bn);
+    else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24>), grid, dim3(512), p.lds, stream, a, bn);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0>), grid, dim3(512), p.lds, stream, a, bn);
     if (p.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, act,
                                               slope, stream);

@@ -7,11 +7,26 @@ int pesr_pack_conv3x3_launch(const float* w, float* out, int O, int I, int mode,
 int pesr_pack_conv3x3_batched_launch(const long long* desc, int count, hipStream_t stream);
 int pesr_pack_bias_ps_launch(const float* b, float* out, int O, hipStream_t stream);
 
+// BatchNorm sums out of a conv kernel's epilogue (round 6; include/pesr_hip.h PesrBnFuse + the launcher's own in / out fields)
+struct PesrBnFuseArgs {
+    int mode;                 // 1: sum / sum of squares of the stored output; 2: the kernel writes g' = v * lrelu'(bn(z)) and sums g', g' * xhat
+    int rows;                 // capacity of `part` in rows of [2][C]
+    float* part;
+    const float* z;           // mode 2
+    const float* mean_invstd; // mode 2: [2][C]
+    const float* gamma;
+    const float* beta;
+    float slope;
+    int dry;                  // plan only: report rows_out, launch nothing
+    long rows_out;            // rows the launch writes (0: this shape is not covered - split-K, packed-shuffle stores, odd channel counts)
+};
+
 int pesr_conv3x3_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
                         int N, int H, int W, int Cin, int Cout, int stride, float alpha, int act, float slope, int ps,
-                        int ps_in, int flip, int cin_real, int cout_store, void* ws, size_t ws_bytes, hipStream_t stream);
+                        int ps_in, int flip, int cin_real, int cout_store, void* ws, size_t ws_bytes, hipStream_t stream,
+                        PesrBnFuseArgs* fuse = nullptr);
 int pesr_conv3x3_s2_dgrad_launch(const float* dy, const float* wp, const float* mask, float* dx, int N, int H, int W,
-                                 int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream);
+                                 int Cout_fwd, int Cin_fwd, float alpha, hipStream_t stream, PesrBnFuseArgs* fuse = nullptr);
 
 size_t pesr_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int stride, int algo);
 int pesr_conv3x3_wgrad_launch(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
@@ -45,6 +60,11 @@ int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma
                              float* dx, float* dgamma, float* dbeta, long M, int C, long HW, float slope, int dy_nchw, int accumulate,
                              void* ws, size_t ws_bytes, hipStream_t stream);
 
+int pesr_bn_finalize_launch(const float* part, int rows, int C, long M, float eps, float momentum, float* mean_invstd, float* running_mean,
+                            float* running_var, long long* num_batches, hipStream_t stream);
+int pesr_bn_lrelu_bwd_fused_launch(const float* z, const float* gmasked, const float* part, int rows, const float* gamma, const float* beta,
+                                   const float* mean_invstd, float* dz, float* dgamma, float* dbeta, long M, int C, long HW, int accumulate,
+                                   void* ws, size_t ws_bytes, hipStream_t stream);
 int pesr_bn_lrelu_apply_launch(const float* x, const float* gamma, const float* beta, const float* mean_invstd, float* y, long M,
                                int C, long HW, float slope, int y_nchw, hipStream_t stream);
 int pesr_bn_lrelu_bwd_eval_launch(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean_invstd,
@@ -121,7 +141,7 @@ int pesr_conv3x3_wino4_score_impl(int N, int H, int W, int Cin, int Cout, int al
 int pesr_pack_conv3x3_wino4_launch(const float* w, float* out, int O, int I, int mode, int ps, hipStream_t stream);
 int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
                               int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
-                              void* ws, size_t ws_bytes, hipStream_t stream);
+                              void* ws, size_t ws_bytes, hipStream_t stream, PesrBnFuseArgs* fuse = nullptr);
 int pesr_conv_splitk_finish_launch(const float* slab, const float* bias, const float* skip, const float* mask, float* y, long total,
                                    int C, int ksplit, float alpha, int act, float slope, hipStream_t stream);
 int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,

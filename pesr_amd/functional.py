@@ -617,31 +617,58 @@ class MeanShiftFn(Function):
 # ------------------------------------------------------------------------------------------------
 # Discriminator BasicBlock: conv(no bias) -> BatchNorm2d(train) -> LeakyReLU(0.2)   reference model/basic.py:19-31
 # ------------------------------------------------------------------------------------------------
+class BnLink:
+    """What the block that CONSUMES a BasicBlock's output needs from it (round 6): with z, the saved statistics and the affine
+    parameters of the producer's BatchNorm, the consumer's input-gradient kernel writes the gradient of the producer's output already
+    multiplied by lrelu'(bn(z)) and leaves the two per-channel sums of the BatchNorm backward in its epilogue (ops.conv3x3_dgrad_bn_sums):
+    the producer's backward then runs no reduction pass over the tensor.  The forward fills z .. slope; the consumer's backward fills
+    part / g_ptr; the producer's backward uses them once and clears them.  Only ever attached between two blocks whose connecting tensor
+    nobody else sees (Discriminator.forward's chain), so the gradient that arrives IS the tensor the consumer wrote (checked by address)."""
+    __slots__ = ("z", "stats", "gamma", "beta", "slope", "part", "g_ptr")
+
+    def __init__(self):
+        self.z = self.stats = self.gamma = self.beta = self.part = self.g_ptr = None
+        self.slope = 0.0
+
+
 class ConvBnLReluFn(Function):
     """conv (bias optional) -> BatchNorm2d -> activation given by its negative slope (0.2 LeakyReLU, 0 ReLU, 1 none).
     training = True: batch statistics (and the running-stat update) - the Discriminator's only use; training = False: the
     running statistics (nn.BatchNorm2d in .eval(): a constructor branch of reference model/basic.py:26-30 the reference's own
-    scripts never take)."""
+    scripts never take).
+    Round 6: where the conv kernel can leave the BatchNorm's sums in its epilogue (ops.conv3x3_fwd_bn_stats: the direct stride-2
+    layers and the F(4,3) layers without split-K) the forward runs conv -> finalize -> apply, and the backward takes the sums of
+    its reduction pass from the kernel that produced its incoming gradient (BnLink)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches, cache, stride, eps, momentum,
-                slope, y_nchw, training):
+                slope, y_nchw, training, prev_link=None, link=None):
         x = _c(x)
+        ctx.prev_link, ctx.link = prev_link, None
         if training and bias is None and tuple(weight.shape[2:]) == (3, 3) and ops.conv_rgb_bn_eligible(x.shape[3], weight.shape[0], stride):
             # the Discriminator's features.0: the statistics come out of the conv kernel's epilogue (no pass over z for them)
             z, y, stats = ops.conv_rgb_bn_lrelu_fwd(x, weight.detach(), gamma.detach(), beta.detach(), running_mean, running_var,
                                                     num_batches, eps, momentum, slope, y_nchw)
-            ctx.cache, ctx.stride, ctx.slope, ctx.y_nchw, ctx.training, ctx.bias_ref = cache, stride, slope, y_nchw, training, bias
-            ctx.save_for_backward(x, z, weight, gamma, beta, stats)
-            return y
-        z = ops.conv3x3_fwd(x, lambda: cache.for_fwd(weight, x.shape, stride), None if bias is None else bias.detach(), weight.shape[0],
-                            stride, w_oihw=weight.detach())
-        if training:
-            y, stats = ops.bn_lrelu_fwd(z, gamma.detach(), beta.detach(), running_mean, running_var, num_batches, eps,
-                                        momentum, slope, y_nchw)
         else:
-            stats = ops.bn_eval_stats(running_mean, running_var, eps)
-            y = ops.bn_lrelu_eval_fwd(z, gamma.detach(), beta.detach(), stats, slope, y_nchw)
+            res = None
+            if training:
+                res = ops.conv3x3_fwd_bn_stats(x, cache.for_fwd(weight, x.shape, stride), None if bias is None else bias.detach(), weight.shape[0], stride)
+            if res is not None:
+                z, part = res
+                y, stats = ops.bn_finalize_apply(z, part, gamma.detach(), beta.detach(), running_mean, running_var, num_batches, eps, momentum,
+                                                 slope, y_nchw)
+            else:
+                z = ops.conv3x3_fwd(x, lambda: cache.for_fwd(weight, x.shape, stride), None if bias is None else bias.detach(), weight.shape[0],
+                                    stride, w_oihw=weight.detach())
+                if training:
+                    y, stats = ops.bn_lrelu_fwd(z, gamma.detach(), beta.detach(), running_mean, running_var, num_batches, eps,
+                                                momentum, slope, y_nchw)
+                else:
+                    stats = ops.bn_eval_stats(running_mean, running_var, eps)
+                    y = ops.bn_lrelu_eval_fwd(z, gamma.detach(), beta.detach(), stats, slope, y_nchw)
+        if link is not None and training and not y_nchw:
+            link.z, link.stats, link.gamma, link.beta, link.slope = z, stats, gamma.detach(), beta.detach(), slope
+            ctx.link = link
         ctx.cache, ctx.stride, ctx.slope, ctx.y_nchw, ctx.training, ctx.bias_ref = cache, stride, slope, y_nchw, training, bias
         ctx.save_for_backward(x, z, weight, gamma, beta, stats)
         return y
@@ -652,6 +679,18 @@ class ConvBnLReluFn(Function):
         gy = _c(gy)
         need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         bwd = ops.bn_lrelu_bwd if ctx.training else ops.bn_lrelu_eval_bwd
+        # the gradient that arrives was written by the consumer's input-gradient kernel, already multiplied by lrelu'(bn(z)), and that
+        # kernel left the two sums of the BatchNorm backward (BnLink): no reduction pass
+        link, part = ctx.link, None
+        if link is not None and link.part is not None:
+            if gy.data_ptr() != link.g_ptr or tuple(gy.shape) != tuple(z.shape):
+                raise RuntimeError("pesr_amd: the masked gradient a fused input-gradient kernel wrote for this BatchNorm did not arrive as "
+                                   "written (its block's output has another consumer?)")
+            part, link.part, link.g_ptr = link.part, None, None
+
+            def bwd(z_, gy_, gamma_, beta_, stats_, slope_, nchw_, need_, dgamma_out=None, dbeta_out=None, accumulate=False):   # noqa: F811
+                return ops.bn_lrelu_bwd_fused(z_, gy_, part, gamma_, beta_, stats_, need_, dgamma_out=dgamma_out, dbeta_out=dbeta_out,
+                                              accumulate=accumulate)
         # SECOND use of this block inside one backward pass (the Discriminator sees hr and sr in one graph, reference
         # train.py:205-214): the parameter gradients are ADDED to the flat-gradient slices the first use wrote and autograd gets
         # nothing to add - its fan-in add_ plus the copy of the sum into the flat buffer were two launches per parameter tensor
@@ -686,8 +725,17 @@ class ConvBnLReluFn(Function):
                 else:
                     dw, db = ops.conv3x3_wgrad(x, dz, ctx.stride, want_bias=want_b, dw_out=o_w, db_out=o_b)
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3x3_rgb_in_dgrad(dz, weight.detach(), tuple(x.shape)) if rgb_in_dgrad else ops.conv3x3_dgrad(dz, wpd, tuple(x.shape), ctx.stride)
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+            prev = ctx.prev_link
+            res = None
+            if prev is not None and prev.z is not None and not rgb_in_dgrad:
+                # x is the output of a BatchNorm + LeakyReLU block: fold that block's backward reductions into this kernel's epilogue
+                res = ops.conv3x3_dgrad_bn_sums(dz, wpd, tuple(x.shape), ctx.stride, prev.z, prev.stats, prev.gamma, prev.beta, prev.slope)
+            if res is not None:
+                dx, prev.part = res
+                prev.g_ptr = dx.data_ptr()
+            else:
+                dx = ops.conv3x3_rgb_in_dgrad(dz, weight.detach(), tuple(x.shape)) if rgb_in_dgrad else ops.conv3x3_dgrad(dz, wpd, tuple(x.shape), ctx.stride)
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -146,7 +146,7 @@ def _conv_act(conv, x_nhwc, act):
     return PF.ConvLReluFn.apply(x_nhwc, w, conv.bias, conv.packed, conv.stride, slope)
 
 
-def _conv_bn_act(conv, bn, x_nhwc, act, y_nchw=False):
+def _conv_bn_act(conv, bn, x_nhwc, act, y_nchw=False, prev_link=None, link=None):
     if conv.kernel_size != 3:       # generic conv -> BatchNorm -> activation, un-fused (training-mode statistics only)
         if not (bn.training or bn.running_mean is None):
             raise NotImplementedError("eval-mode BatchNorm behind a conv with kernel_size != 3")
@@ -157,7 +157,7 @@ def _conv_bn_act(conv, bn, x_nhwc, act, y_nchw=False):
         return nchw(y).contiguous() if y_nchw else y
     return PF.ConvBnLReluFn.apply(x_nhwc, conv.effective_weight(), conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked, conv.packed, conv.stride, bn.eps, bn.momentum, _act_slope(act), y_nchw,
-                                  bn.training or bn.running_mean is None)
+                                  bn.training or bn.running_mean is None, prev_link, link)
 
 
 class BasicBlock(nn.Sequential):
@@ -179,6 +179,17 @@ class BasicBlock(nn.Sequential):
         super().__init__(*m)
         self._has_bn, self._has_act = bn, act is not None
         self.flatten_output = False  # set by Discriminator on its last block: emit NCHW-contiguous for .view(B, -1)
+
+    def forward_linked(self, x, prev_link):
+        """forward() for a caller that chains blocks itself and keeps the tensors in between to itself (Discriminator.forward):
+        -> (output, BnLink | None).  prev_link: the link returned for the block that produced x.  With the links the backward pass
+        folds each block's BatchNorm reductions into the input-gradient kernel of the block behind it (functional.BnLink)."""
+        conv = self[0]
+        if not (self._has_bn and conv.kernel_size == 3 and self._has_act) or (self._has_bn and self[1].momentum is None):
+            return self.forward(x), None
+        link = None if self.flatten_output else PF.BnLink()
+        y = _conv_bn_act(conv, self[1], nhwc(x), self[-1], self.flatten_output, prev_link, link)
+        return (y if self.flatten_output else nchw(y)), link
 
     def forward(self, x):
         conv = self[0]

@@ -65,7 +65,11 @@ class Discriminator(nn.Module):
         self.classifier = nn.Sequential(nn.Linear(512 * side * side, 1024), lrelu, nn.Linear(1024, 1))
 
     def forward(self, x):
-        flat = self.features(x)
+        # the blocks are chained here (not through nn.Sequential.forward) so that each block knows its producer: the tensors in between
+        # are seen by nobody else, which lets a block's input-gradient kernel do the BatchNorm reductions of the block in front of it
+        flat, link = x, None
+        for blk in self.features:
+            flat, link = blk.forward_linked(flat, link) if isinstance(blk, BasicBlock) else (blk(flat), None)
         flat = flat.view(flat.size(0), -1)
         fc1, act, fc2 = self.classifier
         hidden = PF.LinearFn.apply(flat, fc1.weight, fc1.bias, ops.ACT_LRELU, act.negative_slope)

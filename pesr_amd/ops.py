@@ -795,6 +795,128 @@ def conv_rgb_bn_lrelu_fwd(x, w_oihw, gamma, beta, running_mean, running_var, num
     return z, y, stats
 
 
+# ---- convs whose epilogue leaves the BatchNorm sums (round 6; include/pesr_hip.h PesrBnFuse) -------------------------------------------
+class _BnFuse(__import__("ctypes").Structure):
+    _fields_ = [("mode", __import__("ctypes").c_int), ("rows", __import__("ctypes").c_int), ("part", __import__("ctypes").c_void_p),
+                ("z", __import__("ctypes").c_void_p), ("mean_invstd", __import__("ctypes").c_void_p), ("gamma", __import__("ctypes").c_void_p),
+                ("beta", __import__("ctypes").c_void_p), ("slope", __import__("ctypes").c_float)]
+
+
+BN_FWD_STATS, BN_BWD_MASK_SUMS = 1, 2
+USE_BN_FUSE = __import__("os").environ.get("PESR_BN_FUSE", "1") != "0"     # PESR_BN_FUSE=0: the un-fused BatchNorm passes everywhere (A/B switch)
+_BN_ROWS = {}
+
+
+def conv_bn_rows(which: int, N: int, H: int, W: int, Cin: int, Cout: int, stride: int = 1) -> int:
+    """Rows of BatchNorm sums the fused call `which` (0 = conv3x3_fwd_bn on direct packing, 1 = conv3x3_dgrad_bn on direct dgrad packing,
+    2 = the F(4,3) kernel) leaves for this problem; 0: not covered (split-K layers, odd channel counts) - use the un-fused calls."""
+    if not USE_BN_FUSE:
+        return 0
+    key = (which, N, H, W, Cin, Cout, stride)
+    r = _BN_ROWS.get(key)
+    if r is None:
+        r = _BN_ROWS[key] = int(_lib.lib().pesr_conv3x3_bn_rows(which, N, H, W, Cin, Cout, stride))
+    return r
+
+
+def _fuse_struct(mode, part, z=None, stats=None, gamma=None, beta=None, slope=0.0):
+    f = _BnFuse()
+    f.mode, f.rows, f.part = mode, part.shape[0], part.data_ptr()
+    f.z, f.mean_invstd, f.gamma, f.beta, f.slope = _p(z), _p(stats), _p(gamma), _p(beta), float(slope)
+    return f
+
+
+def conv3x3_fwd_bn_stats(x: torch.Tensor, wp, bias: Optional[torch.Tensor], cout: int, stride: int = 1):
+    """z = conv(x) (+ bias) with the per-pixel-tile sums of z and z^2 left by the kernel's epilogue -> (z, part [rows, 2, cout]) or None when
+    the fused form does not cover this problem / packing (the caller then runs conv3x3_fwd + bn_lrelu_fwd)."""
+    import ctypes
+    _chk(x, "conv3x3_fwd_bn_stats.x")
+    N, H, W, Cin = x.shape
+    four = isinstance(wp, Wino4Packed)
+    if not four and not torch.is_tensor(wp):
+        return None
+    rows = conv_bn_rows(2, N, H, W, Cin, cout, 1) if four else conv_bn_rows(0, N, H, W, Cin, cout, stride)
+    if rows == 0:
+        return None
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    L = _lib.lib()
+    z = torch.empty((N, OH, OW, cout), dtype=torch.float32, device=x.device)
+    part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    f = _fuse_struct(BN_FWD_STATS, part)
+    nws = L.pesr_conv3x3_workspace_bytes(N, OH, OW, cout)
+    ws = workspace(nws, x.device) if nws else None
+    if FLOPS.on:
+        FLOPS.add(18.0 * N * OH * OW * Cin * cout, *_conv_family(wp))
+    br = KERNEL_EVENTS.begin("fwd", N, H, W, Cin, cout, stride)
+    if four:
+        rc = L.pesr_conv3x3_wino4_bn(_p(x), _p(wp.t), _p(bias), _p(z), N, H, W, Cin, cout, _p(ws), nws, ctypes.byref(f), _stream())
+    else:
+        rc = L.pesr_conv3x3_fwd_bn(_p(x), _p(wp), _p(bias), _p(z), N, H, W, Cin, cout, stride, _p(ws), nws, ctypes.byref(f), _stream())
+    KERNEL_EVENTS.end(br)
+    _lib.check(rc, f"pesr_conv3x3_{'wino4' if four else 'fwd'}_bn[{N}x{H}x{W}x{Cin}->{cout},s{stride}]")
+    return z, part
+
+
+def bn_finalize_apply(z, part, gamma, beta, running_mean, running_var, num_batches, eps=1e-5, momentum=0.1, slope=0.2, y_nchw=False):
+    """The BatchNorm of z from the sums a conv kernel left (conv3x3_fwd_bn_stats): finalize + apply -> (y, stats [2, C])."""
+    N, H, W, C = z.shape
+    L = _lib.lib()
+    stats = torch.empty((2, C), dtype=torch.float32, device=z.device)
+    _lib.check(L.pesr_bn_finalize(_p(part), part.shape[0], C, N * H * W, eps, momentum, _p(stats), _p(running_mean), _p(running_var),
+                                  _p(num_batches), _stream()), "pesr_bn_finalize")
+    y = torch.empty((N, C, H, W) if y_nchw else (N, H, W, C), dtype=torch.float32, device=z.device)
+    _lib.check(L.pesr_bn_lrelu_eval_fwd(_p(z), _p(gamma), _p(beta), _p(stats), _p(y), N, H, W, C, slope, int(y_nchw), _stream()), "pesr_bn_lrelu_eval_fwd")
+    return y, stats
+
+
+def conv3x3_dgrad_bn_sums(dy: torch.Tensor, wpd, in_shape, stride, z, stats, gamma, beta, slope):
+    """The input gradient dx of a conv whose INPUT was y = lrelu(bn(z)): the kernel stores g' = dx * lrelu'(bn(z)) and leaves the sums of g'
+    and g' * xhat per pixel tile -> (g' [in_shape], part [rows, 2, C]) or None when the fused form does not cover the problem / packing."""
+    import ctypes
+    _chk(dy, "conv3x3_dgrad_bn_sums.dy")
+    N, H, W, Cin = in_shape
+    cout = dy.shape[3]
+    four = isinstance(wpd, Wino4Packed)
+    if not four and not torch.is_tensor(wpd):
+        return None
+    rows = conv_bn_rows(2, N, H, W, cout, Cin, 1) if four else conv_bn_rows(1, N, H, W, Cin, cout, stride)
+    if rows == 0:
+        return None
+    assert tuple(z.shape) == tuple(in_shape) and z.is_contiguous()
+    L = _lib.lib()
+    g = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
+    part = torch.empty((rows, 2, Cin), dtype=torch.float32, device=dy.device)
+    f = _fuse_struct(BN_BWD_MASK_SUMS, part, z, stats, gamma, beta, slope)
+    nws = L.pesr_conv3x3_workspace_bytes(N, H, W, Cin) if stride == 1 else 0
+    ws = workspace(nws, dy.device) if nws else None
+    if FLOPS.on:
+        FLOPS.add(18.0 * N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * Cin * cout, *_conv_family(wpd))
+    br = KERNEL_EVENTS.begin("dgrad", N, H, W, Cin, cout, stride)
+    if four:
+        rc = L.pesr_conv3x3_wino4_bn(_p(dy), _p(wpd.t), None, _p(g), N, H, W, cout, Cin, _p(ws), nws, ctypes.byref(f), _stream())
+    else:
+        rc = L.pesr_conv3x3_dgrad_bn(_p(dy), _p(wpd), _p(g), N, H, W, Cin, cout, stride, _p(ws), nws, ctypes.byref(f), _stream())
+    KERNEL_EVENTS.end(br)
+    _lib.check(rc, f"pesr_conv3x3_{'wino4' if four else 'dgrad'}_bn[{N}x{H}x{W}x{Cin}<-{cout},s{stride}]")
+    return g, part
+
+
+def bn_lrelu_bwd_fused(z, g_masked, part, gamma, beta, stats, need_param_grads=True, dgamma_out=None, dbeta_out=None, accumulate=False):
+    """BatchNorm backward from the sums the producing conv kernel left (conv3x3_dgrad_bn_sums): -> (dz, dgamma, dbeta)."""
+    _chk(g_masked, "bn_lrelu_bwd_fused.g")
+    assert not accumulate or (dgamma_out is not None and dbeta_out is not None)
+    N, H, W, C = z.shape
+    L = _lib.lib()
+    ws = workspace(2 * C * 4 + 256, z.device)
+    dz = torch.empty_like(z)
+    dgamma = _out(dgamma_out, (C,), z.device) if need_param_grads else None
+    dbeta = _out(dbeta_out, (C,), z.device) if need_param_grads else None
+    rc = L.pesr_bn_lrelu_bwd_fused(_p(z), _p(g_masked), _p(part), part.shape[0], _p(gamma), _p(beta), _p(stats), _p(dz), _p(dgamma), _p(dbeta),
+                                   N, H, W, C, int(accumulate), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "pesr_bn_lrelu_bwd_fused")
+    return dz, dgamma, dbeta
+
+
 def bn_lrelu_bwd(x, dy, gamma, beta, stats, slope=0.2, dy_nchw=False, need_param_grads=True, dgamma_out=None, dbeta_out=None,
                  accumulate=False):
     """accumulate: add to dgamma_out / dbeta_out (which then must be given) instead of overwriting them."""

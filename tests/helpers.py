@@ -134,7 +134,7 @@ def record_margins(record_id, rows, extra=None):
     return worst[0], worst[1], median
 
 
-def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0, detail=None, record=None, median_max=None):
+def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0, detail=None, record=None, median_max=None, median_vs_ref=None):
     """Gradient parity where fp32 itself is ill-conditioned (ReLU / LeakyReLU kinks, BatchNorm batch statistics, L1's sign):
     `g` holds the REFERENCE's fp32 gradient samples, `g64` the same computation done in float64
     (tests/golden/make_golden_fp64.py).  Per tensor, our error against the fp64 truth may be at most `factor` x the
@@ -144,7 +144,11 @@ def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0, detail=None, record=N
     get_grad(name) -> our gradient tensor.  Returns (tensors checked, (worst error / allowance, its name)).
     detail: a dict that receives {name: (our error, the reference's own fp32 error)}, both relative to the tensor's maximum.
     record: an id under which the margins are written to / checked against the parity-margin record (record_margins);
-    median_max: bound on the MEDIAN of our per-tensor errors (the whole-step bar: 1e-5)."""
+    median_max: bound on the MEDIAN of our per-tensor errors (the bar of the well-conditioned whole steps: 1e-5);
+    median_vs_ref: bound on median(our errors) / median(the reference's own fp32 errors) - the bar where fp32 itself is ill-conditioned
+    (the full GAN step: the reference's fp32 gradients miss the float64 truth by 1.5e-3 of a tensor's maximum AT THE MEDIAN, measured
+    in round 6, so no fp32 implementation can meet 1e-5 there; what can be held is that ours are as close to the truth as the
+    reference's)."""
     keys = [k[len(prefix) + 5:] for k in g.files if k.startswith(prefix + "gidx.")]
     assert keys
     net_floor = float(g64[prefix + "floor_worst"])
@@ -170,4 +174,9 @@ def grads_vs_fp64(get_grad, g, g64, prefix="", factor=3.0, detail=None, record=N
         _, _, median = record_margins(record, rows)
         if median_max is not None:
             assert median <= median_max, f"{record}: median gradient error {median:.2e} of the maximum > {median_max:.0e}"
+        if median_vs_ref is not None:
+            refs = sorted(r[1] for r in rows.values())
+            ref_median = refs[len(refs) // 2]
+            assert median <= median_vs_ref * ref_median, (f"{record}: median gradient error {median:.2e} > {median_vs_ref} x the reference's "
+                                                          f"own fp32 median {ref_median:.2e}")
     return len(keys), worst

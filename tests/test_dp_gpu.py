@@ -378,6 +378,13 @@ def test_n_rank_steps_vs_full_batch_oracle(nproc, backend, share, config, tmp_pa
     if gan:
         for k, v in st32.d.items():
             if v.is_floating_point() and "running" not in k:
+                g64 = st64.d[k].grad if k in st64.d else None
+                if g64 is not None and float(g64.abs().max()) < 1e-10:
+                    # a gradient that is ZERO in exact arithmetic (classifier.2.bias under RSGAN: pred_real - pred_fake cancels it; ~1e-9
+                    # of rounding noise in fp32): Adam moves the element by lr * g / (|g| + eps) - anywhere in +-lr per step, decided by the
+                    # noise (seen with eight ranks: 0.43 lr).  Only the bound of a step is a statement about the implementation.
+                    assert float((got["D"][k].double() - v.double()).abs().max()) <= 2.2 * 5e-5 * cfg["steps"], "D." + k
+                    continue
                 adam_close(got["D"][k], v, 5e-5, cfg["steps"], "D." + k)
 
 
