@@ -81,12 +81,13 @@ __device__ __forceinline__ void bn_rows2(const float* __restrict__ part, int nb,
     double s = 0.0, u = 0.0;
     if (valid) {
         int k = rl;
-        for (; k + 3 * RL < nb; k += 4 * RL) {
+        for (; k + 7 * RL < nb; k += 8 * RL) {      // 16 independent loads in flight; the additions stay in row order
             const float* p0 = part + (size_t)k * ncols;
-            const float a = p0[col0], b = p0[(size_t)RL * ncols + col0], c = p0[(size_t)2 * RL * ncols + col0], d = p0[(size_t)3 * RL * ncols + col0];
-            const float e = p0[col1], f = p0[(size_t)RL * ncols + col1], g = p0[(size_t)2 * RL * ncols + col1], h = p0[(size_t)3 * RL * ncols + col1];
-            s += (double)a; s += (double)b; s += (double)c; s += (double)d;
-            u += (double)e; u += (double)f; u += (double)g; u += (double)h;
+            float a[8], b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] = p0[(size_t)j * RL * ncols + col0]; b[j] = p0[(size_t)j * RL * ncols + col1]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s += (double)a[j]; u += (double)b[j]; }
         }
         for (; k < nb; k += RL) { s += (double)part[(size_t)k * ncols + col0]; u += (double)part[(size_t)k * ncols + col1]; }
     }
@@ -195,6 +196,28 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const float* __
     }
 }
 
+// [N][C][HW] -> [N][HW][C] through a 32 x 33 LDS tile (round 6): the gradient of the Discriminator's last block arrives NCHW-contiguous
+// (it is the flattened classifier input, reference model/pesr.py:79); read in place, a channel-group lane of the backward kernels
+// gathers its four channels HW floats apart - 64 cache lines per wave-load (bn_reduce<1> 43 us on 4.7 MB).  4 us for the copy instead.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    const float* s = src + (size_t)n * C * HW;
+    float* d = dst + (size_t)n * C * HW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + j * 8, p = p0 + tx;
+        if (c < C && p < HW) tile[ty + j * 8][tx] = s[(size_t)c * HW + p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + ty + j * 8, c = c0 + tx;
+        if (c < C && p < HW) d[(size_t)p * C + c] = tile[tx][ty + j * 8];
+    }
+}
+
 namespace {
 // many rows (a conv epilogue's pixel tiles, the 3 -> C kernel's 2048 workgroups): 16-channel blocks of 64 row lanes; few rows (bn_reduce's
 // <= 512 blocks): the 64-channel blocks of 16 row lanes these kernels always had (same order of additions as before round 6)
@@ -220,9 +243,14 @@ static void bn_grid(long M, long* nb, long* rpb) {
 }
 }  // namespace
 
-size_t pesr_bn_ws_bytes(long M, int C) {
+static size_t bn_ws_base(long M, int C) {
     long nb, rpb; bn_grid(M, &nb, &rpb);
-    return (size_t)nb * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(float) + 2 * (size_t)C * sizeof(double) + 512;
+    return ((size_t)nb * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(float) + 2 * (size_t)C * sizeof(double) + 512 + 255) / 256 * 256;
+}
+// + room for an NHWC copy of an NCHW gradient (small tensors only: the layer in front of the classifier)
+size_t pesr_bn_ws_bytes(long M, int C) {
+    const size_t copy = (size_t)M * C * sizeof(float);
+    return bn_ws_base(M, C) + (copy <= ((size_t)64 << 20) ? copy : 0);
 }
 
 // forward: x [M][C] (M = N*H*W) -> y; saves mean_invstd [2][C]
@@ -290,7 +318,17 @@ int pesr_bn_lrelu_bwd_launch(const float* x, const float* dy, const float* gamma
     float* part = (float*)((char*)ws + dsum_bytes);
     float* sums = (float*)((char*)ws + dsum_bytes + part_bytes);
     long sn = HW * C, sc = 1, sp = C;
-    if (dy_nchw) { sn = HW * C; sc = HW; sp = 1; }
+    if (dy_nchw) {
+        const size_t base = bn_ws_base(M, C), copy = (size_t)M * C * sizeof(float);
+        if (ws_bytes >= base + copy && HW > 1) {      // transpose once, then the coalesced NHWC paths
+            float* dyt = (float*)((char*)ws + base);
+            hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)(M / HW)), dim3(256), 0, stream,
+                               dy, dyt, C, (int)HW);
+            dy = dyt;
+        } else {
+            sn = HW * C; sc = HW; sp = 1;
+        }
+    }
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, x, dy, mean_invstd, gamma, beta, part, M, C, rpb, slope,
                        sn, sc, sp, HW);
     bn_bwd_sums_launch(part, (int)nb, C, sums, dbeta, dgamma, accumulate, stream);

@@ -347,7 +347,40 @@ __device__ __forceinline__ void conv3x3_mfma_body(const ConvArgs& a, const int b
         constexpr int MT = WAVES_M * WM * 16;
         constexpr int C4 = BN / 4;                  // float4 columns of the tile
         constexpr int RS = BN * 4 + 16;             // padded row stride: the 4 pixel rows of a store hit disjoint banks
+        constexpr int EIT = (MT * C4 + NT - 1) / NT;   // output float4s per thread
         char* const ob = smem;
+        // BatchNorm sums (NT % C4 == 0: a thread keeps its four channels over all its pixels)
+        const BnEpi* const bn = pesr_bn_epi(bn_kernarg_off);
+        const int bn_mode = a.ksplit == 1 ? bn->mode : 0;
+        const bool bn_on = bn_mode != 0;
+        const float bn_slope = bn->slope;
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bmu = st1, bis = st1, bga = st1, bbe = st1;
+        // output element u = tid + k * NT of the tile -> (in range, element offset of its four channels)
+        auto out_index = [&](int u, size_t* idx) -> bool {
+            const int m = u / C4, c4 = u - m * C4;
+            const int co = n0 + c4 * 4;
+            const int py = m / a.TW, px = m - py * a.TW;
+            const int gy = gy0 + py, gx = gx0 + px;
+            if (u >= MT * C4 || gy >= a.GH || gx >= a.GW || co >= a.cout_store) return false;
+            const int oy = gy * a.out_my + a.out_ay, ox = gx * a.out_mx + a.out_ax;
+            if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
+                const int C = a.Cout >> 2;
+                const int sub = co / C, cc = co - sub * C;
+                *idx = (((size_t)img * (2 * a.OH) + 2 * oy + (sub >> 1)) * (2 * a.OW) + 2 * ox + (sub & 1)) * C + cc;
+            } else {
+                *idx = (img_out + (size_t)oy * a.OW + ox) * a.cout_store + co;
+            }
+            return true;
+        };
+        f32x4 zpre[EIT];
+        if (bn_mode == 2) {
+            const int cq = n0 + (tid % C4) * 4;
+            if (cq < a.cout_store) {
+                bmu = *(const f32x4*)(bn->mi + cq); bis = *(const f32x4*)(bn->mi + a.cout_store + cq);
+                bga = *(const f32x4*)(bn->gamma + cq); bbe = *(const f32x4*)(bn->beta + cq);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -359,66 +392,61 @@ __device__ __forceinline__ void conv3x3_mfma_body(const ConvArgs& a, const int b
             }
         __syncthreads();
         const size_t slab_off = (size_t)ks * ((size_t)a.N * a.OH * a.OW * a.cout_store);
-        // BatchNorm sums (NT % C4 == 0: a thread keeps its four channels over all its pixels)
-        const BnEpi* const bn = pesr_bn_epi(bn_kernarg_off);
-        const int bn_mode = a.ksplit == 1 ? bn->mode : 0;
-        const bool bn_on = bn_mode != 0;
-        const float* const bn_z = bn->z;
-        const float bn_slope = bn->slope;
-        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 bmu = st1, bis = st1, bga = st1, bbe = st1;
         if (bn_mode == 2) {
-            const int cq = n0 + (tid % C4) * 4;
-            if (cq < a.cout_store) {
-                bmu = *(const f32x4*)(bn->mi + cq); bis = *(const f32x4*)(bn->mi + a.cout_store + cq);
-                bga = *(const f32x4*)(bn->gamma + cq); bbe = *(const f32x4*)(bn->beta + cq);
-            }
-        }
-        for (int u = tid; u < MT * C4; u += NT) {
-            const int m = u / C4, c4 = u - m * C4;
-            const int co = n0 + c4 * 4;
-            const int py = m / a.TW, px = m - py * a.TW;
-            const int gy = gy0 + py, gx = gx0 + px;
-            if (gy >= a.GH || gx >= a.GW || co >= a.cout_store) continue;
-            const int oy = gy * a.out_my + a.out_ay, ox = gx * a.out_mx + a.out_ax;
-            f32x4 v = *(const f32x4*)(ob + m * RS + c4 * 16);
-            size_t idx;
-            if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
-                const int C = a.Cout >> 2;
-                const int sub = co / C, cc = co - sub * C;
-                idx = (((size_t)img * (2 * a.OH) + 2 * oy + (sub >> 1)) * (2 * a.OW) + 2 * ox + (sub & 1)) * C + cc;
-            } else {
-                idx = (img_out + (size_t)oy * a.OW + ox) * a.cout_store + co;
-            }
-            if (a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
-                *(f32x4*)(a.slab + slab_off + idx) = v;
-                continue;
-            }
-            if (a.bias) v += *(const f32x4*)(a.bias + co);
-            v *= a.alpha;
-            if (a.mask) {
-                const f32x4 mk = *(const f32x4*)(a.mask + idx);
-                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-            }
-            if (a.skip) v += *(const f32x4*)(a.skip + idx);
-            if (a.act == PESR_ACT_RELU) {
-                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-            } else if (a.act == PESR_ACT_LRELU) {
-                v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
-                v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
-            }
-            if (bn_on) {
-                if (bn_mode == 2) {
-                    const f32x4 xh = (*(const f32x4*)(bn_z + idx) - bmu) * bis;
-                    const f32x4 zz = bga * xh + bbe;
-                    v.x = zz.x > 0.f ? v.x : v.x * bn_slope; v.y = zz.y > 0.f ? v.y : v.y * bn_slope;
-                    v.z = zz.z > 0.f ? v.z : v.z * bn_slope; v.w = zz.w > 0.f ? v.w : v.w * bn_slope;
-                    st1 += v; st2 += v * xh;
-                } else {
-                    st1 += v; st2 += v * v;
+            // (no bias / mask / skip / activation here: the launcher refuses them with this mode)
+            // mode 2 reads z at every output element: ALL of a thread's loads are issued here, behind the staging barrier, and the store
+            // loop consumes them in order.  Measured on the 16 x 192 x 192 x 64 input gradient (157 us plain): loads inside the store
+            // loop 218 us (a chain of EIT dependent HBM latencies per thread), all issued in FRONT of the staging barrier 216 (the
+            // barrier's vmcnt(0) waits for them with nothing to overlap), all issued here 196 (scripts/bn_fuse_time.py)
+            {
+                const float* const bn_z = bn->z;
+#pragma unroll
+                for (int k = 0; k < EIT; ++k) {
+                    size_t idx;
+                    zpre[k] = out_index(tid + k * NT, &idx) ? *(const f32x4*)(bn_z + idx) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
-            *(f32x4*)(a.y + idx) = v;
+#pragma unroll
+            for (int k = 0; k < EIT; ++k) {
+                const int u = tid + k * NT;
+                size_t idx;
+                if (!out_index(u, &idx)) continue;
+                const int m = u / C4, c4 = u - m * C4;
+                f32x4 v = *(const f32x4*)(ob + m * RS + c4 * 16) * a.alpha;
+                const f32x4 xh = (zpre[k] - bmu) * bis;
+                const f32x4 zz = bga * xh + bbe;
+                v.x = zz.x > 0.f ? v.x : v.x * bn_slope; v.y = zz.y > 0.f ? v.y : v.y * bn_slope;
+                v.z = zz.z > 0.f ? v.z : v.z * bn_slope; v.w = zz.w > 0.f ? v.w : v.w * bn_slope;
+                st1 += v; st2 += v * xh;
+                *(f32x4*)(a.y + idx) = v;
+            }
+        } else {
+            for (int u = tid; u < MT * C4; u += NT) {
+                size_t idx;
+                if (!out_index(u, &idx)) continue;
+                const int m = u / C4, c4 = u - m * C4;
+                const int co = n0 + c4 * 4;
+                f32x4 v = *(const f32x4*)(ob + m * RS + c4 * 16);
+                if (a.ksplit > 1) {   // raw partial sums; the finish kernel applies the epilogue
+                    *(f32x4*)(a.slab + slab_off + idx) = v;
+                    continue;
+                }
+                if (a.bias) v += *(const f32x4*)(a.bias + co);
+                v *= a.alpha;
+                if (a.mask) {
+                    const f32x4 mk = *(const f32x4*)(a.mask + idx);
+                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                }
+                if (a.skip) v += *(const f32x4*)(a.skip + idx);
+                if (a.act == PESR_ACT_RELU) {
+                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                } else if (a.act == PESR_ACT_LRELU) {
+                    v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+                    v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+                }
+                if (bn_on) { st1 += v; st2 += v * v; }
+                *(f32x4*)(a.y + idx) = v;
+            }
         }
         if (bn_on) {
             __syncthreads();                                 // every thread is done with the accumulator tile in `ob`

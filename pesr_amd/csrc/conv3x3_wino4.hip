@@ -68,7 +68,10 @@ constexpr int W4_BN = 64, W4_MG = 9;
 // or 0 = a.TXT at run time.  With it the (ky, xi) part of a fragment read's address is an immediate of the ds_read and "this
 // chunk's V buffer" is one add per fragment offset and chunk: the loop loses its per-read address add (87 -> 38 v_add_u32 per
 // chunk and wave; G body forward 185.1 -> 182.6 us, 227.7 -> 229.4 patches/s).
-template <bool DENSE, int TXTC>
+// BNF: the instantiation carries the BatchNorm-sums epilogue (common.h BnEpi; the Discriminator's layers).  false: none of that code -
+// the Generator's / VGG's kernels keep the register allocation they had (with it, the 18 prefetched z values of mode 2 cost the
+// 48-wide instantiation 52 bytes of scratch in its epilogue).
+template <bool DENSE, int TXTC, bool BNF = false>
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a, const BnEpi bn_arg) {
     (void)bn_arg;                                          // BatchNorm sums from the epilogue (common.h BnEpi): read through pesr_bn_epi() behind the main loop
     static_assert(!(DENSE && TXTC), "the constant-row-length form is for the non-dense layout");
@@ -325,19 +328,52 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a, c
             *(f32x4*)slot(1, i, 0) = sm; *(f32x4*)slot(1, i, 1) = 2.0f * df;
         }
     }
-    __syncthreads();
     const size_t img_out = (size_t)img * a.H * a.W;
     const int co = n0 + cb * 16 + g * 4;
+    // output e = (m-tile i, k) of this lane -> (inside the image, element offset of its four channels)
+    auto out_index = [&](const int i, const int k, size_t* idx) -> bool {
+        const int m = i * 16 + r;
+        const int trow = m / TXTv, txt = m - trow * TXTv;
+        int oy = gy0 + trow;
+        const int ox = 4 * (gt0 + txt) + 2 * xt + k;
+        bool ok = oy < a.H && ox < a.W;
+        if (a.stack) {                                  // virtual row -> row of the [N * H] row space; separator rows are dropped
+            const int im = oy / a.stack, yy = oy - im * a.stack;
+            ok = im < a.stack_n && yy < a.H && ox < a.W;
+            oy = im * a.H + yy;
+        }
+        if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
+            const int C = a.Cout >> 2;
+            const int sub = co / C, cc = co - sub * C;
+            *idx = (((size_t)img * (2 * a.H) + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1)) * C + cc;
+        } else {
+            *idx = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
+        }
+        if (!ok) *idx = 0;
+        return ok;
+    };
+    __syncthreads();
+    // BatchNorm mode 2 reads z at every output element: all 18 loads of a lane are issued here, right behind the exchange barrier (in
+    // front of it the barrier's vmcnt(0) would wait for them with nothing to overlap - conv3x3_mfma.hip measured both)
+    const BnEpi* const bn = pesr_bn_epi((unsigned)((sizeof(Wino4Args) + 7) & ~(size_t)7));
+    const int bn_mode = (BNF && a.ksplit == 1) ? bn->mode : 0;
+    f32x4 zall[BNF ? 2 * W4_MG : 1];
+    if (BNF && bn_mode == 2) {
+        const float* const bn_z = bn->z;
+#pragma unroll
+        for (int e = 0; e < 2 * W4_MG; ++e) {
+            size_t idx;
+            out_index(e >> 1, e & 1, &idx);
+            zall[e] = *(const f32x4*)(bn_z + idx);           // (an out-of-image element reads offset 0: valid memory, value unused)
+        }
+    }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias && a.ksplit == 1) bias4 = *(const f32x4*)(a.bias + co);
-    const BnEpi* const bn = pesr_bn_epi((unsigned)((sizeof(Wino4Args) + 7) & ~(size_t)7));
-    const int bn_mode = a.ksplit == 1 ? bn->mode : 0;
-    const bool bn_on = bn_mode != 0;
-    const float* const bn_z = bn->z;
-    const float bn_slope = bn->slope;
+    const bool bn_on = BNF && bn_mode != 0;
+    const float bn_slope = BNF ? bn->slope : 0.f;
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
     f32x4 bmu = st1, bis = st1, bga = st1, bbe = st1;
-    if (bn_mode == 2) {
+    if (BNF && bn_mode == 2) {
         bmu = *(const f32x4*)(bn->mi + co); bis = *(const f32x4*)(bn->mi + a.Cout + co);
         bga = *(const f32x4*)(bn->gamma + co); bbe = *(const f32x4*)(bn->beta + co);
     }
@@ -351,36 +387,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a, c
     // profiles/r04_ab_notes.txt)
 #pragma unroll
     for (int ib = 0; ib < W4_MG; ib += 3) {
-        f32x4 v[6], mkv[6], skv[6], zv[6];
+        f32x4 v[6], mkv[6], skv[6];
         size_t idx[6];
         bool ok[6];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
             const int i = ib + (e >> 1), k = e & 1;
-            const int m = i * 16 + r;
-            const int trow = m / TXTv, txt = m - trow * TXTv;
-            int oy = gy0 + trow;
-            const int ox = 4 * (gt0 + txt) + 2 * xt + k;
-            ok[e] = oy < a.H && ox < a.W;
-            if (a.stack) {                                  // virtual row -> row of the [N * H] row space; separator rows are dropped
-                const int im = oy / a.stack, yy = oy - im * a.stack;
-                ok[e] = im < a.stack_n && yy < a.H && ox < a.W;
-                oy = im * a.H + yy;
-            }
+            ok[e] = out_index(i, k, &idx[e]);
             // same order of additions as a sequential y = (xi 0..2 part) + (xi 3..5 part)
             v[e] = xt == 0 ? keep[i][k] + *(const f32x4*)slot(1, i, k) : *(const f32x4*)slot(0, i, k) + keep[i][k];
-            if (a.ps) {   // packed channel co = (2*si+sj)*C + c  ->  out[n][2*oy+si][2*ox+sj][c]
-                const int C = a.Cout >> 2;
-                const int sub = co / C, cc = co - sub * C;
-                idx[e] = (((size_t)img * (2 * a.H) + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1)) * C + cc;
-            } else {
-                idx[e] = (img_out + (size_t)oy * a.W + ox) * a.Cout + co;
-            }
-            if (!ok[e]) idx[e] = 0;
             if (a.ksplit == 1) {
                 if (a.mask) mkv[e] = *(const f32x4*)(a.mask + idx[e]);
                 if (a.skip) skv[e] = *(const f32x4*)(a.skip + idx[e]);
-                if (bn_mode == 2) zv[e] = *(const f32x4*)(bn_z + idx[e]);
             }
         }
 #pragma unroll
@@ -406,7 +424,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const Wino4Args a, c
             }
             if (bn_on) {
                 if (bn_mode == 2) {
-                    const f32x4 xh = (zv[e] - bmu) * bis;
+                    const f32x4 xh = (zall[BNF ? ib * 2 + e : 0] - bmu) * bis;
                     const f32x4 zz = bga * xh + bbe;
                     o.x = zz.x > 0.f ? o.x : o.x * bn_slope; o.y = zz.y > 0.f ? o.y : o.y * bn_slope;
                     o.z = zz.z > 0.f ? o.z : o.z * bn_slope; o.w = zz.w > 0.f ? o.w : o.w * bn_slope;
@@ -579,9 +597,18 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<false, 24, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid((unsigned)(p.tiles * p.ksplit));
-    if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0>), grid, dim3(512), p.lds, stream, a, bn);
+    if (bn.mode) {
+        if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0, true>), grid, dim3(512), p.lds, stream, a, bn);
+        else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12, true>), grid, dim3(512), p.lds, stream, a, bn);
+        else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24, true>), grid, dim3(512), p.lds, stream, a, bn);
+        else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0, true>), grid, dim3(512), p.lds, stream, a, bn);
+    } else if (p.dense) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, 0>), grid, dim3(512), p.lds, stream, a, bn);
     else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12>), grid, dim3(512), p.lds, stream, a, bn);
     else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24>), grid, dim3(512), p.lds, stream, a, bn);
     else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0>), grid, dim3(512), p.lds, stream, a, bn);

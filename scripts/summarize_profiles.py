@@ -11,19 +11,39 @@ def short(name):
 
 
 def trace(path, steps, out, warmup=0):
-    """steps = timed steps in the run; the launches of the `warmup` untimed steps (first in time, per group) are dropped."""
-    groups = collections.OrderedDict()
+    """steps = steps summarised; warmup = steps skipped in front of them.  Round 6: the window is cut by TIME at optimizer steps - a
+    GAN step ends with its second adam_kernel launch, so launches that start after the end of adam launch 2 * warmup and up to the end of
+    adam launch 2 * (warmup + steps) are counted; everything else (first-use weight packing, the warm-up) is dropped.  (Rounds 1 - 5
+    dropped the first warmup / (warmup + steps) of every group's launches BY COUNT: a kernel that runs only in the first step - the ~170
+    lazy pack_wino4 launches - then showed up as ~20 launches 'per step'.)  Falls back to the by-count rule when the trace has no adam
+    launches (pretrain-only or inference runs pass their own windows)."""
+    rows_ = []
+    adam_ends = []
     for r in csv.DictReader(open(path)):
         grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
         wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
-        key = (short(r["Kernel_Name"]), grid, wg)
-        groups.setdefault(key, []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        t0, t1 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        rows_.append(((short(r["Kernel_Name"]), grid, wg), t0, (t1 - t0) / 1e3))
+        if r["Kernel_Name"].startswith("adam_kernel") or r["Kernel_Name"].startswith("adam_dev_kernel"):
+            adam_ends.append(t1)
+    adam_ends.sort()
+    groups = collections.OrderedDict()
     agg = {}
-    for key, lst in groups.items():
-        lst.sort()
-        drop = len(lst) * warmup // (warmup + steps) if len(lst) >= warmup + steps else 0
-        kept = lst[drop:]
-        agg[key] = (len(kept), sum(t for _, t in kept))
+    if len(adam_ends) >= 2 * (warmup + steps):
+        lo = adam_ends[2 * warmup - 1] if warmup else 0
+        hi = adam_ends[2 * (warmup + steps) - 1]
+        for key, t0, us in rows_:
+            if lo < t0 <= hi:
+                n, s = agg.get(key, (0, 0.0))
+                agg[key] = (n + 1, s + us)
+    else:
+        for key, t0, us in rows_:
+            groups.setdefault(key, []).append((t0, us))
+        for key, lst in groups.items():
+            lst.sort()
+            drop = len(lst) * warmup // (warmup + steps) if len(lst) >= warmup + steps else 0
+            kept = lst[drop:]
+            agg[key] = (len(kept), sum(t for _, t in kept))
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
     with open(out, "w", newline="") as f:
         w = csv.writer(f)

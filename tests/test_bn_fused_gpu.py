@@ -48,7 +48,7 @@ def _packed(w, x_shape, stride, kind, mode):
 
 # (N, H, W, Cin, Cout, stride, kernel): the Discriminator's features.1 / .3 / .5 (direct stride-2 kernel: 64-, 144- and 48-pixel tiles),
 # features.2 / .4 (F(4,3)), ragged and small shapes, the direct stride-1 kernel
-FWD = [(16, 192, 192, 64, 64, 2, "direct"), (4, 96, 96, 128, 128, 2, "direct"), (16, 48, 48, 256, 256, 2, "direct"),
+FWD = [(16, 192, 192, 64, 64, 2, "direct"), (16, 96, 96, 128, 128, 2, "direct"), (16, 48, 48, 256, 256, 2, "direct"),
        (2, 37, 50, 64, 64, 2, "direct"), (16, 96, 96, 64, 128, 1, "wino4"), (16, 48, 48, 128, 256, 1, "wino4"), (3, 20, 28, 64, 128, 1, "direct"),
        (16, 40, 44, 64, 64, 1, "wino4")]
 
@@ -90,7 +90,7 @@ def test_conv_bn_forward_statistics_from_the_epilogue(N, H, W, Cin, Cout, stride
 
 
 # (N, H, W of the BatchNorm'd tensor = the next conv's input, C of it, Cout of the next conv, its stride, kernel)
-BWD = [(16, 192, 192, 64, 64, 2, "direct"), (4, 96, 96, 128, 128, 2, "direct"), (16, 48, 48, 256, 256, 2, "direct"), (16, 24, 24, 512, 512, 2, "direct"),
+BWD = [(16, 192, 192, 64, 64, 2, "direct"), (16, 96, 96, 128, 128, 2, "direct"), (16, 48, 48, 256, 256, 2, "direct"), (16, 24, 24, 512, 512, 2, "direct"),
        (2, 37, 50, 64, 64, 2, "direct"), (16, 96, 96, 64, 128, 1, "wino4"), (3, 20, 28, 128, 64, 1, "direct"), (16, 40, 44, 64, 64, 1, "wino4")]
 
 
@@ -119,8 +119,11 @@ def test_bn_backward_sums_from_the_next_convs_input_gradient_kernel(N, H, W, C, 
     dz2, dg2, db2 = ops.bn_lrelu_bwd(zg, gy, gamma.cuda(), beta.cuda(), stats)
     _close(dz.cpu(), dz2.cpu(), 1e-5, "dz vs the un-fused path"); _close(dg.cpu(), dg2.cpu(), 1e-5, "dgamma vs un-fused"); _close(db.cpu(), db2.cpu(), 1e-5, "dbeta vs un-fused")
     # g' is exactly the plain kernel's gradient times lrelu'(bn(z)) - the same bits
+    # (away from the kink: at |bn(z)| ~ 1e-7 the kernel's fused multiply-add and torch's two roundings may disagree on the sign)
     zz = gamma.cuda() * ((zg - stats[0]) * stats[1]) + beta.cuda()
-    assert torch.equal(gm, torch.where(zz > 0, gy, gy * 0.2)), "masked gradient"
+    far = zz.abs() > 1e-5
+    assert torch.equal(gm[far], torch.where(zz > 0, gy, gy * 0.2)[far]), "masked gradient"
+    assert float(far.float().mean()) > 0.999
     # accumulate form (second use of a layer inside one backward pass) and run-to-run bits
     dg3, db3 = dg.clone(), db.clone()
     ops.bn_lrelu_bwd_fused(zg, gm, part, gamma.cuda(), beta.cuda(), stats, dgamma_out=dg3, dbeta_out=db3, accumulate=True)
