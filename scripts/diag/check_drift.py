@@ -8,7 +8,7 @@ import difflib, os, re
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "..", "..", "pesr_amd", "csrc")
 FORKS = {"conv3x3_wgrad_wino4_diag.hip": "conv3x3_wgrad_wino4.hip", "conv3x3_wino4_diag.hip": "conv3x3_wino4.hip",
-         "conv3x3_wino4_stag_diag.hip": "conv3x3_wino4.hip", "conv3x3_wino4_persist.hip": "conv3x3_wino4.hip",
+         "conv3x3_wino4_stag_diag.hip": "conv3x3_wino4.hip", "conv3x3_wino4_persist.hip": "conv3x3_wino4.hip", "conv3x3_wino4_vstore_diag.hip": "conv3x3_wino4.hip",
          "conv3x3_bf16_diag.hip": "conv3x3_bf16.hip", "conv3x3_mfma_diag.hip": "conv3x3_mfma.hip", "conv3x3_wgrad_bf16_ldsdma.hip": "conv3x3_wgrad_bf16.hip", "linear_diag.hip": "linear.hip"}
 
 
