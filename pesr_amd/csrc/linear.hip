@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma_kernel(const float* __res
 #pragma unroll
     for (int b = 0; b < NB; ++b) { const int n = n0 + b * 16 + i; wok[b] = n < N; wr[b] = W + (size_t)(wok[b] ? n : 0) * K; }
     const bool xok = i < M;
+    // (Round 6: x repacked k-major - a wave's x piece of a 16-k step as ONE contiguous KiB, [K/16][16][16], by a 5.9 us pack launch -
+    // measured 84.6 us for this kernel against 83 - 85 on the plain layout: no gain; with NO x loads at all it takes ~72.  Not adopted.)
     // LU 16-k steps per trip, all their loads issued before the first MFMA (the two 64-byte halves of every 128-byte line of W
     // are then in flight together): LU * (NB + 1) KiB per wave
     constexpr int LU = 2;
@@ -167,6 +169,71 @@ __global__ __launch_bounds__(LD_BT) void linear_dgrad_kernel(const float* __rest
     for (int m = 0; m < MB; ++m)
         if (m < M) *(f32x4*)(part + ((size_t)ns * M + m) * K + k) = acc[m];
 }
+// M <= 16 (round 6): the input gradient on the matrix pipe.  One wave owns 64 consecutive k and an N slice.  Per 16 weight rows: every lane
+// loads ONE 16-byte piece of dy - row i = lane % 16, columns n + 4 g .. + 3 (g = lane / 16) - and FOUR pieces of W - row n + 4 g + t
+// (t = 0 .. 3), columns k0 + 4 i .. + 3: 16 lanes x 16 B = 256 contiguous bytes of each of four rows per load instruction.  MFMA (t, e):
+// A = dy piece element t (k-slot g stands for weight row n + 4 g + t), B = element e of W piece t (column k0 + 4 i + e), accumulator e:
+// D_e[m][i] = dx[m][k0 + 4 i + e].  A lane ends with dx[m = 4 g + jj][k0 + 4 i .. + 3] = {acc[0][jj] .. acc[3][jj]}: one 16-byte store
+// per jj.  Against the VALU form above: no 64 FMAs per 16 bytes of W (the kernel was bound by them: 105 - 110 us = 0.45 of the HBM rate,
+// W alone streams in ~60), and an N split of 4 instead of 16 (19 MB of partial slabs instead of 75).
+__global__ __launch_bounds__(256) void linear_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                                float* __restrict__ part, int M, int N, long K, int nchunk, long ktiles) {
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const long kt = wave % ktiles;
+    const int ns = (int)(wave / ktiles);
+    const int n0 = ns * nchunk;
+    if (n0 >= N) return;
+    int n1 = n0 + nchunk; if (n1 > N) n1 = N;
+    const long k0 = kt * 64;
+    const long kl = k0 + 4 * i;                              // this lane's four columns
+    const bool kok = kl < K;                                 // (K % 4 == 0)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = zero;
+    const float* const dyr = dy + (size_t)(i < M ? i : 0) * N;
+    const bool mok = i < M;
+    constexpr int U = 2;                                     // 16-row groups per trip: 8 KiB of W in flight per wave
+    int n = n0;
+    for (; n + 16 * U <= n1; n += 16 * U) {
+        f32x4 d[U], w[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int nb = n + 16 * u + 4 * g;
+            d[u] = mok ? *(const f32x4*)(dyr + nb) : zero;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[u][t] = kok ? __builtin_nontemporal_load((const f32x4*)(W + (size_t)(nb + t) * K + kl)) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u][t], w[u][t][e], acc[e], 0, 0, 0);
+    }
+    for (; n < n1; n += 16) {                                // ragged end of the slice: rows past n1 contribute zeros
+        const int nb = n + 4 * g;
+        f32x4 d = zero, w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool rok = nb + t < n1;
+            d[t] = (mok && rok) ? dyr[nb + t] : 0.f;
+            w[t] = (kok && rok) ? *(const f32x4*)(W + (size_t)(nb + t) * K + kl) : zero;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[t], w[t][e], acc[e], 0, 0, 0);
+    }
+    if (kok) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = 4 * g + jj;
+            if (m < M) *(f32x4*)(part + ((size_t)ns * M + m) * K + kl) = (f32x4){acc[0][jj], acc[1][jj], acc[2][jj], acc[3][jj]};
+        }
+    }
+}
 // finalize: dx = sum over N-slices; the LeakyReLU derivative of the layer below is applied by its own backward
 __global__ void linear_dgrad_final_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dx, long MK4, int nsplit) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < MK4; e += (long)gridDim.x * blockDim.x) {
@@ -229,7 +296,13 @@ static void lin_plan(int M, int N, long K, LinPlan* p) {
     constexpr int LD_NS_TARGET = 1024, LD_NS_MAX = 16;    // (the 16 x 4 point of the sweep in profiles/r03_linear_sweep.txt)
     int ns = (int)((LD_NS_TARGET * 256 / LD_BT + kb - 1) / kb); if (ns < 1) ns = 1; if (ns > N) ns = N; if (ns > LD_NS_MAX) ns = LD_NS_MAX;
     p->nchunk = (N + ns - 1) / ns; p->nsplit = (N + p->nchunk - 1) / p->nchunk;
-    (void)M;
+    if (M <= 16) {
+        // MFMA input gradient: waves = ceil(K / 64) * nsplit ~ 4608 (18 per CU), slices in multiples of 32 rows (the loop's trip)
+        const long ktiles = (K + 63) / 64;
+        int ns2 = (int)((4608 + ktiles - 1) / ktiles); if (ns2 < 1) ns2 = 1; if (ns2 > 16) ns2 = 16;
+        int nc = ((N + ns2 - 1) / ns2 + 31) / 32 * 32; if (nc < 32) nc = 32;
+        p->nchunk = nc; p->nsplit = (N + nc - 1) / nc;
+    }
 }
 }  // namespace
 
@@ -260,7 +333,10 @@ int pesr_linear_dgrad_launch(const float* dy, const float* W, float* dx, int M, 
     LinPlan p; lin_plan(M, N, K, &p);
     if (!ws || ws_bytes < (size_t)p.nsplit * M * K * sizeof(float)) return PESR_EWORKSPACE;
     const dim3 grid((unsigned)((K / 4 + LD_BT - 1) / LD_BT), (unsigned)p.nsplit);
-    if (M <= 16) hipLaunchKernelGGL(linear_dgrad_kernel<16>, grid, dim3(LD_BT), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
+    if (M <= 16 && N % 4 == 0) {
+        const long ktiles = (K + 63) / 64, waves = ktiles * p.nsplit;
+        hipLaunchKernelGGL(linear_dgrad_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk, ktiles);
+    } else if (M <= 16) hipLaunchKernelGGL(linear_dgrad_kernel<16>, grid, dim3(LD_BT), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(LD_BT), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
     const long MK4 = (long)M * K / 4;
     hipLaunchKernelGGL(linear_dgrad_final_kernel, dim3((unsigned)((MK4 + 255) / 256 < 4096 ? (MK4 + 255) / 256 : 4096)), dim3(256), 0, stream,

@@ -192,7 +192,7 @@ def test_conv_rgb_bn_lrelu_fused_statistics(N, H, W, C, nchw):
     assert torch.equal(y, y3) and torch.equal(stats, stats3) and torch.equal(z, z3)
 
 
-@pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (3, 70, 1000), (16, 1024, 73728), (70, 96, 2048)])
+@pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (3, 70, 1000), (16, 1024, 73728), (70, 96, 2048), (5, 100, 1000), (16, 96, 4100)])
 def test_linear(M, N, K):
     """(70 rows: more than one 32-row kernel call - a per-GPU batch of 64 must not abort in D's classifier.)"""
     from pesr_amd import ops
