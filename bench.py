@@ -31,7 +31,7 @@ GFLOP_PER_PATCH = {"gan": 844.10, "pretrain": 694.69}   # SURVEY.md 8(d), necess
 K1_GFLOP = 2.0 * 16 * 48 * 48 * 256 * 256 * 9 / 1e9     # body conv 256->256 @48x48, batch 16: 43.487 GFLOP per launch
 
 
-PMC_SUMMARIES = ("r05_k1_pmc_summary.csv", "r04_k1_pmc_summary.csv", "r04_bf16_pmc_summary.csv", "r03_k1_pmc_summary.csv", "r03_bf16_pmc_summary.csv")     # newest first
+PMC_SUMMARIES = ("r06_k1_pmc_summary.csv", "r05_k1_pmc_summary.csv", "r04_k1_pmc_summary.csv", "r04_bf16_pmc_summary.csv", "r03_k1_pmc_summary.csv", "r03_bf16_pmc_summary.csv")     # newest first
 # kernel name -> the source file whose hash must match the summary's side-car (scripts/summarize_profiles.py writes <summary>.meta.json)
 KERNEL_SOURCE = {"conv3x3_bf16x3_kernel": "conv3x3_bf16x3.hip", "conv3x3_wino4_kernel": "conv3x3_wino4.hip", "conv3x3_wino_kernel": "conv3x3_wino.hip", "conv3x3_mfma_kernel": "conv3x3_mfma.hip",
                  "conv3x3_wgrad_wino4p_kernel": "conv3x3_wgrad_wino4.hip", "conv3x3_wgrad_wino4x_kernel": "conv3x3_wgrad_wino4.hip", "conv3x3_wgrad_wino4_kernel": "conv3x3_wgrad_wino4.hip",

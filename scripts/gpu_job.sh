@@ -8,6 +8,7 @@
 #   trace                       single-stream kernel trace condensed per (kernel, grid) -> kernel_trace_by_grid.csv
 #   pmc <name> <script.py>      SQ / GRBM / FETCH_SIZE / WRITE_SIZE in four SEPARATE passes over one script -> <name>_pmc_summary.csv
 #   hbm <name> <script.py>      FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE only (HBM-bound kernels)
+#   tcc <name> <script.py>      TCC_EA0_RDREQ / _32B / TCC_HIT / TCC_MISS (+ TCC_REQ / READ / WRITE in a second pass) -> <name>_tcc_summary.csv
 #   py <name> <script.py> [..]  any measurement script, output -> <name>.txt
 # TAG=<dir> selects the output directory under gpurun_out/ (default: job).
 export TMPDIR=/tmp; export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -33,6 +34,11 @@ case $job in
           for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/hbm_$c -o run -- python3 $R/$s > $O/hbm_$c.log 2>&1; done
           cd $R; python3 scripts/summarize_profiles.py pmc $O/${n}_pmc_summary.csv $(find $O/hbm_* -name "*counter_collection.csv"); rm -rf $O/hbm_*/
           grep -v "at::native" $O/${n}_pmc_summary.csv | head -80 ;;
+  tcc)    n=$1; s=$2; cd /tmp      # L2 <-> fabric request counters (one pass: four TCC slots): read requests, the 32-byte ones among them, L2 hits / misses
+          timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/tcc_a -o run -- python3 $R/$s > $O/tcc_a.log 2>&1
+          timeout 300 rocprofv3 --pmc TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum --output-format csv -d $O/tcc_b -o run -- python3 $R/$s > $O/tcc_b.log 2>&1
+          cd $R; python3 scripts/summarize_profiles.py pmc $O/${n}_tcc_summary.csv $(find $O/tcc_* -name "*counter_collection.csv"); rm -rf $O/tcc_*/
+          grep -v "at::native" $O/${n}_tcc_summary.csv | head -40; tail -3 $O/tcc_a.log ;;
   py)     n=$1; s=$2; shift 2; cd $R; timeout 900 python3 $s "$@" 2>&1 | grep -v amdgpu.ids > $O/$n.txt; tail -60 $O/$n.txt ;;
   *)      echo "unknown job $job"; exit 2 ;;
 esac
