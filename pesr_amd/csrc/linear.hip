@@ -105,6 +105,78 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma_kernel(const float* __res
             if (m < M && n < N) part[((size_t)ks * M + m) * N + n] = acc[b][jj];
         }
 }
+// Round 6: the same product with W fetched in the pattern that streams fastest.  The kernel above takes W as 16 rows x 64 B per load
+// instruction (the MFMA's B fragment: lane % 16 = row) - the fabric then sees a mix of 64- and 128-byte requests (profiles/
+// r06_linear_tcc_summary.csv: 3.57 M requests for 2.36 M lines, none of 32 B) and the stream runs at 3.6 TB/s, while the input gradient's
+// 4 rows x 256 B per instruction produce 128-byte requests only and reach 4.9.  Here a wave fetches its 64-row x 64-k tile of W as sixteen
+// 4 x 256 B loads, passes it through a wave-private 16 KiB LDS image (16-byte chunks XOR-swizzled by the row: the writes fill whole rows,
+// the 8 lanes of a fragment-read cycle hit 8 different chunks) and reads the B fragments from there; x as before.  No barrier: the
+// image belongs to one wave, whose LDS operations execute in order.
+template <int NB>
+__global__ __launch_bounds__(256) void linear_fwd_mfma_lds_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                  float* __restrict__ part, int M, int N, long K, int ksplit, long kchunk) {
+    extern __shared__ __attribute__((aligned(16))) char lin_smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + wv;
+    const int i = lane & 15, g = lane >> 4;
+    const int ngroups = (N + 16 * NB - 1) / (16 * NB);
+    const int ng = (int)(wave % ngroups), ks = (int)(wave / ngroups);
+    if (ks >= ksplit) return;
+    const int n0 = ng * 16 * NB;
+    const long k0 = ks * kchunk;
+    long k1 = k0 + kchunk; if (k1 > K) k1 = K;
+    char* const tile = lin_smem + wv * (16 * NB * 256);     // [16 NB rows][16 chunks of 16 B], chunk c of row r at slot c ^ (r & 15)
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float* const xr = x + (size_t)(i < M ? i : 0) * K;
+    const bool xok = i < M;
+    const bool rows_in = n0 + 16 * NB <= N;
+    for (long k = k0; k < k1; k += 64) {
+        const bool all_in = rows_in && k + 64 <= k1;          // wave-uniform: the whole 64 x 64 tile and the x pieces exist
+        f32x4 w[4 * NB], a[4];
+        if (all_in) {
+#pragma unroll
+            for (int j = 0; j < 4 * NB; ++j) w[j] = __builtin_nontemporal_load((const f32x4*)(W + (size_t)(n0 + 4 * j + g) * K + k + 4 * i));
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) a[s_] = xok ? *(const f32x4*)(xr + k + 16 * s_ + 4 * g) : zero;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4 * NB; ++j) {
+                const int n = n0 + 4 * j + g;
+                w[j] = (n < N && k + 4 * i < k1) ? *(const f32x4*)(W + (size_t)n * K + k + 4 * i) : zero;
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) a[s_] = (xok && k + 16 * s_ + 4 * g < k1) ? *(const f32x4*)(xr + k + 16 * s_ + 4 * g) : zero;
+        }
+#pragma unroll
+        for (int j = 0; j < 4 * NB; ++j) {
+            const int r = 4 * j + g;
+            *(f32x4*)(tile + r * 256 + ((i ^ (r & 15)) << 4)) = w[j];
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            f32x4 bf[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int r = 16 * b + i;                       // (r & 15) == i
+                bf[b] = *(const f32x4*)(tile + r * 256 + (((4 * s_ + g) ^ i) << 4));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_][e], bf[b][e], acc[b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = 4 * g + jj, n = n0 + b * 16 + i;
+            if (m < M && n < N) part[((size_t)ks * M + m) * N + n] = acc[b][jj];
+        }
+}
 __global__ void linear_fwd_final_kernel(const float* __restrict__ part, const float* __restrict__ b, float* __restrict__ y, int M,
                                         int N, int ksplit, int act, float slope) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,18 +320,30 @@ __global__ void linear_dgrad_final_kernel(const f32x4* __restrict__ part, f32x4*
 template <int MB>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            float* __restrict__ dW, int M, int N, long K, int nchunk, int accumulate) {
+    // Round 6: the block's dy tile [M][nchunk <= 64] goes to LDS once (transposed to [n][MB]: a row of it is the MB multipliers of one
+    // output row, read as broadcast ds_read_b128s) - as wave-uniform global reads inside the n loop every output row waited for 16
+    // dependent scalar loads before its store could issue.
+    __shared__ __attribute__((aligned(16))) float dyt[64 * MB];
     const long k = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const int n0 = blockIdx.y * nchunk;
     int n1 = n0 + nchunk; if (n1 > N) n1 = N;
+    for (int e = threadIdx.x; e < 64 * MB; e += 256) {
+        const int nn = e / MB, m = e - nn * MB;
+        dyt[e] = (m < M && n0 + nn < n1) ? dy[(size_t)m * N + n0 + nn] : 0.f;
+    }
+    __syncthreads();
     if (k >= K) return;
     f32x4 xv[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) xv[m] = m < M ? *(const f32x4*)(x + (size_t)m * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int n = n0; n < n1; ++n) {
+        const f32x4* const d4 = (const f32x4*)(dyt + (n - n0) * MB);
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
-            if (m < M) s += xv[m] * dy[(size_t)m * N + n];
+        for (int q = 0; q < MB / 4; ++q) {      // rows m >= M hold zeros in both operands: same order of additions as before
+            const f32x4 d = d4[q];
+            s += xv[4 * q] * d.x; s += xv[4 * q + 1] * d.y; s += xv[4 * q + 2] * d.z; s += xv[4 * q + 3] * d.w;
+        }
         // (non-temporal: the 302 MB stream is written once and not re-read by this kernel - 88 -> 78 us)
         if (accumulate) s += __builtin_nontemporal_load((const f32x4*)(dW + (size_t)n * K + k));   // dW += ... : a second use of the layer in one backward
         __builtin_nontemporal_store(s, (f32x4*)(dW + (size_t)n * K + k));
@@ -281,7 +365,7 @@ static void lin_plan(int M, int N, long K, LinPlan* p) {
     if (M <= 16) {
         const int ngroups = (N + 63) / 64;
         int ks = 2048 / ngroups; if (ks < 1) ks = 1;
-        long kc = ((K + ks - 1) / ks + 15) / 16 * 16;
+        long kc = ((K + ks - 1) / ks + 63) / 64 * 64;         // (multiples of 64: a trip of the LDS-staged kernel)
         if (kc < 64) kc = 64;
         p->kchunk = kc; p->ksplit = (int)((K + kc - 1) / kc);
     } else {
@@ -320,7 +404,12 @@ int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float
     if (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float)) return PESR_EWORKSPACE;
     if (M <= 16) {
         const long waves = (long)((N + 63) / 64) * p.ksplit;
-        hipLaunchKernelGGL(linear_fwd_mfma_kernel<4>, dim3((int)((waves + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+        if (N >= 64) {   // W through the wave-private LDS image (whole 128-byte lines per fetch); tiny N: the direct form
+            static PesrDeviceOnce attr_once;
+            attr_once([&] { (void)hipFuncSetAttribute((const void*)linear_fwd_mfma_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); });
+            hipLaunchKernelGGL(linear_fwd_mfma_lds_kernel<4>, dim3((int)((waves + 3) / 4)), dim3(256), 64 * 1024, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+        } else
+            hipLaunchKernelGGL(linear_fwd_mfma_kernel<4>, dim3((int)((waves + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
     } else
         hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), dim3((int)(((long)((N + 1) / 2) * p.ksplit + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
     hipLaunchKernelGGL(linear_fwd_final_kernel, dim3((M * N + 63) / 64), dim3(64), 0, stream, (const float*)ws, b, y, M, N, p.ksplit, act, slope);
