@@ -654,7 +654,7 @@ def side_measurements(args, trainer, G, batches, device):
                         "issued_frac_of_mfma_peak": round(fl5["issued"] / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                         "hbm_bound_kernels": hbm,
                         "hbm_note": "HIP events on the launch stream around every launch of these ops inside the timed batches; bytes are "
-                                    "ALGORITHMIC (SURVEY Appendix A.4 'min MB'), PMC traffic for the same kernels: profiles/r05_hbm_pmc_summary.csv (r04_ where round 5 did not re-measure)"}
+                                    "ALGORITHMIC (SURVEY Appendix A.4 'min MB'), PMC traffic for the same kernels: profiles/r06_hbm_pmc_summary.csv, request counters profiles/r06_hbm_tcc_summary.csv"}
     return side
 
 
