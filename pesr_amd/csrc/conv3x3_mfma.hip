@@ -588,6 +588,81 @@ __global__ void conv_splitk_finish4_kernel(const f32x4* __restrict__ slab, const
     }
 }
 
+// The split-K finish WITH the BatchNorm sums of common.h BnEpi (round 6): the layers whose conv kernel cannot leave them because its
+// workgroups hold partial sums only (the Discriminator's features.6 / .7 forward, the input gradients of features.4 / .6).  PESR_BN_FINISH_ROWS
+// workgroups walk the tensor with a stride that is a multiple of the channel groups, so a thread keeps its four channels; one row of
+// [2][C] per workgroup, fp32 per thread, double across the threads of a workgroup in a fixed order.  (No bias / mask / skip / activation
+// in mode 2; mode 1 sums what it stores.)
+constexpr int PESR_BN_FINISH_ROWS = 256;
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_splitk_finish4_bn_kernel(const f32x4* __restrict__ slab, const float* __restrict__ bias, f32x4* __restrict__ y,
+                                                                      long total4, int C, int ksplit, float alpha, const BnEpi bn) {
+    const int C4 = C >> 2;
+    const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);            // (gridDim.x * 256) % C4 == 0: fixed over the walk
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1, bmu = st1, bis = st1, bga = st1, bbe = st1, b4 = st1;
+    if (MODE == 2) {
+        bmu = *(const f32x4*)(bn.mi + c4 * 4); bis = *(const f32x4*)(bn.mi + C + c4 * 4);
+        bga = *(const f32x4*)(bn.gamma + c4 * 4); bbe = *(const f32x4*)(bn.beta + c4 * 4);
+    }
+    if (bias) b4 = *(const f32x4*)(bias + c4 * 4);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
+        f32x4 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < ksplit) p[k] = slab[(size_t)k * total4 + e];
+        f32x4 v = p[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < ksplit) v += p[k];
+        v = (v + b4) * alpha;
+        if (MODE == 2) {
+            const f32x4 xh = (((const f32x4*)bn.z)[e] - bmu) * bis;
+            const f32x4 zz = bga * xh + bbe;
+            v.x = zz.x > 0.f ? v.x : v.x * bn.slope; v.y = zz.y > 0.f ? v.y : v.y * bn.slope;
+            v.z = zz.z > 0.f ? v.z : v.z * bn.slope; v.w = zz.w > 0.f ? v.w : v.w * bn.slope;
+            st1 += v; st2 += v * xh;
+        } else {
+            st1 += v; st2 += v * v;
+        }
+        y[e] = v;
+    }
+    __shared__ f32x4 red[2][256];
+    red[0][threadIdx.x] = st1; red[1][threadIdx.x] = st2;
+    __syncthreads();
+    // threads t, t + C4', ... hold the same channels (C4' = the channel groups one workgroup covers: min(C4, 256))
+    const int cw = C4 < 256 ? C4 : 256;
+    if (threadIdx.x < cw) {
+        f64x4 d1 = {0.0, 0.0, 0.0, 0.0}, d2 = {0.0, 0.0, 0.0, 0.0};
+        for (int k = threadIdx.x; k < 256; k += cw) {
+            d1 += __builtin_convertvector(red[0][k], f64x4);
+            d2 += __builtin_convertvector(red[1][k], f64x4);
+        }
+        float* const pr = bn.part + (size_t)blockIdx.x * 2 * C + c4 * 4;
+        *(f32x4*)pr = __builtin_convertvector(d1, f32x4);
+        *(f32x4*)(pr + C) = __builtin_convertvector(d2, f32x4);
+    }
+}
+
+// rows the finish kernel above leaves (0: the shape is not covered): one per workgroup
+long pesr_conv_splitk_finish_bn_rows(int C, int ksplit) {
+    const int C4 = C >> 2;
+    if (C % 4 || ksplit > 8 || C4 < 1 || (C4 < 256 ? 256 % C4 : C4 % 256)) return 0;
+    return PESR_BN_FINISH_ROWS;
+}
+
+int pesr_conv_splitk_finish_bn_launch(const float* slab, const float* bias, float* y, long total, int C, int ksplit, float alpha, const BnEpi& bn,
+                                      hipStream_t stream) {
+    if (!pesr_conv_splitk_finish_bn_rows(C, ksplit) || !bn.part) return PESR_EINVAL;
+    const long total4 = total / 4;
+    if (bn.mode == 2)
+        hipLaunchKernelGGL(conv_splitk_finish4_bn_kernel<2>, dim3(PESR_BN_FINISH_ROWS), dim3(256), 0, stream, (const f32x4*)slab, bias, (f32x4*)y, total4, C, ksplit,
+                           alpha, bn);
+    else
+        hipLaunchKernelGGL(conv_splitk_finish4_bn_kernel<1>, dim3(PESR_BN_FINISH_ROWS), dim3(256), 0, stream, (const f32x4*)slab, bias, (f32x4*)y, total4, C, ksplit,
+                           alpha, bn);
+    return pesr_launch_status();
+}
+
 int pesr_conv_splitk_finish_launch(const float* slab, const float* bias, const float* skip, const float* mask, float* y, long total,
                                    int C, int ksplit, float alpha, int act, float slope, hipStream_t stream) {
     if (C % 4 == 0 && ksplit <= 8) {
@@ -685,12 +760,15 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int t
     const int rc = prep_cfg<WAVES_M, WAVES_N, WM, WN, S, HL>(a, hext, wext, target_wgs, &lds, &mode, &grid);
     if (rc) return rc;
     // rows of BatchNorm partial sums the epilogue can leave: one per pixel tile (not with split-K: the finish kernel sums slabs)
-    a.bn_rows = (a.ksplit == 1 && a.cout_store % 4 == 0 && NT % (WAVES_N * WN * 4) == 0 && !a.ps) ? (long)a.N * a.tiles_y * a.tiles_x : 0;
+    // (with split-K: from the finish kernel, which sums the slabs - one row per finish workgroup)
+    a.bn_rows = (a.cout_store % 4 == 0 && NT % (WAVES_N * WN * 4) == 0 && !a.ps)
+                    ? (a.ksplit == 1 ? (long)a.N * a.tiles_y * a.tiles_x : pesr_conv_splitk_finish_bn_rows(a.cout_store, a.ksplit)) : 0;
     if (a.dry) return PESR_OK;
     if (a.bn_mode && (a.bn_rows == 0 || a.bn_row0 + a.bn_rows > a.bn_cap || !g_bn_epi.part)) return PESR_EINVAL;
     const size_t out_bytes = (size_t)a.N * a.OH * a.OW * a.cout_store * sizeof(float);
     const float* bias = a.bias; const float* skip = a.skip; const float* mask = a.mask;
-    const BnEpi a_bn = g_bn_epi;
+    BnEpi a_bn = g_bn_epi;
+    if (a.ksplit > 1) a_bn.mode = 0;              // the conv kernel stores raw partial sums; the finish kernel does the BatchNorm part
 #define PESR_LAUNCH_MODE(M_)                                                                              \
     {                                                                                                      \
         auto kern = conv3x3_mfma_kernel<WAVES_M, WAVES_N, WM, WN, S, HL, M_>;                              \
@@ -702,6 +780,11 @@ static int launch_cfg(ConvArgs& a, int hext, int wext, hipStream_t stream, int t
     }
     if (mode == 2) PESR_LAUNCH_MODE(2) else if (mode == 1) PESR_LAUNCH_MODE(1) else PESR_LAUNCH_MODE(0)
 #undef PESR_LAUNCH_MODE
+    if (a.ksplit > 1 && g_bn_epi.mode) {
+        if (skip || mask || a.act != PESR_ACT_NONE) return PESR_EINVAL;
+        return pesr_conv_splitk_finish_bn_launch((const float*)a.slab, bias, a.y, (long)(out_bytes / sizeof(float)), a.cout_store, a.ksplit, a.alpha,
+                                                 g_bn_epi, stream);
+    }
     if (a.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)a.slab, bias, skip, mask, a.y, (long)(out_bytes / sizeof(float)), a.cout_store,
                                               a.ksplit, a.alpha, a.act, a.slope, stream);

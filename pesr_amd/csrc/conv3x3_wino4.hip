@@ -566,8 +566,9 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     W4Plan p;
     if (fuse) fuse->rows_out = 0;
     if (!w4_plan(N, H, W, Cin, Cout, (ws != nullptr || (fuse && fuse->dry)) && !ps, (fuse && fuse->dry) ? (size_t)-1 : ws_bytes, !ps && !ps_in, &p)) return PESR_EINVAL;
-    // BatchNorm sums from the epilogue: one row per pixel tile; not with split-K (the finish kernel sums the slabs) or a shuffled store
-    const long bn_rows = (p.ksplit == 1 && !ps) ? p.tiles / p.n_tiles : 0;
+    // BatchNorm sums: one row per pixel tile from the epilogue; with split-K from the finish kernel that sums the slabs (one row per finish
+    // workgroup); not with a shuffled store
+    const long bn_rows = ps ? 0 : (p.ksplit == 1 ? p.tiles / p.n_tiles : pesr_conv_splitk_finish_bn_rows(Cout, p.ksplit));
     if (fuse) {
         fuse->rows_out = bn_rows;
         if (fuse->dry) return PESR_OK;
@@ -586,10 +587,11 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     a.ksplit = p.ksplit; a.chunks_per_split = p.chunks_per_split; a.slab = (float*)ws;
     a.stack = p.stack; a.stack_n = N; a.v_row = p.v_row;
     if (p.stack) a.N = 1;
-    BnEpi bn{};
+    BnEpi bn{}, bn_fin{};
     if (fuse && fuse->mode) {
         bn.mode = fuse->mode; bn.part = fuse->part; bn.z = fuse->z; bn.mi = fuse->mean_invstd; bn.gamma = fuse->gamma;
         bn.beta = fuse->beta; bn.slope = fuse->slope;
+        if (p.ksplit > 1) { bn_fin = bn; bn = BnEpi{}; }      // the conv kernel stores raw partial sums: the finish kernel does the BatchNorm part
     }
     static PesrDeviceOnce attr_once;
     attr_once([&] {
@@ -612,6 +614,8 @@ int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias
     else if (p.TXT == 12) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 12>), grid, dim3(512), p.lds, stream, a, bn);
     else if (p.TXT == 24) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 24>), grid, dim3(512), p.lds, stream, a, bn);
     else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, 0>), grid, dim3(512), p.lds, stream, a, bn);
+    if (p.ksplit > 1 && bn_fin.mode)
+        return pesr_conv_splitk_finish_bn_launch((const float*)ws, bias, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, bn_fin, stream);
     if (p.ksplit > 1)
         return pesr_conv_splitk_finish_launch((const float*)ws, bias, skip, mask, y, (long)N * H * W * Cout, Cout, p.ksplit, alpha, act,
                                               slope, stream);

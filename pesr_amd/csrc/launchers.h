@@ -142,6 +142,10 @@ int pesr_pack_conv3x3_wino4_launch(const float* w, float* out, int O, int I, int
 int pesr_conv3x3_wino4_launch(const float* x, const float* wp, const float* bias, const float* skip, const float* mask, float* y,
                               int N, int H, int W, int Cin, int Cout, float alpha, int act, float slope, int ps, int ps_in,
                               void* ws, size_t ws_bytes, hipStream_t stream, PesrBnFuseArgs* fuse = nullptr);
+struct BnEpi;
+long pesr_conv_splitk_finish_bn_rows(int C, int ksplit);
+int pesr_conv_splitk_finish_bn_launch(const float* slab, const float* bias, float* y, long total, int C, int ksplit, float alpha, const BnEpi& bn,
+                                      hipStream_t stream);
 int pesr_conv_splitk_finish_launch(const float* slab, const float* bias, const float* skip, const float* mask, float* y, long total,
                                    int C, int ksplit, float alpha, int act, float slope, hipStream_t stream);
 int pesr_conv_rgb_in_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int act,

@@ -50,7 +50,9 @@ def _packed(w, x_shape, stride, kind, mode):
 # features.2 / .4 (F(4,3)), ragged and small shapes, the direct stride-1 kernel
 FWD = [(16, 192, 192, 64, 64, 2, "direct"), (16, 96, 96, 128, 128, 2, "direct"), (16, 48, 48, 256, 256, 2, "direct"),
        (2, 37, 50, 64, 64, 2, "direct"), (16, 96, 96, 64, 128, 1, "wino4"), (16, 48, 48, 128, 256, 1, "wino4"), (3, 20, 28, 64, 128, 1, "direct"),
-       (16, 40, 44, 64, 64, 1, "wino4")]
+       (16, 40, 44, 64, 64, 1, "wino4"),
+       # split-K layers (features.7 / .6): the sums come from the finish kernel that adds the slabs
+       (16, 24, 24, 512, 512, 2, "direct"), (16, 24, 24, 256, 512, 1, "wino4")]
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,stride,kind", FWD)
@@ -91,7 +93,9 @@ def test_conv_bn_forward_statistics_from_the_epilogue(N, H, W, Cin, Cout, stride
 
 # (N, H, W of the BatchNorm'd tensor = the next conv's input, C of it, Cout of the next conv, its stride, kernel)
 BWD = [(16, 192, 192, 64, 64, 2, "direct"), (16, 96, 96, 128, 128, 2, "direct"), (16, 48, 48, 256, 256, 2, "direct"), (16, 24, 24, 512, 512, 2, "direct"),
-       (2, 37, 50, 64, 64, 2, "direct"), (16, 96, 96, 64, 128, 1, "wino4"), (3, 20, 28, 128, 64, 1, "direct"), (16, 40, 44, 64, 64, 1, "wino4")]
+       (2, 37, 50, 64, 64, 2, "direct"), (16, 96, 96, 64, 128, 1, "wino4"), (3, 20, 28, 128, 64, 1, "direct"), (16, 40, 44, 64, 64, 1, "wino4"),
+       # split-K input gradients (of features.4 / .6): masked gradient and sums from the finish kernel
+       (16, 48, 48, 128, 256, 1, "wino4"), (16, 24, 24, 256, 512, 1, "wino4")]
 
 
 @pytest.mark.parametrize("N,H,W,C,Cnext,stride,kind", BWD)
@@ -132,17 +136,17 @@ def test_bn_backward_sums_from_the_next_convs_input_gradient_kernel(N, H, W, C, 
     assert torch.equal(gm, gm4) and torch.equal(part, part4)
 
 
-def test_planner_refuses_split_k_layers_and_the_caller_falls_back():
-    """The layers whose tiles cannot fill the chip sum split-K slabs in a finish kernel: no epilogue to leave the sums in -> rows == 0
-    and the autograd function runs the stand-alone passes (same results)."""
+def test_planner_rows_for_the_discriminators_layers():
+    """Rows of sums per call: one per pixel tile where the conv kernel's epilogue leaves them, 256 (the finish kernel's workgroups) where
+    split-K slabs are summed first; 0 only for what neither covers (a packing without the epilogue: the caller runs the stand-alone passes)."""
     from pesr_amd import ops
-    assert ops.conv_bn_rows(0, 16, 24, 24, 512, 512, 2) == 0        # features.7 forward (split-K 2)
-    assert ops.conv_bn_rows(2, 16, 24, 24, 256, 512, 1) == 0        # features.6 forward (F(4,3), split-K)
-    assert ops.conv_bn_rows(2, 16, 48, 48, 256, 128, 1) == 0        # input gradient of features.4
-    assert ops.conv_bn_rows(0, 16, 192, 192, 64, 64, 2) == 16 * 144  # features.1: 64-pixel tiles
+    assert ops.conv_bn_rows(0, 16, 192, 192, 64, 64, 2) == 16 * 144   # features.1: 64-pixel tiles
+    assert ops.conv_bn_rows(0, 16, 24, 24, 512, 512, 2) == 256        # features.7 forward (split-K 2): the finish kernel
+    assert ops.conv_bn_rows(2, 16, 24, 24, 256, 512, 1) == 256        # features.6 forward (F(4,3), split-K)
+    assert ops.conv_bn_rows(2, 16, 48, 48, 256, 128, 1) == 256        # input gradient of features.4
     assert ops.conv_bn_rows(1, 16, 192, 192, 64, 64, 2) > 0 and ops.conv_bn_rows(2, 16, 96, 96, 64, 128, 1) > 0
-    x = _nhwc(_rand(16, 512, 24, 24, seed=41)); w = _rand(512, 512, 3, 3, seed=42, lo=-0.02, hi=0.02)
-    assert ops.conv3x3_fwd_bn_stats(x, ops.pack_conv3x3(w.cuda(), 0), None, 512, 2) is None
+    x = _nhwc(_rand(2, 64, 20, 20, seed=41)); w = _rand(128, 64, 3, 3, seed=42, lo=-0.02, hi=0.02)
+    assert ops.conv3x3_fwd_bn_stats(x, ops.pack_conv3x3_wino(w.cuda(), 0), None, 128, 1) is None      # F(2,3) packing: no epilogue
 
 
 @pytest.mark.parametrize("ps", [8, 24])
