@@ -51,15 +51,23 @@ __global__ __launch_bounds__(256) void conv_rgb_in_kernel(const float* __restric
         const int x0 = tx * RGB_TW, y0 = ty * RGB_TH;
         const float* xi = x + (size_t)n * H * W * 3;
         __syncthreads();                             // the previous tile's readers are done
-        for (int e = threadIdx.x; e < HH_ * HW_; e += 256) {
+        constexpr int HIT = (HH_ * HW_ + 255) / 256;  // both halo entries of a thread are loaded before either is stored (as a loop: one
+        f32x4 hv[HIT];                                // dependent round trip per entry)
+#pragma unroll
+        for (int k = 0; k < HIT; ++k) {
+            const int e = threadIdx.x + k * 256;
             const int hy = e / HW_, hx = e - hy * HW_;
             const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (e < HH_ * HW_ && iy >= 0 && iy < H && ix >= 0 && ix < W) {
                 const float* q = xi + ((size_t)iy * W + ix) * 3;
-                v.x = q[0]; v.y = q[1]; v.z = q[2];
+                hv[k].x = q[0]; hv[k].y = q[1]; hv[k].z = q[2];
             }
-            halo[e] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < HIT; ++k) {
+            const int e = threadIdx.x + k * 256;
+            if (e < HH_ * HW_) halo[e] = hv[k];
         }
         __syncthreads();
         if (pl < ppb) {

@@ -59,18 +59,6 @@ __global__ __launch_bounds__(RO_NT) void conv_rgb_out_kernel(const RgbOutArgs a)
     const int y0 = band * RO_TH;
     const int xin0 = strip * a.outw - a.halo;               // image column of the strip's local column 0
 
-    // ---- weights: OIHW -> [chunk][n = ky*9 + kx*3 + co][c & 15], columns n >= 27 zero; P ring zeroed (its pad columns stay zero)
-    for (int e = tid; e < C16 * 512; e += RO_NT) {
-        const int c15 = e & 15, n = (e >> 4) & 31, chunk = e >> 9;
-        float v = 0.f;
-        if (n < 27) {
-            const int ky = n / 9, kx = (n - ky * 9) / 3, co = n % 3, c = chunk * 16 + c15;
-            v = a.wmode ? a.w[((size_t)(c * 3 + co) * 3 + (2 - ky)) * 3 + (2 - kx)] : a.w[((size_t)(co * a.C + c) * 3 + ky) * 3 + kx];
-        }
-        wl[e] = v;
-    }
-    for (int e = tid; e < 4 * RO_PROW; e += RO_NT) pring[e] = 0.f;
-
     // ---- per-lane A offsets: column tile t of this wave, pixel i, k-slot g (bytes inside an input row; out of the image: 2^31)
     unsigned a_off[RO_MT];
 #pragma unroll
@@ -89,24 +77,76 @@ __global__ __launch_bounds__(RO_NT) void conv_rgb_out_kernel(const RgbOutArgs a)
                     (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pv)),     // (unsigned): the builtin returns int - no sign extension
             0, __builtin_amdgcn_readfirstlane(ok ? row_bytes : 0u), 0x00020000);
     };
-    __syncthreads();
 
-    // Input rows ti = 0 .. TH+1 are image rows y0 - 1 + ti.  Even bands walk them downwards, odd bands upwards: a band and its
-    // neighbour (same XCD, see above) then read the two halo rows they share at the same time, and the second read hits L2.
+    // Input rows ti = 0 .. TH+1 are image rows y0 - 1 + ti.  Even bands walk them downwards, odd bands upwards, so that a band and its
+    // neighbour (same XCD, see above) read the two halo rows they share at the same time and the second read hits L2 - which takes the
+    // SAME order inside the shared pair (round 6: with the pair crossed, the two reads of a row were one row step = ~6 MB of the XCD's
+    // traffic apart and both went to HBM: 5.34 M fabric requests for 4.72 M lines).  An odd band therefore walks 12, 13, 11, 10 .. 2, 0, 1.
     const int rows_in = RO_TH + 2;
     const bool rev = band & 1;
-    const int dir = rev ? -1 : 1;
+    auto row_of_step = [&](int step) -> int {
+        if (!rev) return step;
+        if (step < 2) return rows_in - 2 + step;
+        if (step >= rows_in - 2) return step - (rows_in - 2);
+        return rows_in - 1 - step;
+    };
     u32x4 fa[RO_D][RO_MT];
     bool primed = false;
+    for (int step = 0; step < rows_in; ++step) {            // the first valid row's loads go out before the weights are staged
+        const int r = y0 - 1 + row_of_step(step);
+        if (r >= 0 && r < a.H) {
+            const __amdgpu_buffer_rsrc_t rs = row_rsrc(r);
+#pragma unroll
+            for (int d = 0; d < RO_D - 1; ++d)
+#pragma unroll
+                for (int tt = 0; tt < RO_MT; ++tt) fa[d][tt] = __builtin_amdgcn_raw_buffer_load_b128(rs, a_off[tt], d * 64, 0);
+            primed = true;
+            break;
+        }
+    }
+
+    // ---- weights: OIHW -> [chunk][n = ky*9 + kx*3 + co][c & 15], columns n >= 27 zero; P ring zeroed (its pad columns stay zero).
+    // The 27 C floats are read in their own order, sixteen loads of a thread in flight at a time (round 6: as a gather loop of one load
+    // and one LDS store per iteration the 32 dependent round trips of this prologue cost ~20 us of a 170 us launch).
+    for (int e = tid; e < C16 * 80; e += RO_NT) {
+        const int chunk = e / 80, rem = e - chunk * 80;
+        wl[chunk * 512 + 27 * 16 + rem] = 0.f;
+    }
+    const int wtotal = 27 * a.C;
+#pragma unroll 1
+    for (int base = 0; base < wtotal; base += 16 * RO_NT) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = base + k * RO_NT + tid;
+            v[k] = idx < wtotal ? a.w[idx] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = base + k * RO_NT + tid;
+            if (idx < wtotal) {
+                const int t9 = idx / 9, k9 = idx - t9 * 9;
+                int c, co, ky = k9 / 3, kx = k9 - ky * 3;
+                if (a.wmode) { c = t9 / 3; co = t9 - c * 3; ky = 2 - ky; kx = 2 - kx; }      // w is [C][3][3][3] of the transposed conv, taps flipped
+                else { co = (t9 >= a.C) + (t9 >= 2 * a.C); c = t9 - co * a.C; }              // w is [3][C][3][3]
+                wl[(c >> 4) * 512 + (ky * 9 + kx * 3 + co) * 16 + (c & 15)] = v[k];
+            }
+        }
+    }
+    for (int e = tid; e < 4 * RO_PROW; e += RO_NT) pring[e] = 0.f;
+    __syncthreads();
+
 #pragma unroll 1
     for (int step = 0; step < rows_in; ++step) {
-        const int t = rev ? rows_in - 1 - step : step;
+        const int t = row_of_step(step);
         const int r = y0 - 1 + t;
         const bool valid = r >= 0 && r < a.H;
+        if (rev && step == rows_in - 2) __syncthreads();    // row 0 takes the ring slot of row 4, which the previous step's gather still reads
         if (valid) {                                        // rows outside the image contribute zeros: skipped in the gather below
             const __amdgpu_buffer_rsrc_t rs = row_rsrc(r);
-            const bool next_valid = step + 1 < rows_in && r + dir >= 0 && r + dir < a.H;
-            const __amdgpu_buffer_rsrc_t rs_next = row_rsrc(r + dir);
+            const int r_next = y0 - 1 + row_of_step(step + 1);
+            const bool next_valid = step + 1 < rows_in && r_next >= 0 && r_next < a.H;
+            const __amdgpu_buffer_rsrc_t rs_next = row_rsrc(r_next);
             if (!primed) {                                  // first row of the band: fill the pipeline
 #pragma unroll
                 for (int d = 0; d < RO_D - 1; ++d)
@@ -154,9 +194,12 @@ __global__ __launch_bounds__(RO_NT) void conv_rgb_out_kernel(const RgbOutArgs a)
                 }
         }
         __syncthreads();
-        // output row j (image row y0 + j) needs the P rows of input rows j, j+1, j+2: complete two steps behind the walk
-        const int j = rev ? t : t - 2, oy = y0 + j;
-        if (step >= 2 && j >= 0 && j < RO_TH && oy < a.H) {
+        // output row j (image row y0 + j) needs the P rows of input rows j, j+1, j+2: complete two steps behind the walk (an odd band's
+        // rows 1 and 0 both with its last step)
+        const int nout = step < 2 ? 0 : !rev ? 1 : step < rows_in - 2 ? 1 : step == rows_in - 1 ? 2 : 0;
+        for (int o = 0; o < nout; ++o) {
+            const int j = rev ? t - o : t - 2, oy = y0 + j;
+            if (j < 0 || j >= RO_TH || oy >= a.H) continue;
             float* const yrow = a.y + ((size_t)img * a.H + oy) * a.W * 3;
             for (int u = tid; u < a.outw * 3; u += RO_NT) {
                 const int lx = u / 3, co = u - lx * 3;              // output column strip * outw + lx = local column lx + halo

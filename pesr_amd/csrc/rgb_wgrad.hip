@@ -102,18 +102,36 @@ __global__ __launch_bounds__(256) void corr_rgb_mfma_kernel(const float* __restr
     const int boff1 = n1 < 27 ? (n1 / 9) * WP3 + (n1 % 9) : -1;
     const unsigned row_bytes = (unsigned)W * C * 4;
     const unsigned a_lane = (unsigned)((c0 + 4 * i) * 4);                 // + pixel * C * 4
-    auto stage_b = [&](int row, int buf) {                                 // padded rows y .. y+2 of image n (= neighbours y-1 .. y+1)
+    // padded rows y .. y+2 of image n (= neighbours y-1 .. y+1) -> LDS.  Eight loads of a thread in flight at a time, and (in the row loop)
+    // issued BEFORE the row's A loads and stored behind them: as a plain copy loop (one load, one wait, one LDS store per iteration) the
+    // next row's staging stood in front of every row with seven dependent round trips (round 6).
+    constexpr int SB = 8;
+    const int nb3 = 3 * WP3;
+    auto stage_src = [&](int row) -> const float* {
         const int n = row / H, y = row - n * H;
-        const float* src = b3p + ((size_t)n * (H + 2) + y) * WP3;
-        float* dst = lds + buf * 3 * WP3;
-        for (int e = tid; e < 3 * WP3; e += 256) dst[e] = src[e];
+        return b3p + ((size_t)n * (H + 2) + y) * WP3;
     };
-    if (r0 < r1) stage_b(r0, 0);
+    auto stage_load = [&](const float* src, int base, float (&v)[SB]) {
+#pragma unroll
+        for (int k = 0; k < SB; ++k) { const int e = base + k * 256 + tid; v[k] = e < nb3 ? src[e] : 0.f; }
+    };
+    auto stage_store = [&](float* dst, int base, const float (&v)[SB]) {
+#pragma unroll
+        for (int k = 0; k < SB; ++k) { const int e = base + k * 256 + tid; if (e < nb3) dst[e] = v[k]; }
+    };
+    if (r0 < r1) {
+        const float* src = stage_src(r0);
+        for (int base = 0; base < nb3; base += SB * 256) { float v[SB]; stage_load(src, base, v); stage_store(lds, base, v); }
+    }
     __syncthreads();
 #pragma unroll 1
     for (int row = r0; row < r1; ++row) {
         const int buf = (row - r0) & 1;
-        if (row + 1 < r1) stage_b(row + 1, buf ^ 1);                       // visible after the barrier at the end of this row
+        const bool more = row + 1 < r1;                                    // the next row's B3 rows: visible after the barrier at the end of this row
+        const float* const nsrc = stage_src(more ? row + 1 : row);
+        float* const ndst = lds + (buf ^ 1) * 3 * WP3;
+        float sv[SB];
+        if (more) stage_load(nsrc, 0, sv);
         const float* const bl = lds + buf * 3 * WP3;
         const unsigned long long av = (unsigned long long)(A + (size_t)row * W * C);      // provably wave-uniform base: no waterfall loops
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -127,6 +145,10 @@ __global__ __launch_bounds__(256) void corr_rgb_mfma_kernel(const float* __restr
         u32x4 fa[CR_D];
 #pragma unroll
         for (int d = 0; d < CR_D - 1; ++d) fa[d] = a_load(d);              // s >= ksteps: all lanes out of range, harmless
+        if (more) {
+            stage_store(ndst, 0, sv);
+            for (int base = SB * 256; base < nb3; base += SB * 256) { float v[SB]; stage_load(nsrc, base, v); stage_store(ndst, base, v); }   // W > 680
+        }
 #pragma unroll 1
         for (int s0 = 0; s0 < ksteps; s0 += CR_D)
 #pragma unroll
