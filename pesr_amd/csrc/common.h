@@ -62,6 +62,23 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Column sum over `rows` partial rows in increasing order, in double - eight loads in flight at a time (as a plain loop hipcc emits one
+// load, one s_waitcnt vmcnt(0) and one add per iteration: `rows` dependent round trips on a single thread that its whole block waits for).
+__device__ __forceinline__ double pesr_colsum_rows(const float* __restrict__ part, int rows, size_t stride) {
+    double s = 0.0;
+    int k = 0;
+    for (; k + 8 <= rows; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; k < rows; ++k) s += (double)part[(size_t)k * stride];
+    return s;
+}
+
+
 // ---- BatchNorm sums out of a conv kernel's epilogue (round 6; SURVEY K10, reference model/basic.py:26-30) ------------------------
 // mode 1 (a conv in front of a BatchNorm): the workgroup leaves the per-channel sum and sum of squares of what it stored in
 //   part[row0 + pixel tile][2][C] - bn_reduce_kernel<0>'s row layout, so bn_finalize_kernel takes the rows as they are.

@@ -250,7 +250,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
         const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
         if (p < Cout) {
             double s = 0.0;
-            for (int k = 0; k < bias_rows; ++k) s += (double)bias_part[(size_t)k * Cout + p];
+            s = pesr_colsum_rows(bias_part + p, bias_rows, (size_t)Cout);
             int o = (int)p;
             if (ps) { const int sub = (int)p / C, cc = (int)p - sub * C; o = 4 * cc + sub; }
             db[o] = alpha * (float)s + (accumulate ? db[o] : 0.f);
@@ -427,8 +427,7 @@ __global__ __launch_bounds__(576) void wgrad_reduce_rows_kernel(const float* __r
     int o = p;
     if (ps) { const int sub = p / C, cc = p - sub * C; o = 4 * cc + sub; }
     if (bias_part && ci0 == 0 && tid == 0) {
-        double sb = 0.0;
-        for (int k = 0; k < bias_rows; ++k) sb += (double)bias_part[(size_t)k * Cout + p];
+        const double sb = pesr_colsum_rows(bias_part + p, bias_rows, (size_t)Cout);
         db[o] = alpha * (float)sb + (accumulate ? db[o] : 0.f);
     }
     if (lane * 4 < CIB) {

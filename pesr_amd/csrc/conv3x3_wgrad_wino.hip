@@ -257,7 +257,7 @@ __global__ void wgrad_wino_reduce_kernel(const float* __restrict__ slab, float* 
         const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
         if (p < Cout) {
             double s = 0.0;
-            for (int k = 0; k < bias_rows; ++k) s += (double)bias_part[(size_t)k * Cout + p];
+            s = pesr_colsum_rows(bias_part + p, bias_rows, (size_t)Cout);
             int o = (int)p;
             if (ps) { const int sub = (int)p / C, cc = (int)p - sub * C; o = 4 * cc + sub; }
             db[o] = alpha * (float)s;

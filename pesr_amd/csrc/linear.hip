@@ -327,10 +327,14 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     const long k = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const int n0 = blockIdx.y * nchunk;
     int n1 = n0 + nchunk; if (n1 > N) n1 = N;
-    for (int e = threadIdx.x; e < 64 * MB; e += 256) {
-        const int nn = e / MB, m = e - nn * MB;
-        dyt[e] = (m < M && n0 + nn < n1) ? dy[(size_t)m * N + n0 + nn] : 0.f;
+    float dv[64 * MB / 256];                               // all of a thread's dy values are in flight before the first is stored
+#pragma unroll
+    for (int j = 0; j < 64 * MB / 256; ++j) {
+        const int e = threadIdx.x + j * 256, nn = e / MB, m = e - nn * MB;
+        dv[j] = (m < M && n0 + nn < n1) ? dy[(size_t)m * N + n0 + nn] : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < 64 * MB / 256; ++j) dyt[threadIdx.x + j * 256] = dv[j];
     __syncthreads();
     if (k >= K) return;
     f32x4 xv[MB];

@@ -11,6 +11,13 @@ __device__ __forceinline__ double reduce_rows_block(const float* __restrict__ pa
     double s = 0.0;
     if (valid) {
         int k = rl;
+        for (; k + 240 < nb; k += 256) { // 16 independent loads in flight (thousands of rows: the C <-> 3 weight gradients' partials)
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(k + 16 * u) * ncols + col];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += (double)v[u];
+        }
         for (; k + 48 < nb; k += 64) {   // 4 independent loads in flight
             const float a = part[(size_t)k * ncols + col], b = part[(size_t)(k + 16) * ncols + col];
             const float c = part[(size_t)(k + 32) * ncols + col], d = part[(size_t)(k + 48) * ncols + col];
