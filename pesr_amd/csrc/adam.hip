@@ -5,18 +5,32 @@
 #include "common.h"
 #include "launchers.h"
 
+__device__ __forceinline__ void adam_update(f32x4& pp, f32x4& mm, f32x4& vv, f32x4 gg, float one_minus_b1, float b2, float one_minus_b2,
+                                            float step_size, float bc2_sqrt, float eps, float gscale) {
+    gg = gg * gscale;
+    mm = mm + (gg - mm) * one_minus_b1;
+    vv = vv * b2 + gg * gg * one_minus_b2;
+    f32x4 den;
+    den.x = sqrtf(vv.x) / bc2_sqrt + eps; den.y = sqrtf(vv.y) / bc2_sqrt + eps;
+    den.z = sqrtf(vv.z) / bc2_sqrt + eps; den.w = sqrtf(vv.w) / bc2_sqrt + eps;
+    pp.x -= step_size * (mm.x / den.x); pp.y -= step_size * (mm.y / den.y);
+    pp.z -= step_size * (mm.z / den.z); pp.w -= step_size * (mm.w / den.w);
+}
 __global__ void adam_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v, long n4,
                             float one_minus_b1, float b2, float one_minus_b2, float step_size, float bc2_sqrt, float eps, float gscale) {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
-        const f32x4 gg = g[e] * gscale;
+    const long stride = (long)gridDim.x * blockDim.x;
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; e + stride < n4; e += 2 * stride) {             // two elements per pass, the gradient (read once, dead afterwards) non-temporal:
+        const long e1 = e + stride;                        // 226 -> 211 us for the Generator's 43 M parameters (round 6)
+        f32x4 g0 = __builtin_nontemporal_load(g + e), g1 = __builtin_nontemporal_load(g + e1);
+        f32x4 m0 = m[e], v0 = v[e], p0 = p[e], m1 = m[e1], v1 = v[e1], p1 = p[e1];
+        adam_update(p0, m0, v0, g0, one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale);
+        adam_update(p1, m1, v1, g1, one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale);
+        p[e] = p0; m[e] = m0; v[e] = v0; p[e1] = p1; m[e1] = m1; v[e1] = v1;
+    }
+    for (; e < n4; e += stride) {
         f32x4 mm = m[e], vv = v[e], pp = p[e];
-        mm = mm + (gg - mm) * one_minus_b1;
-        vv = vv * b2 + gg * gg * one_minus_b2;
-        f32x4 den;
-        den.x = sqrtf(vv.x) / bc2_sqrt + eps; den.y = sqrtf(vv.y) / bc2_sqrt + eps;
-        den.z = sqrtf(vv.z) / bc2_sqrt + eps; den.w = sqrtf(vv.w) / bc2_sqrt + eps;
-        pp.x -= step_size * (mm.x / den.x); pp.y -= step_size * (mm.y / den.y);
-        pp.z -= step_size * (mm.z / den.z); pp.w -= step_size * (mm.w / den.w);
+        adam_update(pp, mm, vv, g[e], one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale);
         p[e] = pp; m[e] = mm; v[e] = vv;
     }
 }
@@ -54,16 +68,19 @@ __global__ void adam_tick_kernel(float* __restrict__ state, float b1, float b2) 
 __global__ void adam_dev_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v, long n4,
                                 float one_minus_b1, float b2, float one_minus_b2, const float* __restrict__ state, float eps, float gscale) {
     const float step_size = state[2], bc2_sqrt = state[3];
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
-        const f32x4 gg = g[e] * gscale;
+    const long stride = (long)gridDim.x * blockDim.x;
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; e + stride < n4; e += 2 * stride) {
+        const long e1 = e + stride;
+        f32x4 g0 = __builtin_nontemporal_load(g + e), g1 = __builtin_nontemporal_load(g + e1);
+        f32x4 m0 = m[e], v0 = v[e], p0 = p[e], m1 = m[e1], v1 = v[e1], p1 = p[e1];
+        adam_update(p0, m0, v0, g0, one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale);
+        adam_update(p1, m1, v1, g1, one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale);
+        p[e] = p0; m[e] = m0; v[e] = v0; p[e1] = p1; m[e1] = m1; v[e1] = v1;
+    }
+    for (; e < n4; e += stride) {
         f32x4 mm = m[e], vv = v[e], pp = p[e];
-        mm = mm + (gg - mm) * one_minus_b1;
-        vv = vv * b2 + gg * gg * one_minus_b2;
-        f32x4 den;
-        den.x = sqrtf(vv.x) / bc2_sqrt + eps; den.y = sqrtf(vv.y) / bc2_sqrt + eps;
-        den.z = sqrtf(vv.z) / bc2_sqrt + eps; den.w = sqrtf(vv.w) / bc2_sqrt + eps;
-        pp.x -= step_size * (mm.x / den.x); pp.y -= step_size * (mm.y / den.y);
-        pp.z -= step_size * (mm.z / den.z); pp.w -= step_size * (mm.w / den.w);
+        adam_update(pp, mm, vv, g[e], one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale);
         p[e] = pp; m[e] = mm; v[e] = vv;
     }
 }
