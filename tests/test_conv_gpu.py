@@ -509,3 +509,26 @@ def test_conv3x3_s2_dgrad_256_channel_tiles_one_tap_class():
             _close(dx[:, :, py::2, px::2], dx_ref[:, :, py::2, px::2], 1e-5)
     for rep in range(3):        # and bit-reproducible (a race would not be)
         assert torch.equal(dx, _nchw(ops.conv3x3_dgrad(_nhwc(dy), ops.pack_conv3x3(w.cuda(), 1), (N, H, W, Cin), 2)))
+
+
+@pytest.mark.parametrize("O,I,ps", [(64, 64, False), (256, 256, False), (128, 64, False), (64, 192, False), (1024, 256, True), (256, 64, True)])
+def test_batched_wino4_repack_equals_the_single_pack(O, I, ps):
+    """The one-launch re-pack behind every optimizer step (pesr_pack_conv3x3_batched, F(4,3) modes 4 / 5: one thread per
+    (row, channel) of a 16 x 16 tile) against the per-element packing the first forward uses (pesr_pack_conv3x3_wino4): bit-identical, forward and input-gradient
+    layouts, with and without the pixel-shuffle channel order; also from a weight tensor that sits 4 bytes off a 16-byte boundary."""
+    import numpy as np
+    from pesr_amd import ops, _lib
+    for shift in (0, 1):
+        base = torch.empty(O * I * 9 + 4, device="cuda")
+        w = base[shift:shift + O * I * 9].view(O, I, 3, 3)
+        w.copy_(_rand(O, I, 3, 3, seed=O + I + shift, scale=0.1))
+        jobs, outs = [], []
+        for mode in (0, 1):
+            out = torch.full((18 * O * I,), float("nan"), device="cuda")
+            outs.append(out)
+            jobs.append((w.data_ptr(), out.data_ptr(), O, I, 4 + mode, int(ps), I if mode == 0 else O, O if mode == 0 else I))
+        table = torch.from_numpy(np.array(jobs, dtype=np.int64)).cuda()
+        _lib.check(_lib.lib().pesr_pack_conv3x3_batched(table.data_ptr(), len(jobs), torch.cuda.current_stream().cuda_stream), "batched pack")
+        for mode in (0, 1):
+            ref = ops.pack_conv3x3_wino4(w, mode, ps=ps).t
+            assert torch.equal(outs[mode], ref), (mode, shift)
