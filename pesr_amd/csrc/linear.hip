@@ -1,7 +1,7 @@
 // Skinny-batch Linear for the Discriminator's classifier (reference model/pesr.py:69-74: Linear(73728, 1024)
 // -> LeakyReLU(0.2) -> Linear(1024, 1); ATen addmm / mm in forward and backward).  M (batch) <= 32.
 // All three passes are HBM-bound on the 302 MB weight matrix, which each streams exactly once:
-//   fwd  : y[m][n]  = act(sum_k x[m][k] W[n][k] + b[n])     split-K partials (MFMA for M <= 16) + fixed-order finalize
+//   fwd  : y[m][n]  = act(sum_k x[m][k] W[n][k] + b[n])     split-K partials (MFMA: the batch is one or two 16-row tiles) + fixed-order finalize
 //   dgrad: dx[m][k] = sum_n dy[m][n] W[n][k]                 split-N partials + fixed-order finalize
 //   wgrad: dW[n][k] = sum_m dy[m][n] x[m][k],  db[n] = sum_m dy[m][n]
 #include <mutex>
@@ -11,44 +11,6 @@
 #define LIN_MAXM 32
 
 // ---- forward -----------------------------------------------------------------------------------
-// one wave: NR consecutive output features, one K slice; lanes stride over K with float4 loads.
-template <int MB, int NR>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                         float* __restrict__ part, int M, int N, long K, int ksplit, long kchunk) {
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const int ngroups = (N + NR - 1) / NR;
-    const int ng = wave % ngroups, ks = wave / ngroups;
-    if (ks >= ksplit) return;
-    const int n0 = ng * NR;
-    const long k0 = ks * kchunk;
-    long k1 = k0 + kchunk; if (k1 > K) k1 = K;
-    float acc[NR][MB];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
-    for (long k = k0 + lane * 4; k < k1; k += 256) {
-        f32x4 w[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) w[r] = (n0 + r < N) ? *(const f32x4*)(W + (size_t)(n0 + r) * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            if (m < M) {
-                const f32x4 xv = *(const f32x4*)(x + (size_t)m * K + k);
-#pragma unroll
-                for (int r = 0; r < NR; ++r)
-                    acc[r][m] = fmaf(w[r].w, xv.w, fmaf(w[r].z, xv.z, fmaf(w[r].y, xv.y, fmaf(w[r].x, xv.x, acc[r][m]))));
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const float s = wave_sum(acc[r][m]);
-            if (lane == 0 && m < M && n0 + r < N) part[((size_t)ks * M + m) * N + n0 + r] = s;
-        }
-}
 // M <= 16: the batch IS an MFMA dimension.  One wave owns NB x 16 output features and one K slice; per 16-k step every
 // lane loads ONE 16-byte piece of x (row lane%16, k-slot lane/16) and NB pieces of W, and element e of the pieces feeds
 // MFMA k-step e (k-slot g of step e stands for k = k0 + 4g + e).  The x slice is thus read once per NB*16 features
@@ -112,8 +74,8 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma_kernel(const float* __res
 // 4 x 256 B loads, passes it through a wave-private 16 KiB LDS image (16-byte chunks XOR-swizzled by the row: the writes fill whole rows,
 // the 8 lanes of a fragment-read cycle hit 8 different chunks) and reads the B fragments from there; x as before.  No barrier: the
 // image belongs to one wave, whose LDS operations execute in order.
-template <int NB>
-__global__ __launch_bounds__(256) void linear_fwd_mfma_lds_kernel(const float* __restrict__ x, const float* __restrict__ W,
+template <int NB, int MT>   // MT: 16-row tiles of x (M <= 16 MT): two calls of a layer batched into one pass over W (round 6, the Discriminator's
+__global__ __launch_bounds__(256) void linear_fwd_mfma_lds_kernel(const float* __restrict__ x, const float* __restrict__ W,   // classifier on [hr; sr])
                                                                   float* __restrict__ part, int M, int N, long K, int ksplit, long kchunk) {
     extern __shared__ __attribute__((aligned(16))) char lin_smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -126,21 +88,27 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma_lds_kernel(const float* _
     const long k0 = ks * kchunk;
     long k1 = k0 + kchunk; if (k1 > K) k1 = K;
     char* const tile = lin_smem + wv * (16 * NB * 256);     // [16 NB rows][16 chunks of 16 B], chunk c of row r at slot c ^ (r & 15)
-    f32x4 acc[NB];
+    f32x4 acc[MT][NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[t][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const float* const xr = x + (size_t)(i < M ? i : 0) * K;
-    const bool xok = i < M;
+    const float* xr[MT];
+    bool xok[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { xok[t] = 16 * t + i < M; xr[t] = x + (size_t)(xok[t] ? 16 * t + i : 0) * K; }
     const bool rows_in = n0 + 16 * NB <= N;
     for (long k = k0; k < k1; k += 64) {
         const bool all_in = rows_in && k + 64 <= k1;          // wave-uniform: the whole 64 x 64 tile and the x pieces exist
-        f32x4 w[4 * NB], a[4];
+        f32x4 w[4 * NB], a[MT][4];
         if (all_in) {
 #pragma unroll
             for (int j = 0; j < 4 * NB; ++j) w[j] = __builtin_nontemporal_load((const f32x4*)(W + (size_t)(n0 + 4 * j + g) * K + k + 4 * i));
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) a[s_] = xok ? *(const f32x4*)(xr + k + 16 * s_ + 4 * g) : zero;
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) a[t][s_] = xok[t] ? *(const f32x4*)(xr[t] + k + 16 * s_ + 4 * g) : zero;
         } else {
 #pragma unroll
             for (int j = 0; j < 4 * NB; ++j) {
@@ -148,7 +116,9 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma_lds_kernel(const float* _
                 w[j] = (n < N && k + 4 * i < k1) ? *(const f32x4*)(W + (size_t)n * K + k + 4 * i) : zero;
             }
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) a[s_] = (xok && k + 16 * s_ + 4 * g < k1) ? *(const f32x4*)(xr + k + 16 * s_ + 4 * g) : zero;
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) a[t][s_] = (xok[t] && k + 16 * s_ + 4 * g < k1) ? *(const f32x4*)(xr[t] + k + 16 * s_ + 4 * g) : zero;
         }
 #pragma unroll
         for (int j = 0; j < 4 * NB; ++j) {
@@ -166,16 +136,20 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma_lds_kernel(const float* _
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_][e], bf[b][e], acc[b], 0, 0, 0);
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s_][e], bf[b][e], acc[t][b], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int m = 4 * g + jj, n = n0 + b * 16 + i;
-            if (m < M && n < N) part[((size_t)ks * M + m) * N + n] = acc[b][jj];
-        }
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = 16 * t + 4 * g + jj, n = n0 + b * 16 + i;
+                if (m < M && n < N) part[((size_t)ks * M + m) * N + n] = acc[t][b][jj];
+            }
 }
 __global__ void linear_fwd_final_kernel(const float* __restrict__ part, const float* __restrict__ b, float* __restrict__ y, int M,
                                         int N, int ksplit, int act, float slope) {
@@ -248,6 +222,7 @@ __global__ __launch_bounds__(LD_BT) void linear_dgrad_kernel(const float* __rest
 // D_e[m][i] = dx[m][k0 + 4 i + e].  A lane ends with dx[m = 4 g + jj][k0 + 4 i .. + 3] = {acc[0][jj] .. acc[3][jj]}: one 16-byte store
 // per jj.  Against the VALU form above: no 64 FMAs per 16 bytes of W (the kernel was bound by them: 105 - 110 us = 0.45 of the HBM rate,
 // W alone streams in ~60), and an N split of 4 instead of 16 (19 MB of partial slabs instead of 75).
+template <int MT>             // 16-row tiles of dy (M <= 16 MT)
 __global__ __launch_bounds__(256) void linear_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ W,
                                                                 float* __restrict__ part, int M, int N, long K, int nchunk, long ktiles) {
     const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -261,19 +236,24 @@ __global__ __launch_bounds__(256) void linear_dgrad_mfma_kernel(const float* __r
     const long kl = k0 + 4 * i;                              // this lane's four columns
     const bool kok = kl < K;                                 // (K % 4 == 0)
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = zero;
-    const float* const dyr = dy + (size_t)(i < M ? i : 0) * N;
-    const bool mok = i < M;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mt][e] = zero;
+    const float* dyr[MT];
+    bool mok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { mok[mt] = 16 * mt + i < M; dyr[mt] = dy + (size_t)(mok[mt] ? 16 * mt + i : 0) * N; }
     constexpr int U = 2;                                     // 16-row groups per trip: 8 KiB of W in flight per wave
     int n = n0;
     for (; n + 16 * U <= n1; n += 16 * U) {
-        f32x4 d[U], w[U][4];
+        f32x4 d[U][MT], w[U][4];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int nb = n + 16 * u + 4 * g;
-            d[u] = mok ? *(const f32x4*)(dyr + nb) : zero;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) d[u][mt] = mok[mt] ? *(const f32x4*)(dyr[mt] + nb) : zero;
 #pragma unroll
             for (int t = 0; t < 4; ++t) w[u][t] = kok ? __builtin_nontemporal_load((const f32x4*)(W + (size_t)(nb + t) * K + kl)) : zero;
         }
@@ -282,28 +262,35 @@ __global__ __launch_bounds__(256) void linear_dgrad_mfma_kernel(const float* __r
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u][t], w[u][t][e], acc[e], 0, 0, 0);
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u][mt][t], w[u][t][e], acc[mt][e], 0, 0, 0);
     }
     for (; n < n1; n += 16) {                                // ragged end of the slice: rows past n1 contribute zeros
         const int nb = n + 4 * g;
-        f32x4 d = zero, w[4];
+        f32x4 d[MT], w[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const bool rok = nb + t < n1;
-            d[t] = (mok && rok) ? dyr[nb + t] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) d[mt][t] = (mok[mt] && rok) ? dyr[mt][nb + t] : 0.f;
             w[t] = (kok && rok) ? *(const f32x4*)(W + (size_t)(nb + t) * K + kl) : zero;
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[t], w[t][e], acc[e], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[mt][t], w[t][e], acc[mt][e], 0, 0, 0);
     }
     if (kok) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int m = 4 * g + jj;
-            if (m < M) *(f32x4*)(part + ((size_t)ns * M + m) * K + kl) = (f32x4){acc[0][jj], acc[1][jj], acc[2][jj], acc[3][jj]};
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = 16 * mt + 4 * g + jj;
+                if (m < M) *(f32x4*)(part + ((size_t)ns * M + m) * K + kl) = (f32x4){acc[mt][0][jj], acc[mt][1][jj], acc[mt][2][jj], acc[mt][3][jj]};
+            }
     }
 }
 // finalize: dx = sum over N-slices; the LeakyReLU derivative of the layer below is applied by its own backward
@@ -342,11 +329,19 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     for (int m = 0; m < MB; ++m) xv[m] = m < M ? *(const f32x4*)(x + (size_t)m * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int n = n0; n < n1; ++n) {
         const f32x4* const d4 = (const f32x4*)(dyt + (n - n0) * MB);
+        // Rows are added in groups of sixteen, each group a chain from zero, the groups then to each other: the result for 32 rows is bit
+        // for bit what two calls of 16 rows (the second with `accumulate`) leave - the Discriminator's classifier on [hr; sr] in one pass
+        // gives the gradients its two calls gave.  (Rows m >= M hold zeros in both operands.)
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < MB / 4; ++q) {      // rows m >= M hold zeros in both operands: same order of additions as before
-            const f32x4 d = d4[q];
-            s += xv[4 * q] * d.x; s += xv[4 * q + 1] * d.y; s += xv[4 * q + 2] * d.z; s += xv[4 * q + 3] * d.w;
+        for (int h = 0; h < MB / 16; ++h) {
+            f32x4 sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 4 * h; q < 4 * h + 4; ++q) {
+                const f32x4 d = d4[q];
+                sh += xv[4 * q] * d.x; sh += xv[4 * q + 1] * d.y; sh += xv[4 * q + 2] * d.z; sh += xv[4 * q + 3] * d.w;
+            }
+            s = h == 0 ? sh : sh + s;             // (the second call computed its chain and added what was there)
         }
         // (non-temporal: the 302 MB stream is written once and not re-read by this kernel - 88 -> 78 us)
         if (accumulate) s += __builtin_nontemporal_load((const f32x4*)(dW + (size_t)n * K + k));   // dW += ... : a second use of the layer in one backward
@@ -356,27 +351,25 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 __global__ void linear_bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N, int accumulate) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
+    float s = 0.f;                                          // groups of sixteen rows, as in the weight gradient above: under RSGAN the two
+    for (int m0 = 0; m0 < M; m0 += 16) {                     // halves of [hr; sr] are exact negatives of each other and classifier.2.bias's
+        float sh = 0.f;                                      // gradient is exactly zero, as in the reference
+        for (int m = m0; m < M && m < m0 + 16; ++m) sh += dy[(size_t)m * N + n];
+        s = m0 == 0 ? sh : s + sh;
+    }
     db[n] = accumulate ? db[n] + s : s;
 }
 
 namespace {
 struct LinPlan { int ksplit; long kchunk; int nsplit, nchunk; };
 static void lin_plan(int M, int N, long K, LinPlan* p) {
-    // forward: M <= 16: waves = ceil(N/64) * ksplit ~ 2048 (more waves or deeper unrolling measured slower), K slices in multiples of 16 (MFMA kernel);
-    //          M  > 16: waves = ceil(N/2) * ksplit ~ 4096, K slices in multiples of 256 (lane-strided kernel)
-    if (M <= 16) {
+    // forward, MFMA kernels (one or two 16-row tiles of x; a tiny N with M > 16 is launched as two 16-row calls): waves = ceil(N/64) * ksplit
+    // ~ 2048 (more waves or deeper unrolling measured slower), K slices in multiples of 64
+    if (M <= LIN_MAXM) {
         const int ngroups = (N + 63) / 64;
         int ks = 2048 / ngroups; if (ks < 1) ks = 1;
         long kc = ((K + ks - 1) / ks + 63) / 64 * 64;         // (multiples of 64: a trip of the LDS-staged kernel)
         if (kc < 64) kc = 64;
-        p->kchunk = kc; p->ksplit = (int)((K + kc - 1) / kc);
-    } else {
-        const int ngroups = (N + 1) / 2;
-        int ks = 4096 / ngroups; if (ks < 1) ks = 1;
-        long kc = ((K + ks - 1) / ks + 255) / 256 * 256;
-        if (kc < 256) kc = 256;
         p->kchunk = kc; p->ksplit = (int)((K + kc - 1) / kc);
     }
     // dgrad: one-wave blocks, ceil(K/256) * nsplit ~ 1024 of them (every N slice writes an M x K partial: keep them few)
@@ -384,7 +377,7 @@ static void lin_plan(int M, int N, long K, LinPlan* p) {
     constexpr int LD_NS_TARGET = 1024, LD_NS_MAX = 16;    // (the 16 x 4 point of the sweep in profiles/r03_linear_sweep.txt)
     int ns = (int)((LD_NS_TARGET * 256 / LD_BT + kb - 1) / kb); if (ns < 1) ns = 1; if (ns > N) ns = N; if (ns > LD_NS_MAX) ns = LD_NS_MAX;
     p->nchunk = (N + ns - 1) / ns; p->nsplit = (N + p->nchunk - 1) / p->nchunk;
-    if (M <= 16) {
+    if (M <= LIN_MAXM) {
         // MFMA input gradient: waves = ceil(K / 64) * nsplit ~ 4608 (18 per CU), slices in multiples of 32 rows (the loop's trip)
         const long ktiles = (K + 63) / 64;
         int ns2 = (int)((4608 + ktiles - 1) / ktiles); if (ns2 < 1) ns2 = 1; if (ns2 > 16) ns2 = 16;
@@ -406,16 +399,25 @@ int pesr_linear_fwd_launch(const float* x, const float* W, const float* b, float
     if (M > LIN_MAXM || M < 1 || K % 4) return PESR_EINVAL;
     LinPlan p; lin_plan(M, N, K, &p);
     if (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float)) return PESR_EWORKSPACE;
-    if (M <= 16) {
+    {
         const long waves = (long)((N + 63) / 64) * p.ksplit;
+        const dim3 grid((unsigned)((waves + 3) / 4));
         if (N >= 64) {   // W through the wave-private LDS image (whole 128-byte lines per fetch); tiny N: the direct form
             static PesrDeviceOnce attr_once;
-            attr_once([&] { (void)hipFuncSetAttribute((const void*)linear_fwd_mfma_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); });
-            hipLaunchKernelGGL(linear_fwd_mfma_lds_kernel<4>, dim3((int)((waves + 3) / 4)), dim3(256), 64 * 1024, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
-        } else
-            hipLaunchKernelGGL(linear_fwd_mfma_kernel<4>, dim3((int)((waves + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
-    } else
-        hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), dim3((int)(((long)((N + 1) / 2) * p.ksplit + 3) / 4)), dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+            attr_once([&] {
+                (void)hipFuncSetAttribute((const void*)linear_fwd_mfma_lds_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                (void)hipFuncSetAttribute((const void*)linear_fwd_mfma_lds_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            });
+            if (M <= 16) hipLaunchKernelGGL((linear_fwd_mfma_lds_kernel<4, 1>), grid, dim3(256), 64 * 1024, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+            else hipLaunchKernelGGL((linear_fwd_mfma_lds_kernel<4, 2>), grid, dim3(256), 64 * 1024, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+        } else if (M <= 16) {
+            hipLaunchKernelGGL(linear_fwd_mfma_kernel<4>, grid, dim3(256), 0, stream, x, W, (float*)ws, M, N, K, p.ksplit, p.kchunk);
+        } else {         // tiny N (classifier.2): the 16-row kernel twice - per row the sums its single calls make
+            int rc = pesr_linear_fwd_launch(x, W, b, y, 16, N, K, act, slope, ws, ws_bytes, stream);
+            if (rc) return rc;
+            return pesr_linear_fwd_launch(x + (size_t)16 * K, W, b, y + (size_t)16 * N, M - 16, N, K, act, slope, ws, ws_bytes, stream);
+        }
+    }
     hipLaunchKernelGGL(linear_fwd_final_kernel, dim3((M * N + 63) / 64), dim3(64), 0, stream, (const float*)ws, b, y, M, N, p.ksplit, act, slope);
     return pesr_launch_status();
 }
@@ -426,9 +428,10 @@ int pesr_linear_dgrad_launch(const float* dy, const float* W, float* dx, int M, 
     LinPlan p; lin_plan(M, N, K, &p);
     if (!ws || ws_bytes < (size_t)p.nsplit * M * K * sizeof(float)) return PESR_EWORKSPACE;
     const dim3 grid((unsigned)((K / 4 + LD_BT - 1) / LD_BT), (unsigned)p.nsplit);
-    if (M <= 16 && N % 4 == 0) {
+    if (N % 4 == 0) {
         const long ktiles = (K + 63) / 64, waves = ktiles * p.nsplit;
-        hipLaunchKernelGGL(linear_dgrad_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk, ktiles);
+        if (M <= 16) hipLaunchKernelGGL(linear_dgrad_mfma_kernel<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk, ktiles);
+        else hipLaunchKernelGGL(linear_dgrad_mfma_kernel<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk, ktiles);
     } else if (M <= 16) hipLaunchKernelGGL(linear_dgrad_kernel<16>, grid, dim3(LD_BT), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
     else hipLaunchKernelGGL(linear_dgrad_kernel<32>, grid, dim3(LD_BT), 0, stream, dy, W, (float*)ws, M, N, K, p.nchunk);
     const long MK4 = (long)M * K / 4;

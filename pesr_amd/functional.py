@@ -977,11 +977,15 @@ INPLACE_SECOND_USE = True
 
 
 class LinearFn(Function):
+    """grad_rows (optional): only the first grad_rows rows of x need an input gradient - the Discriminator's classifier on [sr; hr] in the
+    generator phase, whose hr half comes from a no_grad pass (Discriminator.classify); the other rows of the returned gradient are
+    never read (torch.cat's backward hands them to an input that requires none) and stay uninitialised."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, act, slope):
+    def forward(ctx, x, weight, bias, act, slope, grad_rows=None):
         x = _c(x)
         y = ops.linear_fwd(x, weight.detach(), bias.detach(), act, slope)
-        ctx.act, ctx.slope, ctx.bias_ref = act, slope, bias
+        ctx.act, ctx.slope, ctx.bias_ref, ctx.grad_rows = act, slope, bias, grad_rows
         ctx.save_for_backward(x, weight, y if act != ops.ACT_NONE else None)
         return y
 
@@ -994,7 +998,14 @@ class LinearFn(Function):
                 gy = ops.relu_mask(gy, y, slope=ctx.slope if ctx.act == ops.ACT_LRELU else 0.0)
             else:  # scalar-sized tail case
                 gy = torch.where(y > 0, gy, gy * (ctx.slope if ctx.act == ops.ACT_LRELU else 0.0))
-        dx = ops.linear_dgrad(gy, weight.detach()) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            r = ctx.grad_rows
+            if r is not None and 0 < r < gy.shape[0]:
+                dx = torch.empty((gy.shape[0], weight.shape[1]), dtype=torch.float32, device=gy.device)
+                ops.linear_dgrad(gy[:r], weight.detach(), out=dx[:r])
+            else:
+                dx = ops.linear_dgrad(gy, weight.detach())
         dw = db = None
         if ctx.needs_input_grad[1]:
             o_w, o_b = grad_out(weight), grad_out(ctx.bias_ref)
@@ -1005,9 +1016,33 @@ class LinearFn(Function):
                 a_w, a_b = grad_out_again(weight), grad_out_again(ctx.bias_ref)
                 if a_w is not None and a_b is not None:
                     ops.linear_wgrad(gy, x, want_bias=True, dw_out=a_w, db_out=a_b, accumulate=True)
-                    return dx, None, None, None, None
+                    return dx, None, None, None, None, None
             dw, db = ops.linear_wgrad(gy, x, want_bias=True, dw_out=o_w, db_out=o_b)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
+
+
+class SplitRowsFn(Function):
+    """t[:n], t[off:off + n] whose backward is ONE buffer (two slicing nodes cost two zero fills, two copies and an add - five launches
+    for the [2B, 1] logits of the Discriminator's paired classifier).  Rows outside the two pieces get zero gradients."""
+
+    @staticmethod
+    def forward(ctx, t, n, off):
+        ctx.n, ctx.off, ctx.rows = n, off, t.shape[0]
+        return t[:n].clone(), t[off:off + n].clone()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None, None
+        ref = ga if ga is not None else gb
+        if ctx.off == ctx.n and ctx.rows == 2 * ctx.n and ga is not None and gb is not None:
+            return torch.cat([ga, gb]), None, None
+        g = ref.new_zeros((ctx.rows,) + tuple(ref.shape[1:]))
+        if ga is not None:
+            g[:ctx.n] = ga
+        if gb is not None:
+            g[ctx.off:ctx.off + ctx.n] = gb
+        return g, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@ on the HIP kernels, API- and checkpoint-compatible with reference model/pesr.py:
 (`sub_mean, embed, body, upsample, add_mean` / `features, classifier`), hence the same state_dict keys and shapes, and the
 same order of parameter-initialisation RNG draws.
 """
+import torch
 import torch.nn as nn
 
 from .. import functional as PF
@@ -64,16 +65,44 @@ class Discriminator(nn.Module):
         side = (opt['patch_size'] * 4) // 16                 # four stride-2 stages on the HR patch
         self.classifier = nn.Sequential(nn.Linear(512 * side * side, 1024), lrelu, nn.Linear(1024, 1))
 
-    def forward(self, x):
+    def forward_features(self, x):
+        """The eight conv + BatchNorm + LeakyReLU blocks: [B, 3, H, W] -> [B, 512 * side * side] in the reference's NCHW column order
+        (reference model/pesr.py:78-79).  One call = one set of BatchNorm batch statistics, as in the reference."""
         # the blocks are chained here (not through nn.Sequential.forward) so that each block knows its producer: the tensors in between
         # are seen by nobody else, which lets a block's input-gradient kernel do the BatchNorm reductions of the block in front of it
         flat, link = x, None
         for blk in self.features:
             flat, link = blk.forward_linked(flat, link) if isinstance(blk, BasicBlock) else (blk(flat), None)
-        flat = flat.view(flat.size(0), -1)
+        return flat.view(flat.size(0), -1)
+
+    def classify(self, flat, grad_rows=None):
+        """Linear -> LeakyReLU -> Linear (reference model/pesr.py:69-75,80) on the flattened features.  The classifier has no BatchNorm,
+        so its rows are independent: the train step hands it the features of TWO calls at once ([hr; sr]) and the 302 MB weight matrix
+        of classifier.0 is streamed once instead of twice, forward and backward (pesr_amd.step.Trainer.gan_step).  grad_rows: only the
+        first grad_rows rows need an input gradient (functional.LinearFn)."""
         fc1, act, fc2 = self.classifier
-        hidden = PF.LinearFn.apply(flat, fc1.weight, fc1.bias, ops.ACT_LRELU, act.negative_slope)
+        hidden = PF.LinearFn.apply(flat, fc1.weight, fc1.bias, ops.ACT_LRELU, act.negative_slope, grad_rows)
         return PF.LinearFn.apply(hidden, fc2.weight, fc2.bias, ops.ACT_NONE, 0.0)
+
+    PAIR_ROWS = 16   # rows per call inside a paired classifier pass: the Linear kernels add rows in chains of sixteen (linear.hip)
+
+    def classify_pair(self, fa, fb, grad_first_only=False):
+        """classify() of two calls' features in ONE pass over the weights: -> (logits of fa, logits of fb).  Each call takes a block of
+        sixteen rows (shorter batches are padded with zero rows, which add exact zeros), and the kernels sum every block as a chain of its
+        own before adding the blocks - so forward values, input gradients, weight and bias gradients are bit for bit those of two
+        separate calls.  Batches above sixteen: call classify() twice.  grad_first_only: fb came from a no_grad pass."""
+        B, R = fa.shape[0], self.PAIR_ROWS
+        assert fb.shape == fa.shape and B <= R
+        if B < R:
+            pad = fa.new_zeros((R - B, fa.shape[1]))
+            x = torch.cat([fa, pad, fb, pad])
+        else:
+            x = torch.cat([fa, fb])
+        preds = self.classify(x, grad_rows=R if grad_first_only else None)
+        return PF.SplitRowsFn.apply(preds, B, R)
+
+    def forward(self, x):
+        return self.classify(self.forward_features(x))
 
 
 def _forward_second_order(self, x):

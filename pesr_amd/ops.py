@@ -998,12 +998,16 @@ def linear_fwd(x, w, b, act=ACT_NONE, slope=0.0):
     return y
 
 
-def linear_dgrad(dy, w):
+def linear_dgrad(dy, w, out=None):
+    """out: the [M, K] tensor (or leading rows of a larger one) the gradient is written into."""
     _chk(dy, "linear_dgrad.dy")
     M, Nf = dy.shape
     K = w.shape[1]
     L = _lib.lib()
-    dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    if out is not None:
+        _chk(out, "linear_dgrad.out")
+        assert tuple(out.shape) == (M, K)
+    dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dy.device)
     FLOPS.add(2.0 * M * Nf * K, 0.0, "linear (HBM-bound, VALU)")
     for m0 in range(0, M, LIN_MAXM):
         m = min(LIN_MAXM, M - m0)

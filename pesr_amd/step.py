@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from . import functional as PF
 from .model.basic import nhwc
 from .model.focal_loss import FocalLoss
+from .model.pesr import Discriminator
 
 
 class _GlobalBatchMean(torch.autograd.Function):
@@ -76,6 +77,7 @@ class Trainer:
         self.G, self.D, self.vgg = G, D, vgg
         self.optim_G, self.optim_D = optim_G, optim_D
         self.gan_type, self.use_focal = gan_type, focal_loss
+        self.pair_classifier = os.environ.get("PESR_PAIR_CLASSIFIER", "1") != "0"   # D's classifier once per phase on [hr; sr] (gan_step)
         self.f_loss_fn = FocalLoss(fl_gamma)
         self.alpha_vgg, self.alpha_gan, self.alpha_tv, self.alpha_l1 = alpha_vgg, alpha_gan, alpha_tv, alpha_l1
         self.world_size = world_size
@@ -127,9 +129,19 @@ class Trainer:
         for p in D.parameters():
             p.requires_grad = True
         self.optim_D.zero_grad()
-        pred_real = D(hr_cl)
-        sr = G(lr)
-        pred_fake = D(sr.detach())
+        # The two calls of D keep their own BatchNorm statistics (two passes over the blocks, in the reference's order); the classifier
+        # behind them has none, so it runs ONCE on [hr; sr] (Discriminator.classify_pair): one pass over classifier.0's 302 MB instead of
+        # two - forward, input gradient and weight gradient - with results bit for bit those of the separate calls
+        # (tests/test_model_gpu.py).  (A wrapped D - nn.DataParallel replicas - and batches above 16 take the plain path.)
+        pair = self.pair_classifier and isinstance(D, Discriminator) and B <= Discriminator.PAIR_ROWS
+        if pair:
+            f_real = D.forward_features(hr_cl)
+            sr = G(lr)
+            pred_real, pred_fake = D.classify_pair(f_real, D.forward_features(sr.detach()))
+        else:
+            pred_real = D(hr_cl)
+            sr = G(lr)
+            pred_fake = D(sr.detach())
         if self.gan_type not in ("SGAN", "RSGAN", "RaSGAN"):
             raise ValueError(f"unknown gan_type {self.gan_type}")
         fused = pred_real.is_cuda and B <= 1024 and not (self.gan_type == "RaSGAN" and self.world_size > 1)
@@ -167,9 +179,15 @@ class Trainer:
         for p in D.parameters():
             p.requires_grad = False
         self.optim_G.zero_grad()
-        pred_fake = D(sr)
-        with torch.no_grad():          # D's parameters are frozen and hr needs no grad: a pure forward, as in the reference
-            pred_real = D(hr_cl)
+        if pair:
+            f_fake = D.forward_features(sr)
+            with torch.no_grad():      # D's parameters are frozen and hr needs no grad: a pure forward, as in the reference
+                f_real = D.forward_features(hr_cl)
+            pred_fake, pred_real = D.classify_pair(f_fake, f_real, grad_first_only=True)
+        else:
+            pred_fake = D(sr)
+            with torch.no_grad():      # D's parameters are frozen and hr needs no grad: a pure forward, as in the reference
+                pred_real = D(hr_cl)
         loss_fn = self.f_loss_fn if self.use_focal else F.binary_cross_entropy_with_logits
         if fused:
             G_loss = PF.gan_loss(pred_real, pred_fake, self.gan_type, 1, self.use_focal, self.f_loss_fn.gamma, self.alpha_gan)

@@ -16,9 +16,10 @@ def timeit(f, n=20):
     ts.sort()
     return ts[len(ts) // 2]
 
-def main():
+def main(M=16):
     torch.manual_seed(0)
-    M, N, K = 16, 1024, 73728
+    N, K = 1024, 73728
+    print(f"M = {M} rows")
     x = torch.rand(M, K, device="cuda") - 0.5
     w = (torch.rand(N, K, device="cuda") - 0.5) * 0.01
     b = torch.rand(N, device="cuda")
@@ -36,4 +37,5 @@ def main():
         print(f"{name:<16} back-to-back {warm:7.1f} us = {mb / warm:5.2f} TB/s ({100 * mb / warm / 6.29:5.1f} %)   after a 512 MB flush {cold:7.1f} us = {mb / cold:5.2f} TB/s ({100 * mb / cold / 6.29:5.1f} %)")
 
 if __name__ == "__main__":
-    main()
+    main(16)
+    main(32)      # the classifier on [hr; sr]: one pass over W for two of the Discriminator's calls (two 16-row MFMA tiles)

@@ -178,6 +178,31 @@ def test_gv8_two_gan_steps_vs_reference():
             adam_close(v.reshape(-1)[torch.from_numpy(g["D.idx." + k]).cuda()], g["D.val." + k], 5e-5, 2, "D." + k)
 
 
+@pytest.mark.parametrize("B", [4, 16])
+def test_paired_classifier_step_is_bit_identical_to_four_separate_calls(B):
+    """Trainer.gan_step runs D's classifier ONCE per phase on [hr; sr] (Discriminator.classify: the classifier has no BatchNorm, its rows
+    are independent; reference model/pesr.py:77-81 called four times per step, train.py:199-244).  The Linear kernels add rows in groups of
+    sixteen and a shorter batch is padded with zero rows, so the paired step must leave EXACTLY what the four separate calls leave: losses,
+    every parameter, BatchNorm running statistics - two steps, i.e. through both optimizers twice.  (Batches above 16 take the plain path.)"""
+    res = []
+    for pair in (True, False):
+        tr, G, D = _trainer(16, 2, 8)
+        tr.pair_classifier = pair
+        logs = []
+        for it in range(2):
+            lr = detrand.image_batch((B, 3, 8, 8), 300 + it).cuda()
+            hr = detrand.image_batch((B, 3, 32, 32), 400 + it).cuda()
+            log = tr.gan_step(lr, hr)
+            logs.append([float(log[k]) for k in ("l1", "vgg", "g", "tv", "d")])
+        res.append((logs, {k: v.clone() for k, v in G.state_dict().items()}, {k: v.clone() for k, v in D.state_dict().items()}))
+    (la, ga, da), (lb, gb, db) = res
+    assert la == lb, (la, lb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), "G." + k
+    for k in da:
+        assert torch.equal(da[k], db[k]), "D." + k
+
+
 def test_pretrain_step_vs_oracle():
     from model import Generator
     from pesr_amd.optim import FlatAdam

@@ -192,9 +192,11 @@ def test_conv_rgb_bn_lrelu_fused_statistics(N, H, W, C, nchw):
     assert torch.equal(y, y3) and torch.equal(stats, stats3) and torch.equal(z, z3)
 
 
-@pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (3, 70, 1000), (16, 1024, 73728), (70, 96, 2048), (5, 100, 1000), (16, 96, 4100)])
+@pytest.mark.parametrize("M,N,K", [(4, 1024, 2048), (16, 1, 1024), (3, 70, 1000), (16, 1024, 73728), (70, 96, 2048), (5, 100, 1000), (16, 96, 4100),
+                                   (32, 1024, 73728), (20, 1, 1024), (32, 130, 1000), (24, 64, 4100)])
 def test_linear(M, N, K):
-    """(70 rows: more than one 32-row kernel call - a per-GPU batch of 64 must not abort in D's classifier.)"""
+    """(70 rows: more than one 32-row kernel call - a per-GPU batch of 64 must not abort in D's classifier.  17 .. 32 rows: the two-tile forms
+    of the MFMA kernels, which the GAN step uses for the classifier on [hr; sr] - one pass over the 302 MB of weights instead of two.)"""
     from pesr_amd import ops
     x = _rand(M, K, seed=1); w = _rand(N, K, seed=2, lo=-0.01, hi=0.01); b = _rand(N, seed=3)
     ref = F.leaky_relu(F.linear(x, w, b), 0.2)
